@@ -1,0 +1,789 @@
+"""TEST INFRASTRUCTURE ONLY (oracle).  Never imported by the product package `detqmc_amd`;
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+
+CPU restatement (numpy + scipy/LAPACK zgesvd) of the reference's DetModelGC/DetSDW sweep hot
+path, following the reference algorithm literally (SVD-based UdV, checkerboard B-multiplies,
+delayed rank-MSF*D updates in the X/Y form).  Every function cites the reference file:line it
+follows; paths are relative to /root/reference/src.
+
+Pinned against the REAL reference: tests/golden/*.npz are produced by oracle/make_golden.py
+from oracle/_ref/ref_harness_o{1,2,3} (the reference sources compiled where they lie, see
+oracle/ref_build/).  tests/test_oracle_vs_golden.py checks this file against them.
+
+Conventions: matrices are numpy [row, col]; site = y*L + x (neighbortable.h:53-80); block index
+b of an n_g = MSF*N matrix selects rows/cols b*N..(b+1)*N-1; bands: even block -> XBAND,
+odd block -> YBAND (detsdwopdim.cpp:2045-2065).
+"""
+import math
+from dataclasses import dataclass, field
+import numpy as np
+import scipy.linalg as sla
+
+from dsfmt_oracle import RngWrapper
+
+XBAND, YBAND = 0, 1
+
+
+# ---------------------------------------------------------------------------------------------
+# parameters: detsdwparams.h:24-120, detsdwparams.cpp:21-140, detmodelparams.h:68-122
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class SDWParams:
+    opdim: int = 2
+    L: int = 4
+    beta: float = 2.0
+    dtau: float = 0.1
+    s: int = 10
+    r: float = -1.0
+    c: float = 3.0
+    u: float = 1.0
+    lambda_: float = 1.0
+    txhor: float = -1.0
+    txver: float = -0.5
+    tyhor: float = 0.5
+    tyver: float = 1.0
+    mu: float = -0.5
+    mux: float = None
+    muy: float = None
+    accRatio: float = 0.5
+    delaySteps: int = 16
+    bc: str = "pbc"
+    weakZflux: bool = False
+    globalShift: bool = False
+    globalUpdateInterval: int = 100
+    phi2bosons: bool = False
+    rngSeed: int = 1020304050
+    simindex: int = 0
+    # derived
+    m: int = 0
+    n: int = 0
+    N: int = 0
+
+    def finalize(self):
+        # updateTemperatureParameters (detmodelparams.h:68-122)
+        self.m = int(round(self.beta / self.dtau))
+        self.beta = self.m * self.dtau
+        while self.m <= self.s:
+            self.s -= 1
+        if self.s < 1:
+            raise ValueError("Cannot choose parameter s obeying 0 < s < m")
+        # ModelParamsDetSDW::check (detsdwparams.cpp:21-140)
+        if self.opdim not in (1, 2, 3):
+            raise ValueError("opdim")
+        if self.bc not in ("pbc", "apbc-x", "apbc-y", "apbc-xy"):
+            raise ValueError("bc")
+        if self.weakZflux and self.opdim != 2:
+            raise ValueError("Magnetic field only supported for opdim=2")
+        if self.L % 2 != 0:
+            raise ValueError("Checker board decomposition only supported for even linear lattice sizes")
+        self.N = self.L * self.L
+        if self.delaySteps <= 0 or self.delaySteps > self.N:
+            raise ValueError("delaySteps")
+        if self.globalShift and self.globalUpdateInterval == 0:
+            raise ValueError("globalUpdateInterval")
+        # createReplica (detsdwopdim.cpp:75-79)
+        if self.mux is None or self.muy is None:
+            self.mux = self.mu
+            self.muy = self.mu
+        # DetModelGC ctor (detmodel.h:518)
+        self.n = int(math.ceil(self.m / self.s))
+        return self
+
+
+class RunningAverage:
+    """RunningAverage.h:19-80."""
+
+    def __init__(self, sampleSize):
+        self.sampleSize = sampleSize
+        self.samplesAdded = 0
+        self.values = []
+        self.runningAverage = 0.0
+
+    def addValue(self, v):
+        if self.samplesAdded < self.sampleSize:
+            self.values.append(v)
+            self.runningAverage += v / self.sampleSize
+        else:
+            self.runningAverage -= self.values[0] / self.sampleSize
+            self.values.pop(0)
+            self.values.append(v)
+            self.runningAverage += v / self.sampleSize
+        self.samplesAdded += 1
+
+    def get(self):
+        return self.runningAverage
+
+
+class UdV:
+    """udv.h:40-65.  M = U diag(d) V_t^dagger."""
+
+    def __init__(self, U, d, V_t):
+        self.U, self.d, self.V_t = U, d, V_t
+
+    @staticmethod
+    def eye(n):
+        return UdV(np.eye(n, dtype=complex), np.ones(n), np.eye(n, dtype=complex))
+
+    def copy(self):
+        return UdV(self.U.copy(), self.d.copy(), self.V_t.copy())
+
+
+def udvDecompose(M):
+    """udv.h:68-90: arma::svd(U, d, V_t, M, "std") -> LAPACK zgesvd, M = U diag(d) V_t^H."""
+    U, d, Vh = sla.svd(M, full_matrices=True, lapack_driver="gesvd", check_finite=False)
+    return UdV(U, d, Vh.conj().T)
+
+
+def make_test_matrix(n):
+    """Deterministic asymmetric test matrix shared with oracle/ref_build/ref_harness.cpp."""
+    i = np.arange(n, dtype=float)[:, None]
+    j = np.arange(n, dtype=float)[None, :]
+    return np.sin(0.37 * i + 1.31 * j + 0.11 * i * j) + 1j * np.cos(0.73 * i - 0.29 * j + 0.05 * i * j)
+
+
+def replica_exchange_probability(par1, action1, par2, action2):
+    """detsdwopdim.cpp:5251-5264."""
+    delta = (par1 - par2) * (action2 - action1)
+    return 1.0 if delta <= 0.0 else math.exp(-delta)
+
+
+class DetSDWOracle:
+    # AdjustmentData constants, detsdwopdim.h:489-498
+    InitialPhiDelta = 0.5
+    AccRatioAdjustmentSamples = 100
+    phiDeltaGrowFactor = 1.05
+    phiDeltaShrinkFactor = 0.95
+
+    def __init__(self, pars: SDWParams, rng: RngWrapper = None, phi=None):
+        """DetSDW ctor, detsdwopdim.cpp:158-361."""
+        p = pars.finalize() if pars.m == 0 else pars
+        self.pars = p
+        self.rng = rng if rng is not None else RngWrapper(p.rngSeed, p.simindex + 1)  # detqmc.h:181
+        self.OPDIM = p.opdim
+        self.MSF = 4 if p.opdim == 3 else 2                                           # detsdwopdim.h:161
+        self.N, self.L, self.m, self.s, self.n = p.N, p.L, p.m, p.s, p.n
+        self.ng = self.MSF * self.N
+        self.dtau = p.dtau
+        N, m = self.N, self.m
+        self.phi = np.zeros((m + 1, N, self.OPDIM))
+        self.coshTermPhi = np.zeros((m + 1, N))
+        self.sinhTermPhi = np.zeros((m + 1, N))
+        # AdjustmentData (detsdwopdim.h:481-577) and UpdateStatistics (:285-311)
+        self.phiDelta = self.InitialPhiDelta
+        self.targetAccRatioLocal_phi = p.accRatio
+        self.lastAccRatioLocal_phi = 0.0
+        self.accRatioLocal_box_RA = RunningAverage(self.AccRatioAdjustmentSamples)
+        self.acceptedGlobalShifts = 0
+        self.attemptedGlobalShifts = 0
+        self.performedSweeps = 0
+        self._setup_lattice()
+        if phi is None:
+            self.setupRandomField()
+        else:
+            self.phi[:] = phi
+            self.updateCoshSinhTermsPhi()
+        self._setup_hopping()
+        self.g = np.zeros((self.ng, self.ng), dtype=complex)
+        self.g_inv_sv = np.zeros(self.ng)
+        self.UdVStorage = None
+        self.currentTimeslice = 0
+        self.lastSweepDir = +1  # Up
+        self.setupUdVStorage_and_calculateGreen()
+
+    # ------------------------------------------------------------------ lattice / fields
+    def _setup_lattice(self):
+        """neighbortable.h:53-80: site = y*L + x; dirs XPLUS,XMINUS,YPLUS,YMINUS."""
+        L = self.L
+        x = np.arange(self.N) % L
+        y = np.arange(self.N) // L
+        self.neigh = np.stack([
+            y * L + (x + 1) % L,
+            y * L + (x - 1 + L) % L,
+            ((y + 1) % L) * L + x,
+            ((y - 1 + L) % L) * L + x,
+        ])  # [dir, site]
+
+    def setupRandomField(self):
+        """detsdwopdim.cpp:1099-1113: k outer, site, dim; one extra rand01 per site for cdwl."""
+        rng = self.rng
+        for k in range(1, self.m + 1):
+            for site in range(self.N):
+                for dim in range(self.OPDIM):
+                    self.phi[k, site, dim] = rng.randRange(-1.0, 1.0)
+                rng.rand01()  # cdwl draw (value unused while cdwU == 0)
+        self.updateCoshSinhTermsPhi()
+
+    def getCoshSinhTermPhi(self, phivec):
+        """detsdwopdim.cpp:1132-1136."""
+        nrm = math.sqrt(float(np.dot(phivec, phivec)))
+        a = self.pars.lambda_ * self.dtau * nrm
+        return math.cosh(a), math.sinh(a) / nrm
+
+    def updateCoshSinhTermsPhi(self):
+        """detsdwopdim.cpp:1175-1181."""
+        nrm = np.sqrt(np.sum(self.phi[1:] ** 2, axis=2))
+        a = self.pars.lambda_ * self.dtau * nrm
+        self.coshTermPhi[1:] = np.cosh(a)
+        self.sinhTermPhi[1:] = np.sinh(a) / nrm
+
+    # ------------------------------------------------------------------ hopping / checkerboard
+    def _setup_hopping(self):
+        """detsdwopdim.cpp:217-260 (constants), :1598-1684 (flux 4-site exponentials),
+        :1788-1826 (no-flux plaquette factors).  Builds, per (band, kind), the list of
+        plaquette site quadruples [i,j,k,l] per subgroup and their 4x4 matrices.
+        kind: ('full'|'half', sign)."""
+        p, L, dtau = self.pars, self.L, self.dtau
+        hopHor = {XBAND: p.txhor, YBAND: p.tyhor}
+        hopVer = {XBAND: p.txver, YBAND: p.tyver}
+        self.mu_band = {XBAND: p.mux, YBAND: p.muy}
+        zmag = {XBAND: (1.0 / self.N if p.weakZflux else 0.0),       # zmag[XUP]
+                YBAND: (1.0 / self.N if p.weakZflux else 0.0)}       # zmag[YDOWN]
+        apbc_x = p.bc in ("apbc-x", "apbc-xy")
+        apbc_y = p.bc in ("apbc-y", "apbc-xy")
+        self.plaq_sites = {}
+        self.plaq_mats = {}
+        for subgroup in (0, 1):
+            quads = []
+            for i1 in range(subgroup, L, 2):          # x
+                for i2 in range(subgroup, L, 2):      # y
+                    i = i2 * L + i1
+                    j = self.neigh[0, i]
+                    k = self.neigh[2, i]
+                    l = self.neigh[0, k]
+                    quads.append((i, j, k, l, i1, i2))
+            self.plaq_sites[subgroup] = np.array([q[:4] for q in quads], dtype=np.int64)
+            for band in (XBAND, YBAND):
+                for half in (False, True):
+                    for sign in (-1, +1):
+                        mats = np.zeros((len(quads), 4, 4), dtype=complex)
+                        for idx, (i, j, k, l, i1, i2) in enumerate(quads):
+                            if not p.weakZflux:
+                                f = 0.5 if half else 1.0
+                                ch_hor = math.cosh(-f * dtau * hopHor[band])
+                                sh_hor = sign * math.sinh(-f * dtau * hopHor[band])
+                                ch_ver = math.cosh(-f * dtau * hopVer[band])
+                                sh_ver = sign * math.sinh(-f * dtau * hopVer[band])
+                                if apbc_x and i1 == L - 1:
+                                    sh_hor *= -1
+                                if apbc_y and i2 == L - 1:
+                                    sh_ver *= -1
+                                a = ch_hor * ch_ver
+                                b = ch_ver * sh_hor
+                                c = ch_hor * sh_ver
+                                d = sh_hor * sh_ver
+                                mats[idx] = [[a, b, c, d], [b, a, d, c], [c, d, a, b], [d, c, b, a]]
+                            else:
+                                hh, hv = hopHor[band], hopVer[band]
+                                if apbc_x and i1 == L - 1:
+                                    hh *= -1
+                                if apbc_y and i2 == L - 1:
+                                    hv *= -1
+                                zm = zmag[band]
+                                j1 = j % L
+                                k2 = k // L
+                                ph_ij = np.exp(1j * (-2.0 * math.pi * zm * i2))
+                                ph_kl = np.exp(1j * (-2.0 * math.pi * zm * k2))
+                                ph_ik = 1.0 + 0j
+                                ph_jl = 1.0 + 0j
+                                if i2 == L - 1:
+                                    ph_ik = np.exp(1j * (2.0 * math.pi * zm * L * i1))
+                                    ph_jl = np.exp(1j * (2.0 * math.pi * zm * L * j1))
+                                H = np.zeros((4, 4), dtype=complex)
+                                H[0, 1] = ph_ij * hh
+                                H[0, 2] = ph_ik * hv
+                                H[1, 3] = ph_jl * hv
+                                H[2, 3] = ph_kl * hh
+                                H = -(H + H.conj().T)
+                                ev, evec = np.linalg.eigh(H)
+                                pref = sign * (0.5 if half else 1.0) * dtau
+                                mats[idx] = (evec * np.exp(pref * ev)) @ evec.conj().T
+                        self.plaq_mats[(band, subgroup, half, sign)] = mats
+
+    def _apply_plaq_left(self, R, subgroup, mats):
+        """rows[i,j,k,l] <- mat . rows   (detsdwopdim.cpp:1688-1720, :1788-1826)."""
+        q = self.plaq_sites[subgroup]
+        rows = R[q]                                   # [P, 4, ncols]
+        R[q] = np.einsum("pab,pbc->pac", mats, rows)
+
+    def _apply_plaq_right(self, R, subgroup, mats):
+        """cols[i,j,k,l] <- cols . mat   (detsdwopdim.cpp:1722-1756, :1905-1943)."""
+        q = self.plaq_sites[subgroup]
+        cols = R[:, q]                                # [nrows, P, 4]
+        R[:, q] = np.einsum("rpb,pba->rpa", cols, mats)
+
+    def cbLMultHoppingExp(self, A, band, sign):
+        """detsdwopdim.cpp:1839-1869: e^{sign dtau K1/2} e^{sign dtau K0} e^{sign dtau K1/2} A."""
+        R = np.array(A, dtype=complex, copy=True)
+        self._apply_plaq_left(R, 1, self.plaq_mats[(band, 1, True, sign)])
+        self._apply_plaq_left(R, 0, self.plaq_mats[(band, 0, False, sign)])
+        self._apply_plaq_left(R, 1, self.plaq_mats[(band, 1, True, sign)])
+        return R
+
+    def cbRMultHoppingExp(self, A, band, sign):
+        """detsdwopdim.cpp:1948-1979."""
+        R = np.array(A, dtype=complex, copy=True)
+        self._apply_plaq_right(R, 1, self.plaq_mats[(band, 1, True, sign)])
+        self._apply_plaq_right(R, 0, self.plaq_mats[(band, 0, False, sign)])
+        self._apply_plaq_right(R, 1, self.plaq_mats[(band, 1, True, sign)])
+        return R
+
+    # ------------------------------------------------------------------ e^{sign dtau V} per site
+    def evMatrix(self, sign, phivec, coshT, sinhT):
+        """detsdwopdim.cpp:3188-3229 with cdwU == 0 (coshCDW=1, sinhCDW=0)."""
+        M = self.MSF
+        ev = np.zeros((M, M), dtype=complex)
+        p0 = phivec[0]
+        p1 = phivec[1] if self.OPDIM > 1 else 0.0
+        ev[0, 0] = coshT
+        ev[1, 1] = coshT
+        ev[0, 1] = sign * (p0 - 1j * p1) * sinhT
+        ev[1, 0] = sign * (p0 + 1j * p1) * sinhT
+        if self.OPDIM == 3:
+            p2 = phivec[2]
+            ev[2, 2] = coshT
+            ev[3, 3] = coshT
+            ev[0, 3] = sign * p2 * sinhT
+            ev[3, 0] = sign * p2 * sinhT
+            ev[2, 1] = -sign * p2 * sinhT
+            ev[1, 2] = -sign * p2 * sinhT
+            ev[3, 2] = sign * (p0 - 1j * p1) * sinhT
+            ev[2, 3] = sign * (p0 + 1j * p1) * sinhT
+        return ev
+
+    def _V_slice(self, sign, k):
+        """All-site version: array [MSF, MSF, N] of e^{sign dtau V(phi_k)} entries
+        (the vectors cd, cmd, mbx, mbcx, ax, max of detsdwopdim.cpp:2001-2030 / :2100-2130)."""
+        M, N = self.MSF, self.N
+        V = np.zeros((M, M, N), dtype=complex)
+        c = self.coshTermPhi[k]
+        x = self.sinhTermPhi[k]
+        p0 = self.phi[k, :, 0]
+        p1 = self.phi[k, :, 1] if self.OPDIM > 1 else np.zeros(N)
+        b = (p0 - 1j * p1) * x
+        bc = (p0 + 1j * p1) * x
+        V[0, 0] = c
+        V[1, 1] = c
+        V[0, 1] = sign * b
+        V[1, 0] = sign * bc
+        if self.OPDIM == 3:
+            ax = self.phi[k, :, 2] * x
+            V[2, 2] = c
+            V[3, 3] = c
+            V[0, 3] = sign * ax
+            V[3, 0] = sign * ax
+            V[1, 2] = -sign * ax
+            V[2, 1] = -sign * ax
+            V[3, 2] = sign * b
+            V[2, 3] = sign * bc
+        return V
+
+    def _blk(self, b):
+        return slice(b * self.N, (b + 1) * self.N)
+
+    # ------------------------------------------------------------------ B-multiplies (a10)
+    def leftMultiplyBk(self, A, k):
+        """detsdwopdim.cpp:1996-2070: B_k A, B_k = e^{-dtau V_k} diag(e^{dtau mu_band}) e^{-dtau K}."""
+        M = self.MSF
+        V = self._V_slice(-1, k)
+        T = [math.exp(self.dtau * self.mu_band[c % 2]) * self.cbLMultHoppingExp(A[self._blk(c)], c % 2, -1)
+             for c in range(M)]
+        R = np.zeros_like(A, dtype=complex)
+        for r in range(M):
+            for c in range(M):
+                R[self._blk(r)] += V[r, c][:, None] * T[c]
+        return R
+
+    def leftMultiplyBkInv(self, A, k):
+        """detsdwopdim.cpp:2095-2167: B_k^{-1} A."""
+        M = self.MSF
+        V = self._V_slice(+1, k)
+        R = np.zeros_like(A, dtype=complex)
+        for r in range(M):
+            S = np.zeros((self.N, A.shape[1]), dtype=complex)
+            for c in range(M):
+                S += V[r, c][:, None] * A[self._blk(c)]
+            S *= math.exp(-self.dtau * self.mu_band[r % 2])
+            R[self._blk(r)] = self.cbLMultHoppingExp(S, r % 2, +1)
+        return R
+
+    def rightMultiplyBk(self, A, k):
+        """detsdwopdim.cpp:2190-2303: A B_k."""
+        M = self.MSF
+        V = self._V_slice(-1, k)
+        R = np.zeros_like(A, dtype=complex)
+        for c in range(M):
+            S = np.zeros((A.shape[0], self.N), dtype=complex)
+            for r in range(M):
+                S += A[:, self._blk(r)] * V[r, c][None, :]
+            S *= math.exp(self.dtau * self.mu_band[c % 2])
+            R[:, self._blk(c)] = self.cbRMultHoppingExp(S, c % 2, -1)
+        return R
+
+    def rightMultiplyBkInv(self, A, k):
+        """detsdwopdim.cpp:2328-2402: A B_k^{-1}."""
+        M = self.MSF
+        V = self._V_slice(+1, k)
+        T = [math.exp(-self.dtau * self.mu_band[r % 2]) * self.cbRMultHoppingExp(A[:, self._blk(r)], r % 2, +1)
+             for r in range(M)]
+        R = np.zeros_like(A, dtype=complex)
+        for c in range(M):
+            for r in range(M):
+                R[:, self._blk(c)] += T[r] * V[r, c][None, :]
+        return R
+
+    # chains (a14), detsdwopdim.cpp:2076-2090, 2172-2186, 2307-2324, 2406-2420
+    def leftMultiplyBmat(self, A, k2, k1):
+        R = A
+        for k in range(k1 + 1, k2 + 1):
+            R = self.leftMultiplyBk(R, k)
+        return R
+
+    def leftMultiplyBmatInv(self, A, k2, k1):
+        R = A
+        for k in range(k2, k1, -1):
+            R = self.leftMultiplyBkInv(R, k)
+        return R
+
+    def rightMultiplyBmat(self, A, k2, k1):
+        R = A
+        for k in range(k2, k1, -1):
+            R = self.rightMultiplyBk(R, k)
+        return R
+
+    def rightMultiplyBmatInv(self, A, k2, k1):
+        R = A
+        for k in range(k1 + 1, k2 + 1):
+            R = self.rightMultiplyBkInv(R, k)
+        return R
+
+    # ------------------------------------------------------------------ Green's function (a3, a4)
+    def greenFromUdV(self, UdV_l, UdV_r):
+        """detmodel.h:769-818."""
+        VU_rl = UdV_r.V_t.conj().T @ UdV_l.U
+        UtVt_rl = UdV_r.U.conj().T @ UdV_l.V_t
+        tmp = udvDecompose(UtVt_rl + (UdV_r.d[:, None] * VU_rl) * UdV_l.d[None, :])
+        Vt_product = UdV_l.V_t @ tmp.V_t
+        U_product = UdV_r.U @ tmp.U
+        g = (Vt_product * (1.0 / tmp.d)[None, :]) @ U_product.conj().T
+        return g, tmp.d
+
+    def greenFromEye_and_UdV(self, UdV_r):
+        """detmodel.h:823-860."""
+        tmp = udvDecompose(UdV_r.U.conj().T @ UdV_r.V_t + np.diag(UdV_r.d))
+        Vt_product = UdV_r.V_t @ tmp.V_t
+        U_product = UdV_r.U @ tmp.U
+        g = (Vt_product * (1.0 / tmp.d)[None, :]) @ U_product.conj().T
+        return g, tmp.d
+
+    def setupUdVStorage_and_calculateGreen(self):
+        """detmodel.h:680-713."""
+        n, s, m = self.n, self.s, self.m
+        eye = np.eye(self.ng, dtype=complex)
+        storage = [None] * (n + 1)
+        storage[0] = UdV.eye(self.ng)
+        storage[1] = udvDecompose(self.leftMultiplyBmat(eye, s, 0))
+        for l in range(1, n):
+            k_l = s * l
+            k_lp1 = s * (l + 1) if l < n - 1 else m
+            BU = self.leftMultiplyBmat(storage[l].U, k_lp1, k_l)
+            nxt = udvDecompose(BU * storage[l].d[None, :])
+            nxt.V_t = storage[l].V_t @ nxt.V_t
+            storage[l + 1] = nxt
+        self.UdVStorage = storage
+        self.g, self.g_inv_sv = self.greenFromEye_and_UdV(storage[n])
+        self.currentTimeslice = m
+        self.lastSweepDir = +1
+
+    # ------------------------------------------------------------------ advance / wrap (a5-a7)
+    def advanceDownGreen(self, l):
+        """detmodel.h:956-1017."""
+        storage, n, s, m = self.UdVStorage, self.n, self.s, self.m
+        assert self.currentTimeslice == s * (l - 1)
+        k_l = s * l if l < n else m
+        k_lm1 = s * (l - 1)
+        if l < n:
+            st = storage[l]
+            UdV_L = udvDecompose(st.d[:, None] * self.rightMultiplyBmat(st.V_t.conj().T, k_l, k_lm1))
+            UdV_L.U = st.U @ UdV_L.U
+        else:
+            UdV_L = udvDecompose(self.rightMultiplyBmat(np.eye(self.ng, dtype=complex), k_l, k_lm1))
+        if l - 1 > 0:
+            self.g, self.g_inv_sv = self.greenFromUdV(UdV_L, storage[l - 1])
+        else:
+            self.g, self.g_inv_sv = self.greenFromEye_and_UdV(UdV_L)
+        storage[l - 1] = UdV_L
+        self.currentTimeslice = s * (l - 1)
+
+    def advanceUpGreen(self, l):
+        """detmodel.h:1109-1163."""
+        storage, n, s, m = self.UdVStorage, self.n, self.s, self.m
+        k_l = s * l
+        k_lp1 = s * (l + 1) if l < n - 1 else m
+        assert self.currentTimeslice == k_lp1
+        st = storage[l]
+        tmp = udvDecompose(self.leftMultiplyBmat(st.U, k_lp1, k_l) * st.d[None, :])
+        tmp.V_t = st.V_t @ tmp.V_t
+        if k_lp1 != m:
+            self.g, self.g_inv_sv = self.greenFromUdV(storage[l + 1], tmp)
+        else:
+            self.g, self.g_inv_sv = self.greenFromEye_and_UdV(tmp)
+        storage[l + 1] = tmp
+        self.currentTimeslice = k_lp1
+
+    def wrapDownGreen(self, k):
+        """detmodel.h:1066-1095: G <- B_k^{-1} (G B_k)."""
+        assert self.currentTimeslice == k
+        self.g = self.leftMultiplyBmatInv(self.rightMultiplyBmat(self.g, k, k - 1), k, k - 1)
+        self.currentTimeslice = k - 1
+
+    def wrapUpGreen(self, k):
+        """detmodel.h:1236-1259: G <- B_{k+1} (G B_{k+1}^{-1})."""
+        assert self.currentTimeslice == k
+        self.g = self.leftMultiplyBmat(self.rightMultiplyBmatInv(self.g, k + 1, k), k + 1, k)
+        self.currentTimeslice = k + 1
+
+    # ------------------------------------------------------------------ local updates (a17-a20)
+    def deltaSPhi(self, site, k, newphi):
+        """detsdwopdim.cpp:4186-4239."""
+        p = self.pars
+        dtau, r, u, c = self.dtau, p.r, p.u, p.c
+        z = 4
+        oldphi = self.phi[k, site]
+        phiDiff = newphi - oldphi
+        oldphiSq = float(np.dot(oldphi, oldphi))
+        newphiSq = float(np.dot(newphi, newphi))
+        phiSqDiff = newphiSq - oldphiSq
+        if p.phi2bosons:
+            return dtau * 0.5 * r * phiSqDiff
+        phiPow4Diff = newphiSq * newphiSq - oldphiSq * oldphiSq
+        m = self.m
+        kEarlier = k - 1 if k > 1 else m       # PeriodicChainNearestNeighbors over slices 1..m
+        kLater = k + 1 if k < m else 1
+        phiTimeNeigh = self.phi[kLater, site] + self.phi[kEarlier, site]
+        phiSpaceNeigh = np.zeros(self.OPDIM)
+        for d in range(4):
+            phiSpaceNeigh = phiSpaceNeigh + self.phi[k, self.neigh[d, site]]
+        delta1 = (1.0 / (c * c * dtau)) * (phiSqDiff - float(np.dot(phiTimeNeigh, phiDiff)))
+        delta2 = 0.5 * dtau * (z * phiSqDiff - 2.0 * float(np.dot(phiSpaceNeigh, phiDiff)))
+        delta3 = dtau * (0.5 * r * phiSqDiff + 0.25 * u * phiPow4Diff)
+        return delta1 + delta2 + delta3
+
+    def get_delta_forsite(self, newphi, k, site):
+        """detsdwopdim.cpp:3179-3289: e^{-dtau V_new} e^{+dtau V_old} - 1 at one site."""
+        evOld = self.evMatrix(+1, self.phi[k, site], self.coshTermPhi[k, site], self.sinhTermPhi[k, site])
+        cN, sN = self.getCoshSinhTermPhi(newphi)
+        emvNew = self.evMatrix(-1, newphi, cN, sN)
+        return emvNew @ evOld - np.eye(self.MSF)
+
+    def proposeNewPhiBox(self, site, k):
+        """detsdwopdim.cpp:3922-3931."""
+        newphi = self.phi[k, site].copy()
+        for d in range(self.OPDIM):
+            newphi[d] += self.rng.randRange(-self.phiDelta, +self.phiDelta)
+        return newphi
+
+    def updateInSlice_delayed(self, k):
+        """detsdwopdim.cpp:3023-3175."""
+        MSF, N, D = self.MSF, self.N, self.pars.delaySteps
+        g = self.g
+        accratio = 0.0
+        eyeS = np.eye(MSF)
+        site = 0
+        while site < N:
+            delayStepsNow = min(D, N - site)
+            X = np.zeros((MSF * N, MSF * delayStepsNow), dtype=complex)
+            Y = np.zeros((MSF * delayStepsNow, MSF * N), dtype=complex)
+            j = 0
+            while j < delayStepsNow and site < N:
+                newphi = self.proposeNewPhiBox(site, k)
+                probSPhi = math.exp(-self.deltaSPhi(site, k, newphi))
+                delta = self.get_delta_forsite(newphi, k, site)
+                idx = site + N * np.arange(MSF)
+                Rj = g[idx, :].copy()
+                if j > 0:
+                    Rj += X[idx, :MSF * j] @ Y[:MSF * j, :]
+                Sj = Rj[:, idx]
+                Mj = eyeS - Sj @ delta + delta
+                det = np.linalg.det(Mj)
+                if self.OPDIM == 3:
+                    probSFermion = det.real
+                else:
+                    probSFermion = abs(det) ** 2
+                prob = probSPhi * probSFermion
+                if prob > 1.0 or self.rng.rand01() < prob:
+                    accratio += 1.0
+                    self.phi[k, site] = newphi
+                    self.coshTermPhi[k, site], self.sinhTermPhi[k, site] = self.getCoshSinhTermPhi(newphi)
+                    Cj = g[:, idx].copy()
+                    if j > 0:
+                        Cj += X[:, :MSF * j] @ Y[:MSF * j, idx]
+                    Rj[np.arange(MSF), idx] -= 1.0
+                    X[:, MSF * j:MSF * (j + 1)] = Cj @ delta
+                    Y[MSF * j:MSF * (j + 1), :] = np.linalg.solve(Mj, Rj)
+                    j += 1
+                site += 1
+            if j > 0:
+                g += X[:, :MSF * j] @ Y[:MSF * j, :]
+        return accratio / N
+
+    def updateInSlice(self, k):
+        """detsdwopdim.cpp:2428-2489 (box proposals, delayed method, repeatUpdateInSlice=1)."""
+        self.lastAccRatioLocal_phi = self.updateInSlice_delayed(k)
+
+    def updateInSliceThermalization(self, k):
+        """detsdwopdim.cpp:3294-3375 (ADAPT_BOX branch)."""
+        self.updateInSlice(k)
+        ra = self.accRatioLocal_box_RA
+        ra.addValue(self.lastAccRatioLocal_phi)
+        if ra.samplesAdded % self.AccRatioAdjustmentSamples == 0:
+            avg = ra.get()
+            if avg < self.targetAccRatioLocal_phi:
+                self.phiDelta *= self.phiDeltaShrinkFactor
+            elif avg > self.targetAccRatioLocal_phi:
+                self.phiDelta *= self.phiDeltaGrowFactor
+
+    # ------------------------------------------------------------------ sweeps (a9)
+    def sweepDown(self, upd):
+        """detmodel.h:1333-1399."""
+        n, s, m = self.n, self.s, self.m
+        for k in range(m, (n - 1) * s, -1):
+            assert self.currentTimeslice == k
+            upd(k)
+            self.wrapDownGreen(k)
+        for l in range(n - 1, 0, -1):
+            self.advanceDownGreen(l + 1)
+            for k in range(l * s, (l - 1) * s, -1):
+                upd(k)
+                self.wrapDownGreen(k)
+        self.advanceDownGreen(1)
+
+    def sweepUp(self, upd):
+        """detmodel.h:1266-1325."""
+        n, s, m = self.n, self.s, self.m
+        self.UdVStorage[0] = UdV.eye(self.ng)
+        for l in range(0, n - 1):
+            for k in range(l * s + 1, (l + 1) * s + 1):
+                self.wrapUpGreen(k - 1)
+                upd(k)
+            self.advanceUpGreen(l)
+        for k in range((n - 1) * s + 1, m + 1):
+            self.wrapUpGreen(k - 1)
+            upd(k)
+        self.advanceUpGreen(n - 1)
+
+    def _sweep(self, upd):
+        """detmodel.h:1408-1478."""
+        if self.lastSweepDir == +1:
+            self.globalMove()
+            self.sweepDown(upd)
+            self.lastSweepDir = -1
+        else:
+            self.sweepUp(upd)
+            self.lastSweepDir = +1
+        self.performedSweeps += 1
+
+    def sweepThermalization(self):
+        """detsdwopdim.cpp:4474-4502."""
+        self._sweep(self.updateInSliceThermalization)
+
+    def sweep(self, takeMeasurements=False):
+        """detsdwopdim.cpp:4423-4471 (fermion measurements out of scope)."""
+        self._sweep(self.updateInSlice)
+
+    # ------------------------------------------------------------------ global shift move (a21)
+    def phiAction(self):
+        """detsdwopdim.cpp:4242-4300."""
+        p = self.pars
+        dtau, r, u, c, m = self.dtau, p.r, p.u, p.c, self.m
+        phi = self.phi
+        action = 0.0
+        for k in range(1, m + 1):
+            kprev = k - 1 if k > 1 else m
+            for site in range(self.N):
+                ph = phi[k, site]
+                if not p.phi2bosons:
+                    td = (ph - phi[kprev, site]) / dtau
+                    action += (dtau / (2.0 * c * c)) * float(np.dot(td, td))
+                    xd = ph - phi[k, self.neigh[0, site]]
+                    action += 0.5 * dtau * float(np.dot(xd, xd))
+                    yd = ph - phi[k, self.neigh[2, site]]
+                    action += 0.5 * dtau * float(np.dot(yd, yd))
+                phisq = float(np.dot(ph, ph))
+                action += 0.5 * dtau * r * phisq
+                if not p.phi2bosons:
+                    action += 0.25 * dtau * u * phisq ** 2
+        return action
+
+    def globalMove(self):
+        """detsdwopdim.cpp:3461-3486."""
+        p = self.pars
+        if self.performedSweeps % p.globalUpdateInterval == 0 and p.globalShift:
+            self.attemptGlobalShiftMove()
+
+    def attemptGlobalShiftMove(self):
+        """detsdwopdim.cpp:3565-3644, backups :3886-3917, displacement :3755-3763."""
+        old_action = self.phiAction()
+        assert self.currentTimeslice == self.m
+        bak = (self.phi.copy(), self.coshTermPhi.copy(), self.sinhTermPhi.copy(), self.g, self.g_inv_sv,
+               self.UdVStorage)
+        old_sv = self.g_inv_sv
+        for d in range(self.OPDIM):
+            rr = self.rng.randRange(-self.phiDelta, +self.phiDelta)
+            self.phi[:, :, d] += rr
+        self.updateCoshSinhTermsPhi()
+        self.setupUdVStorage_and_calculateGreen()
+        new_action = self.phiAction()
+        prob_scalar = math.exp(-(new_action - old_action))
+        log_prob = float(np.sum(np.log(self.g_inv_sv) - np.log(old_sv)))
+        prob_fermion = math.exp(log_prob)
+        if self.OPDIM < 3:
+            prob_fermion = prob_fermion ** 2
+        prob = prob_scalar * prob_fermion
+        self.attemptedGlobalShifts += 1
+        if prob >= 1.0 or self.rng.rand01() < prob:
+            self.acceptedGlobalShifts += 1
+        else:
+            (self.phi, self.coshTermPhi, self.sinhTermPhi, self.g, self.g_inv_sv, self.UdVStorage) = bak
+
+    # ------------------------------------------------------------------ replica exchange (8e)
+    def get_exchange_action_contribution(self):
+        """detsdwopdim.cpp:5205-5216."""
+        return 0.5 * self.dtau * float(np.sum(self.phi[1:] ** 2))
+
+    # ------------------------------------------------------------------ dense B (a15, checks only)
+    def computeBmatDense(self, k):
+        """detsdwopdim.cpp:1309-1497 single slice, no flux: e^{-dtau V_k} e^{-dtau K}, dense propK via
+        eig_sym (detmodel.cpp:31-39, setupPropK detsdwopdim.cpp:1210-1285)."""
+        p, N, L = self.pars, self.N, self.L
+        hop = {XBAND: (p.txhor, p.txver), YBAND: (p.tyhor, p.tyver)}
+        props = {}
+        for band in (XBAND, YBAND):
+            K = -self.mu_band[band] * np.eye(N, dtype=complex)
+            zm = (1.0 / N) if p.weakZflux else 0.0
+            for site in range(N):
+                sy, sx = divmod(site, L)
+                for d in range(4):
+                    nb = self.neigh[d, site]
+                    h = hop[band][0] if d < 2 else hop[band][1]
+                    if p.bc in ("apbc-x", "apbc-xy") and ((sx == 0 and d == 1) or (sx == L - 1 and d == 0)):
+                        h *= -1
+                    if p.bc in ("apbc-y", "apbc-xy") and ((sy == 0 and d == 3) or (sy == L - 1 and d == 2)):
+                        h *= -1
+                    ph = 1.0 + 0j
+                    if d == 0:
+                        ph = np.exp(1j * (-2.0 * math.pi * zm * sy))
+                    if d == 1:
+                        ph = np.exp(1j * (+2.0 * math.pi * zm * sy))
+                    if d == 2 and sy == L - 1:
+                        ph = np.exp(1j * (+2.0 * math.pi * zm * L * sx))
+                    if d == 3 and sy == 0:
+                        ph = np.exp(1j * (-2.0 * math.pi * zm * L * sx))
+                    K[site, nb] -= h * ph
+            ev, evec = np.linalg.eigh(K)
+            props[band] = (evec * np.exp(-self.dtau * ev)) @ evec.conj().T
+        V = self._V_slice(-1, k)
+        B = np.zeros((self.ng, self.ng), dtype=complex)
+        for r in range(self.MSF):
+            for c in range(self.MSF):
+                B[self._blk(r), self._blk(c)] = V[r, c][:, None] * props[c % 2]
+        return B

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz from the REAL reference.
+
+Runs oracle/_ref/ref_harness_o{1,2,3} (built by `make -C oracle/ref_build OPDIM=n` from the
+reference sources where they lie under /root/reference) for a fixed list of parameter sets
+and packs the raw dumps into small .npz fixtures.  The fixtures are data only: inputs
+(parameters, seeds) and the reference's outputs (fields, Green's functions, singular values).
+Run in the build container only -- the GPU box has no /root/reference and uses the committed
+fixtures.
+
+    python oracle/make_golden.py [case ...]
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+OUTDIR = os.path.join(ROOT, "tests", "golden")
+
+# name -> (harness args, keep-filter or None, subsample big matrices?)
+CASES = {
+    "o2_L4": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=4, dumpUdV=1)),
+    "o2_L4_s7": dict(args=dict(opdim=2, L=4, beta=2.3, s=7, delaySteps=16, sweeps=3)),
+    "o2_L4_flux": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, weakZflux=1)),
+    "o2_L4_apbc": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, bc="apbc-xy",
+                                 mux=-0.4, muy=-0.7, mu=-0.5, r=0.5, c=2.0, u=0.7)),
+    "o2_L4_gshift": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=6, globalShift=1,
+                                   globalUpdateInterval=2, sliceTrace=0)),
+    "o2_L6_seed": dict(args=dict(opdim=2, L=6, beta=3, s=10, delaySteps=8, sweeps=2, rngSeed=5555, simindex=3)),
+    "o1_L4": dict(args=dict(opdim=1, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
+    "o3_L4": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
+    # BASELINE config 2 (bring-up size): full G only at a few points
+    "o2_L8_b5": dict(args=dict(opdim=2, L=8, beta=5, s=10, delaySteps=16, sweeps=2),
+                     drop=("bchain_", "bdense", "bmult_leftinv", "bmult_rightinv", "slice_g_wrapped",
+                           "init_coshTermPhi", "init_sinhTermPhi")),
+    # BASELINE config 3 (headline): checksums / subsamples only
+    "o2_L16_b10": dict(args=dict(opdim=2, L=16, beta=10, s=10, delaySteps=16, sweeps=2, sliceTrace=0),
+                       drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi"),
+                       subsample=16),
+}
+
+
+def run_case(name, spec):
+    opdim = spec["args"].get("opdim", 2)
+    exe = os.path.join(REFDIR, f"ref_harness_o{opdim}")
+    if not os.path.exists(exe):
+        raise SystemExit(f"{exe} missing: run `make -C oracle/ref_build OPDIM={opdim}` first")
+    with tempfile.TemporaryDirectory() as td:
+        cmd = [exe, td] + [f"{k}={v}" for k, v in spec["args"].items()]
+        env = dict(os.environ, MKL_NUM_THREADS="1")
+        subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL)
+        arrays = {}
+        for line in open(os.path.join(td, "manifest.txt")):
+            parts = line.split()
+            nm, dt, shape = parts[0], parts[1], tuple(int(x) for x in parts[2:])
+            if any(nm.startswith(d) for d in spec.get("drop", ())):
+                continue
+            raw = np.fromfile(os.path.join(td, nm + ".bin"), dtype=np.complex128 if dt == "c16" else np.float64)
+            a = raw.reshape(shape, order="F")          # harness writes column-major
+            ss = spec.get("subsample")
+            if ss and a.ndim == 2 and dt == "c16" and a.shape[0] > 64:
+                arrays[nm + "_diag"] = np.diag(a).copy()
+                arrays[nm + "_fro"] = np.array([np.linalg.norm(a)])
+                a = a[::ss, ::ss].copy()
+                nm = nm + f"_sub{ss}"
+            arrays[nm] = np.ascontiguousarray(a)
+        arrays["params_json"] = np.array(json.dumps(spec["args"]))
+    os.makedirs(OUTDIR, exist_ok=True)
+    out = os.path.join(OUTDIR, name + ".npz")
+    np.savez_compressed(out, **arrays)
+    print(f"{name}: {len(arrays)} arrays, {os.path.getsize(out) / 1024:.0f} KiB")
+
+
+def make_rng():
+    exe = os.path.join(REFDIR, "ref_harness_o2")
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run([exe, td, "mode=rng"], check=True, stdout=subprocess.DEVNULL)
+        arrays = {}
+        for line in open(os.path.join(td, "manifest.txt")):
+            nm = line.split()[0]
+            arrays[nm] = np.fromfile(os.path.join(td, nm + ".bin"))
+    np.savez_compressed(os.path.join(OUTDIR, "rng.npz"), **arrays)
+    print("rng: ", list(arrays))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or (["rng"] + list(CASES))
+    for nm in which:
+        if nm == "rng":
+            make_rng()
+        else:
+            run_case(nm, CASES[nm])

@@ -1,0 +1,50 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))   # oracle is test infrastructure: tests may import it
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d = {k: z[k] for k in z.files}
+    d["params"] = json.loads(str(d.pop("params_json")))
+    return d
+
+
+def oracle_params(args):
+    """harness key=value args (oracle/make_golden.py) -> oracle SDWParams."""
+    from detsdw_oracle import SDWParams
+    a = dict(args)
+    kw = {}
+    for k in ("opdim", "L", "s", "delaySteps", "globalUpdateInterval"):
+        if k in a:
+            kw[k] = int(a[k])
+    for k in ("beta", "dtau", "r", "c", "u", "txhor", "txver", "tyhor", "tyver", "mu", "mux", "muy", "accRatio"):
+        if k in a:
+            kw[k] = float(a[k])
+    if "lambda" in a:
+        kw["lambda_"] = float(a["lambda"])
+    if "bc" in a:
+        kw["bc"] = a["bc"]
+    kw["weakZflux"] = bool(int(a.get("weakZflux", 0)))
+    kw["globalShift"] = bool(int(a.get("globalShift", 0)))
+    kw["rngSeed"] = int(a.get("rngSeed", 1020304050))
+    kw["simindex"] = int(a.get("simindex", 0))
+    return SDWParams(**kw)
+
+
+def relerr(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))

@@ -1,0 +1,140 @@
+"""Pins the oracle (oracle/detsdw_oracle.py, oracle/dsfmt_oracle.py) against fixtures generated
+from the REAL reference build (oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, oracle_params, relerr
+from detsdw_oracle import DetSDWOracle, make_test_matrix
+from dsfmt_oracle import RngWrapper
+
+TOL = 1e-10   # BASELINE.json north_star: 1e-10 relative for fp64
+
+SMALL = ["o2_L4", "o2_L4_s7", "o2_L4_flux", "o2_L4_apbc", "o1_L4", "o3_L4", "o2_L6_seed"]
+
+
+def test_rng_bit_exact():
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "rng.npz"))
+    for key in z.files:
+        _, seed, pidx = key.split("_")
+        r = RngWrapper(int(seed), int(pidx))
+        mine = np.array([r.rand01() for _ in range(len(z[key]))])
+        assert np.array_equal(mine, z[key]), key
+
+
+@pytest.fixture(scope="module", params=SMALL + ["o2_L8_b5"])
+def case(request):
+    g = load_golden(request.param)
+    o = DetSDWOracle(oracle_params(g["params"]))
+    return request.param, g, o
+
+
+def test_init_field_and_green(case):
+    name, g, o = case
+    # phi fixture is (N, OPDIM, m+1) col-major -> ours (m+1, N, OPDIM)
+    phi_ref = np.transpose(g["init_phi"], (2, 0, 1))
+    assert np.array_equal(o.phi[1:], phi_ref[1:]), "random field must be bit-identical (same RNG stream)"
+    if "init_coshTermPhi" in g:
+        assert relerr(o.coshTermPhi[1:], g["init_coshTermPhi"].T[1:]) < 1e-14
+        assert relerr(o.sinhTermPhi[1:], g["init_sinhTermPhi"].T[1:]) < 1e-14
+    assert relerr(o.g, g["init_g"]) < TOL
+    assert relerr(o.g_inv_sv, g["init_g_inv_sv"]) < TOL
+    d = np.stack([u.d for u in o.UdVStorage], axis=1)
+    assert np.max(np.abs(d - g["init_udv_d"]) / g["init_udv_d"]) < 1e-9
+
+
+def test_bmult(case):
+    name, g, o = case
+    A = make_test_matrix(o.ng)
+    k = int(g["bmult_k"][0])
+    assert relerr(o.leftMultiplyBk(A, k), g["bmult_left"]) < 1e-13
+    assert relerr(o.rightMultiplyBk(A, k), g["bmult_right"]) < 1e-13
+    if "bmult_leftinv" in g:
+        assert relerr(o.leftMultiplyBkInv(A, k), g["bmult_leftinv"]) < 1e-13
+        assert relerr(o.rightMultiplyBkInv(A, k), g["bmult_rightinv"]) < 1e-13
+    if "bchain_left" in g:
+        k2 = int(g["bchain_k2"][0])
+        assert relerr(o.leftMultiplyBmat(A, k2, 0), g["bchain_left"]) < 1e-12
+        assert relerr(o.leftMultiplyBmatInv(A, k2, 0), g["bchain_leftinv"]) < 1e-12
+        assert relerr(o.rightMultiplyBmat(A, k2, 0), g["bchain_right"]) < 1e-12
+        assert relerr(o.rightMultiplyBmatInv(A, k2, 0), g["bchain_rightinv"]) < 1e-12
+    if "bdense_k" in g:
+        assert relerr(o.computeBmatDense(k), g["bdense_k"]) < 1e-12
+
+
+def test_slice_and_sweeps(case):
+    """Follows the trace the harness took: one slice of delayed updates at k=m, wrap, the rest of the
+    down sweep, then full sweeps.  Same RNG stream => same Markov chain."""
+    name, g, o = case
+    m, n, s = o.m, o.n, o.s
+    o.updateInSliceThermalization(m)
+    assert np.array_equal(o.phi[m], g["slice_phi_m"]), "accept/reject decisions must agree"
+    assert relerr(o.g, g["slice_g"]) < TOL
+    assert abs(o.lastAccRatioLocal_phi - g["slice_accRatio"][0]) < 1e-15
+    o.wrapDownGreen(m)
+    if "slice_g_wrapped" in g:
+        assert relerr(o.g, g["slice_g_wrapped"]) < TOL
+    for k in range(m - 1, (n - 1) * s, -1):
+        o.updateInSliceThermalization(k)
+        o.wrapDownGreen(k)
+    for l in range(n - 1, 0, -1):
+        o.advanceDownGreen(l + 1)
+        if l == n - 1:
+            assert relerr(o.g, g["adv_g"]) < TOL
+            assert relerr(o.g_inv_sv, g["adv_g_inv_sv"]) < TOL
+        for k in range(l * s, (l - 1) * s, -1):
+            o.updateInSliceThermalization(k)
+            o.wrapDownGreen(k)
+    o.advanceDownGreen(1)
+    o.lastSweepDir = -1
+    o.performedSweeps += 1
+    i = 1
+    while f"sweep{i}_phi" in g:
+        if i > 1:
+            o.sweepThermalization()
+        phi_ref = np.transpose(g[f"sweep{i}_phi"], (2, 0, 1))
+        assert np.array_equal(o.phi[1:], phi_ref[1:]), f"sweep {i}: field trajectory diverged"
+        assert relerr(o.g, g[f"sweep{i}_g"]) < TOL
+        assert relerr(o.g_inv_sv, g[f"sweep{i}_g_inv_sv"]) < TOL
+        assert o.phiDelta == g[f"sweep{i}_phiDelta"][0]
+        assert abs(o.lastAccRatioLocal_phi - g[f"sweep{i}_lastAccRatio"][0]) < 1e-15
+        i += 1
+    assert abs(o.get_exchange_action_contribution() - g["exchange_action"][0]) < 1e-12 * abs(g["exchange_action"][0])
+    nxt = np.array([o.rng.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"]), "number of RNG draws consumed differs from the reference"
+
+
+def test_global_shift_trajectory():
+    g = load_golden("o2_L4_gshift")
+    o = DetSDWOracle(oracle_params(g["params"]))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        o.sweepThermalization()
+        phi_ref = np.transpose(g[f"sweep{i}_phi"], (2, 0, 1))
+        assert np.array_equal(o.phi[1:], phi_ref[1:]), f"sweep {i}"
+        assert relerr(o.g, g[f"sweep{i}_g"]) < TOL
+        assert o.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert o.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+        i += 1
+    assert o.attemptedGlobalShifts >= 2
+    nxt = np.array([o.rng.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"])
+
+
+def test_headline_size_checksums():
+    """BASELINE config 3 (L=16, beta=10): the reference's G is pinned through sub-samples, its
+    diagonal, Frobenius norm and singular values; the field trajectory must be identical."""
+    import time
+    g = load_golden("o2_L16_b10")
+    t0 = time.time()
+    o = DetSDWOracle(oracle_params(g["params"]))
+    assert relerr(o.g[::16, ::16], g["init_g_sub16"]) < TOL
+    assert relerr(np.diag(o.g), g["init_g_diag"]) < TOL
+    assert abs(np.linalg.norm(o.g) - g["init_g_fro"][0]) < TOL * g["init_g_fro"][0]
+    assert relerr(o.g_inv_sv, g["init_g_inv_sv"]) < TOL
+    o.sweepThermalization()
+    phi_ref = np.transpose(g["sweep1_phi"], (2, 0, 1))
+    assert np.array_equal(o.phi[1:], phi_ref[1:])
+    assert relerr(o.g[::16, ::16], g["sweep1_g_sub16"]) < TOL
+    assert relerr(np.diag(o.g), g["sweep1_g_diag"]) < TOL
+    assert relerr(o.g_inv_sv, g["sweep1_g_inv_sv"]) < TOL
+    print("oracle L=16: init + 1 sweep in %.1f s" % (time.time() - t0))
