@@ -1,0 +1,151 @@
+"""ctypes binding of the in-tree shared library (include/dqmc_hip.h + include/detsdw_host.h).
+
+There is NO fallback: if libdetqmc_amd.so is missing or cannot be loaded this module raises, and
+every compute entry point needs a GPU (dqmc_create returns DQMC_ENODEV without one).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdetqmc_amd.so")
+
+
+class DqmcError(RuntimeError):
+    """Error code from the C ABI, carrying the library's message (reference: GeneralError)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[dqmc {code}] {msg}")
+        self.code = code
+
+
+class dqmc_cplx(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+class dqmc_params(C.Structure):
+    _fields_ = [("opdim", C.c_int32), ("L", C.c_int32), ("m", C.c_int32), ("s", C.c_int32),
+                ("delaySteps", C.c_int32), ("bc", C.c_int32), ("weakZflux", C.c_int32),
+                ("phi2bosons", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+                ("dtau", C.c_double), ("r", C.c_double), ("c", C.c_double), ("u", C.c_double),
+                ("lambda_", C.c_double),
+                ("txhor", C.c_double), ("txver", C.c_double), ("tyhor", C.c_double), ("tyver", C.c_double),
+                ("mux", C.c_double), ("muy", C.c_double), ("accRatio", C.c_double)]
+
+
+class dqmc_update_state(C.Structure):
+    _fields_ = [("phiDelta", C.c_double), ("targetAccRatio", C.c_double), ("lastAccRatio", C.c_double),
+                ("ra_runningAverage", C.c_double), ("ra_values", C.c_double * 100),
+                ("ra_samplesAdded", C.c_int32), ("ra_head", C.c_int32),
+                ("rng_consumed", C.c_uint64), ("rng_avail", C.c_uint64),
+                ("error", C.c_int32), ("reserved", C.c_int32)]
+
+
+class detsdw_params(C.Structure):
+    _fields_ = [("opdim", C.c_int32), ("L", C.c_int32), ("m", C.c_int32), ("s", C.c_int32),
+                ("delaySteps", C.c_int32), ("globalShift", C.c_int32), ("globalUpdateInterval", C.c_int32),
+                ("weakZflux", C.c_int32), ("phi2bosons", C.c_int32), ("device", C.c_int32),
+                ("simindex", C.c_int32), ("rngSeed", C.c_uint32), ("has_mux_muy", C.c_int32),
+                ("updateMethod", C.c_int32), ("bc", C.c_char * 16),
+                ("beta", C.c_double), ("dtau", C.c_double),
+                ("r", C.c_double), ("c", C.c_double), ("u", C.c_double), ("lambda_", C.c_double),
+                ("txhor", C.c_double), ("txver", C.c_double), ("tyhor", C.c_double), ("tyver", C.c_double),
+                ("mu", C.c_double), ("mux", C.c_double), ("muy", C.c_double),
+                ("accRatio", C.c_double), ("cdwU", C.c_double)]
+
+
+class detsdw_info(C.Structure):
+    _fields_ = [("opdim", C.c_int32), ("L", C.c_int32), ("N", C.c_int32), ("MSF", C.c_int32),
+                ("n_g", C.c_int32), ("m", C.c_int32), ("s", C.c_int32), ("n", C.c_int32),
+                ("performedSweeps", C.c_int32), ("lastSweepDir", C.c_int32),
+                ("acceptedGlobalShifts", C.c_int32), ("attemptedGlobalShifts", C.c_int32),
+                ("currentTimeslice", C.c_int32), ("reserved", C.c_int32),
+                ("beta", C.c_double), ("dtau", C.c_double),
+                ("phiDelta", C.c_double), ("lastAccRatioLocal_phi", C.c_double), ("r", C.c_double),
+                ("rngDrawn", C.c_uint64)]
+
+
+class detsdw_control_data(C.Structure):
+    _fields_ = [("acceptedGlobalShifts", C.c_int32), ("attemptedGlobalShifts", C.c_int32),
+                ("adjust", dqmc_update_state)]
+
+
+# every symbol include/*.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_DP = C.POINTER(C.c_double)
+SYMBOLS = [
+    ("dqmc_create", C.c_int, [C.POINTER(dqmc_params), C.POINTER(_P)]),
+    ("dqmc_destroy", None, [_P]),
+    ("dqmc_last_error", C.c_char_p, []),
+    ("dqmc_synchronize", C.c_int, [_P]),
+    ("dqmc_stream", _P, [_P]),
+    ("dqmc_set_fields_host", C.c_int, [_P, _DP]),
+    ("dqmc_get_fields_host", C.c_int, [_P, _DP, _DP, _DP]),
+    ("dqmc_bmult_host", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    ("dqmc_udv_decompose_host", C.c_int, [_P, _P, _P, _DP, _P, C.POINTER(C.c_int)]),
+    ("dqmc_gemm_host", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
+    ("dqmc_udv_setup", C.c_int, [_P]),
+    ("dqmc_advance", C.c_int, [_P, C.c_int, C.c_int]),
+    ("dqmc_wrap", C.c_int, [_P, C.c_int, C.c_int]),
+    ("dqmc_reset_storage0", C.c_int, [_P]),
+    ("dqmc_push_uniforms_host", C.c_int, [_P, _DP, C.c_size_t]),
+    ("dqmc_update_slice", C.c_int, [_P, C.c_int, C.c_int]),
+    ("dqmc_get_update_state_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),
+    ("dqmc_set_update_state_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),
+    ("dqmc_get_green_host", C.c_int, [_P, _P]),
+    ("dqmc_set_green_host", C.c_int, [_P, _P, C.c_int]),
+    ("dqmc_get_sv_host", C.c_int, [_P, _DP]),
+    ("dqmc_get_udv_host", C.c_int, [_P, C.c_int, _P, _DP, _P]),
+    ("dqmc_current_timeslice", C.c_int, [_P]),
+    ("dqmc_backup", C.c_int, [_P]),
+    ("dqmc_restore", C.c_int, [_P]),
+    ("dqmc_exchange_action_host", C.c_int, [_P, _DP]),
+    ("dqmc_set_exchange_parameter", C.c_int, [_P, C.c_double]),
+    ("dqmc_profile_enable", C.c_int, [_P, C.c_int]),
+    ("dqmc_profile_read", C.c_int, [_P, _DP, C.POINTER(C.c_uint64)]),
+    ("detsdw_create", C.c_int, [C.POINTER(detsdw_params), C.POINTER(_P)]),
+    ("detsdw_destroy", None, [_P]),
+    ("detsdw_last_error", C.c_char_p, []),
+    ("detsdw_sweep", C.c_int, [_P, C.c_int]),
+    ("detsdw_sweep_thermalization", C.c_int, [_P]),
+    ("detsdw_get_info", C.c_int, [_P, C.POINTER(detsdw_info)]),
+    ("detsdw_get_phi", C.c_int, [_P, _DP]),
+    ("detsdw_set_phi", C.c_int, [_P, _DP]),
+    ("detsdw_get_green", C.c_int, [_P, _P]),
+    ("detsdw_get_green_inv_sv", C.c_int, [_P, _DP]),
+    ("detsdw_rng_rand01", C.c_double, [_P]),
+    ("detsdw_ctx", _P, [_P]),
+    ("detsdw_get_exchange_parameter_value", C.c_double, [_P]),
+    ("detsdw_set_exchange_parameter_value", C.c_int, [_P, C.c_double]),
+    ("detsdw_get_exchange_parameter_name", C.c_char_p, [_P]),
+    ("detsdw_get_exchange_action_contribution", C.c_int, [_P, _DP]),
+    ("detsdw_get_control_data", C.c_int, [_P, C.POINTER(detsdw_control_data)]),
+    ("detsdw_set_control_data", C.c_int, [_P, C.POINTER(detsdw_control_data)]),
+    ("detsdw_replica_exchange_probability", C.c_double, [C.c_double] * 4),
+    ("detsdw_rng_fill", C.c_int, [C.c_uint32, C.c_uint32, _DP, C.c_size_t]),
+]
+
+_lib = None
+
+
+def load():
+    """Load the shared library; raises if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -m detqmc_amd.build` "
+                          "(there is no CPU fallback for the DQMC kernels)")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, host=False):
+    if rc != 0:
+        lib = load()
+        msg = (lib.detsdw_last_error() if host else lib.dqmc_last_error()) or b""
+        raise DqmcError(rc, msg.decode("utf-8", "replace"))

@@ -1,0 +1,718 @@
+// C-ABI implementation (include/dqmc_hip.h): device context of one DQMC replica and the
+// stabilised-sweep building blocks of DetModelGC (reference src/detmodel.h) on top of the kernels.
+#include "dqmc_internal.h"
+#include <cmath>
+#include <complex>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+void build_tournament(int nblk, std::vector<int>& out);   // kernels_svd.hip
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                       \
+    do {                                                                                                \
+        hipError_t e_ = (x);                                                                            \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(DQMC_EHIP, std::string(#x) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + \
+                                       std::to_string(__LINE__) + ")");                                  \
+    } while (0)
+
+struct UdVSlot { cplx* U; double* d; cplx* Vt; };
+
+enum { FAM_BMULT = 0, FAM_GEMM = 1, FAM_JACOBI = 2, FAM_UPDATE = 3, FAM_OTHER = 4, FAM_COUNT = 8 };
+
+struct dqmc_ctx {
+    dqmc_params p;
+    DevModel hm;
+    hipStream_t st = nullptr;
+    int n_g = 0, MSF = 0, N = 0, m = 0, s = 0, n = 0, D = 0;
+    std::vector<void*> allocs;
+    // fields + backups
+    double *phi = nullptr, *coshT = nullptr, *sinhT = nullptr;
+    double *phi_bak = nullptr, *cosh_bak = nullptr, *sinh_bak = nullptr;
+    // Green's function, singular values of G^-1
+    cplx *G = nullptr, *G_bak = nullptr;
+    double *sv = nullptr, *sv_bak = nullptr;
+    std::vector<UdVSlot> storage, storage_bak;
+    UdVSlot spare{}, tmpudv{};
+    cplx *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *T4 = nullptr;
+    SvdWork sw{};
+    int max_jacobi_sweeps = 40;
+    int last_svd_sweeps = 0;
+    // updates
+    cplx *X = nullptr, *Gr = nullptr, *W = nullptr;
+    double* uniforms = nullptr;
+    size_t uni_cap = 0;
+    DevUpdateState* us = nullptr;
+    double* scalar_out = nullptr;
+    int currentTimeslice = 0;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, int>> ev_open;   // (family, index of begin event); end = index+1
+    size_t ev_used = 0;
+    double fam_ms[FAM_COUNT] = {0};
+    uint64_t fam_launches[FAM_COUNT] = {0};
+};
+
+template<class T>
+static int dalloc(dqmc_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, count * sizeof(T)));
+    c->allocs.push_back(q);
+    *p = (T*)q;
+    return 0;
+}
+
+struct ProfScope {
+    dqmc_ctx* c; int fam; uint64_t launches;
+    ProfScope(dqmc_ctx* c_, int fam_, uint64_t launches_) : c(c_), fam(fam_), launches(launches_) {
+        c->fam_launches[fam] += launches;
+        if (!c->prof) return;
+        if (c->ev_used + 2 > c->ev_pool.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
+        }
+        (void)hipEventRecord(c->ev_pool[c->ev_used], c->st);
+        c->ev_open.push_back({fam, (int)c->ev_used});
+        c->ev_used += 2;
+    }
+    ~ProfScope() {
+        if (!c->prof) return;
+        (void)hipEventRecord(c->ev_pool[c->ev_open.back().second + 1], c->st);
+    }
+};
+
+extern "C" const char* dqmc_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// model set-up on the host: plaquette tables (detsdwopdim.cpp:217-260, :1598-1684, :1788-1826)
+// ---------------------------------------------------------------------------------------------
+typedef std::complex<double> hc;
+
+// Hermitian 4x4 eigen-decomposition by cyclic Jacobi (replaces arma::eig_sym of :1671)
+static void herm4_exp(const hc H[4][4], double pref, hc out[4][4]) {
+    hc A[4][4], Vv[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { A[i][j] = H[i][j]; Vv[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += std::norm(A[p][q]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
+            double apq = std::abs(A[p][q]);
+            if (apq < 1e-300) continue;
+            hc ph = A[p][q] / apq;
+            double app = A[p][p].real(), aqq = A[q][q].real();
+            double zeta = (aqq - app) / (2.0 * apq);
+            double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+            double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+            // J = [[cs, sn], [-sn conj(ph), cs conj(ph)]]:  A <- A J, V <- V J, then A <- J^H A
+            for (int k = 0; k < 4; ++k) {
+                hc akp = A[k][p], akq = A[k][q];
+                A[k][p] = cs * akp - sn * std::conj(ph) * akq;
+                A[k][q] = sn * akp + cs * std::conj(ph) * akq;
+                hc vkp = Vv[k][p], vkq = Vv[k][q];
+                Vv[k][p] = cs * vkp - sn * std::conj(ph) * vkq;
+                Vv[k][q] = sn * vkp + cs * std::conj(ph) * vkq;
+            }
+            for (int k = 0; k < 4; ++k) {
+                hc apk = A[p][k], aqk = A[q][k];
+                A[p][k] = cs * apk - sn * ph * aqk;
+                A[q][k] = sn * apk + cs * ph * aqk;
+            }
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        hc acc = 0.0;
+        for (int k = 0; k < 4; ++k) acc += Vv[i][k] * std::exp(pref * A[k][k].real()) * std::conj(Vv[j][k]);
+        out[i][j] = acc;
+    }
+}
+
+static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::vector<hc>& pmats,
+                         std::vector<int>& neigh) {
+    const int L = p.L, N = L * L, P = N / 4;
+    neigh.assign(4 * N, 0);
+    for (int site = 0; site < N; ++site) {
+        int x = site % L, y = site / L;
+        neigh[0 * N + site] = y * L + (x + 1) % L;
+        neigh[1 * N + site] = y * L + (x - 1 + L) % L;
+        neigh[2 * N + site] = ((y + 1) % L) * L + x;
+        neigh[3 * N + site] = ((y - 1 + L) % L) * L + x;
+    }
+    psites.assign(2 * P * 4, 0);
+    pmats.assign((size_t)2 * 2 * 2 * P * 16, hc(0.0));
+    const double hopHor[2] = {p.txhor, p.tyhor}, hopVer[2] = {p.txver, p.tyver};
+    const bool apbc_x = (p.bc == DQMC_BC_APBC_X || p.bc == DQMC_BC_APBC_XY);
+    const bool apbc_y = (p.bc == DQMC_BC_APBC_Y || p.bc == DQMC_BC_APBC_XY);
+    const double zmag = p.weakZflux ? 1.0 / N : 0.0;    // zmag[XUP] = zmag[YDOWN] (:218-222, :1619-1620)
+    const double pi = M_PI;
+    for (int sub = 0; sub < 2; ++sub) {
+        int pidx = 0;
+        for (int i1 = sub; i1 < L; i1 += 2)
+            for (int i2 = sub; i2 < L; i2 += 2, ++pidx) {
+                int i = i2 * L + i1, j = neigh[0 * N + i], k = neigh[2 * N + i], l = neigh[0 * N + k];
+                int* ps = &psites[(sub * P + pidx) * 4];
+                ps[0] = i; ps[1] = j; ps[2] = k; ps[3] = l;
+                const bool half = (sub == 1);
+                for (int band = 0; band < 2; ++band)
+                    for (int signIdx = 0; signIdx < 2; ++signIdx) {
+                        const double sign = signIdx == 0 ? -1.0 : +1.0;
+                        hc* M = &pmats[((size_t)((band * 2 + signIdx) * 2 + sub) * P + pidx) * 16];
+                        if (!p.weakZflux) {
+                            const double f = half ? 0.5 : 1.0;
+                            double ch_hor = std::cosh(-f * p.dtau * hopHor[band]);
+                            double sh_hor = sign * std::sinh(-f * p.dtau * hopHor[band]);
+                            double ch_ver = std::cosh(-f * p.dtau * hopVer[band]);
+                            double sh_ver = sign * std::sinh(-f * p.dtau * hopVer[band]);
+                            if (apbc_x && i1 == L - 1) sh_hor *= -1;
+                            if (apbc_y && i2 == L - 1) sh_ver *= -1;
+                            double a = ch_hor * ch_ver, b = ch_ver * sh_hor, c = ch_hor * sh_ver, d = sh_hor * sh_ver;
+                            const double rows[4][4] = {{a, b, c, d}, {b, a, d, c}, {c, d, a, b}, {d, c, b, a}};
+                            for (int r = 0; r < 4; ++r) for (int q = 0; q < 4; ++q) M[r * 4 + q] = rows[r][q];
+                        } else {
+                            double hh = hopHor[band], hv = hopVer[band];
+                            if (apbc_x && i1 == L - 1) hh *= -1;
+                            if (apbc_y && i2 == L - 1) hv *= -1;
+                            int j1 = j % L, k2 = k / L;
+                            hc ph_ij = std::exp(hc(0.0, -2.0 * pi * zmag * i2));
+                            hc ph_kl = std::exp(hc(0.0, -2.0 * pi * zmag * k2));
+                            hc ph_ik = 1.0, ph_jl = 1.0;
+                            if (i2 == L - 1) {
+                                ph_ik = std::exp(hc(0.0, +2.0 * pi * zmag * L * i1));
+                                ph_jl = std::exp(hc(0.0, +2.0 * pi * zmag * L * j1));
+                            }
+                            hc H[4][4];
+                            for (int r = 0; r < 4; ++r) for (int q = 0; q < 4; ++q) H[r][q] = 0.0;
+                            H[0][1] = ph_ij * hh; H[0][2] = ph_ik * hv; H[1][3] = ph_jl * hv; H[2][3] = ph_kl * hh;
+                            hc Hh[4][4];
+                            for (int r = 0; r < 4; ++r) for (int q = 0; q < 4; ++q) Hh[r][q] = -(H[r][q] + std::conj(H[q][r]));
+                            hc E[4][4];
+                            herm4_exp(Hh, sign * (half ? 0.5 : 1.0) * p.dtau, E);
+                            for (int r = 0; r < 4; ++r) for (int q = 0; q < 4; ++q) M[r * 4 + q] = E[r][q];
+                        }
+                    }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------------------------
+static int alloc_slot(dqmc_ctx* c, UdVSlot& sl) {
+    size_t n2 = (size_t)c->n_g * c->n_g;
+    int rc;
+    if ((rc = dalloc(c, &sl.U, n2))) return rc;
+    if ((rc = dalloc(c, &sl.d, (size_t)c->n_g))) return rc;
+    if ((rc = dalloc(c, &sl.Vt, n2))) return rc;
+    return 0;
+}
+
+extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
+    if (!p || !out) return fail(DQMC_EINVAL, "null argument");
+    *out = nullptr;
+    // parameter rules of ModelParamsDetSDW::check (detsdwparams.cpp:21-140) that concern the kernels
+    if (p->opdim < 1 || p->opdim > 3) return fail(DQMC_EINVAL, "opdim must be 1, 2 or 3");
+    if (p->L < 2 || (p->L % 2) != 0)
+        return fail(DQMC_EINVAL, "Checker board decomposition only supported for even linear lattice sizes");
+    if (p->weakZflux && p->opdim != 2) return fail(DQMC_EINVAL, "Magnetic field currently only supported for opdim=2");
+    if (p->m < 2 || p->s < 1 || p->s >= p->m) return fail(DQMC_EINVAL, "need 0 < s < m");
+    const int N = p->L * p->L, MSF = p->opdim == 3 ? 4 : 2;
+    if (p->delaySteps < 1 || p->delaySteps > N) return fail(DQMC_EINVAL, "delaySteps must be in 1..N");
+    if (MSF * p->delaySteps > DQMC_MAX_WDIM) return fail(DQMC_EINVAL, "MSF*delaySteps must be <= 64 on this build");
+    if (p->bc < 0 || p->bc > 3) return fail(DQMC_EINVAL, "bc");
+    if (!(p->dtau > 0)) return fail(DQMC_EINVAL, "dtau");
+    const int ng = MSF * N;
+    if (ng > 2304) return fail(DQMC_EINVAL, "n_g > 2304 not supported by the Jacobi kernel instantiations");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DQMC_ENODEV, "no HIP device available");
+    if (p->device < 0 || p->device >= ndev) return fail(DQMC_ENODEV, "device ordinal out of range");
+    HIPCHK(hipSetDevice(p->device));
+
+    dqmc_ctx* c = new dqmc_ctx();
+    c->p = *p;
+    c->N = N; c->MSF = MSF; c->n_g = ng; c->m = p->m; c->s = p->s; c->D = p->delaySteps;
+    c->n = (p->m + p->s - 1) / p->s;       // ceil(m/s), detmodel.h:518
+    HIPCHK(hipStreamCreate(&c->st));
+
+    DevModel& hm = c->hm;
+    memset(&hm, 0, sizeof(hm));
+    hm.opdim = p->opdim; hm.MSF = MSF; hm.L = p->L; hm.N = N; hm.ng = ng; hm.m = p->m; hm.s = p->s; hm.n = c->n;
+    hm.D = p->delaySteps; hm.P = N / 4; hm.phi2bosons = p->phi2bosons;
+    hm.dtau = p->dtau; hm.r = p->r; hm.c = p->c; hm.u = p->u; hm.lambda = p->lambda;
+    hm.ov[0] = std::exp(p->dtau * p->mux); hm.ov[1] = std::exp(p->dtau * p->muy);
+    hm.ovinv[0] = std::exp(-p->dtau * p->mux); hm.ovinv[1] = std::exp(-p->dtau * p->muy);
+
+    std::vector<int> psites, neigh;
+    std::vector<hc> pmats;
+    build_tables(*p, psites, pmats, neigh);
+    int *d_psites, *d_neigh; cplx* d_pmats;
+    int rc;
+#define A_(x) if ((rc = (x))) { dqmc_destroy(c); return rc; }
+    A_(dalloc(c, &d_psites, psites.size()));
+    A_(dalloc(c, &d_neigh, neigh.size()));
+    A_(dalloc(c, &d_pmats, pmats.size()));
+    HIPCHK(hipMemcpy(d_psites, psites.data(), psites.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_neigh, neigh.data(), neigh.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_pmats, pmats.data(), pmats.size() * sizeof(hc), hipMemcpyHostToDevice));
+    hm.psites = d_psites; hm.neigh = d_neigh; hm.pmats = d_pmats;
+
+    const size_t nphi = (size_t)(p->m + 1) * p->opdim * N, ncs = (size_t)(p->m + 1) * N;
+    A_(dalloc(c, &c->phi, nphi)); A_(dalloc(c, &c->coshT, ncs)); A_(dalloc(c, &c->sinhT, ncs));
+    A_(dalloc(c, &c->phi_bak, nphi)); A_(dalloc(c, &c->cosh_bak, ncs)); A_(dalloc(c, &c->sinh_bak, ncs));
+    HIPCHK(hipMemset(c->phi, 0, nphi * sizeof(double)));
+    HIPCHK(hipMemset(c->coshT, 0, ncs * sizeof(double)));
+    HIPCHK(hipMemset(c->sinhT, 0, ncs * sizeof(double)));
+    hm.phi = c->phi; hm.coshT = c->coshT; hm.sinhT = c->sinhT;
+
+    const size_t n2 = (size_t)ng * ng;
+    A_(dalloc(c, &c->G, n2)); A_(dalloc(c, &c->G_bak, n2));
+    A_(dalloc(c, &c->sv, (size_t)ng)); A_(dalloc(c, &c->sv_bak, (size_t)ng));
+    c->storage.resize(c->n + 1); c->storage_bak.resize(c->n + 1);
+    for (int l = 0; l <= c->n; ++l) { A_(alloc_slot(c, c->storage[l])); A_(alloc_slot(c, c->storage_bak[l])); }
+    A_(alloc_slot(c, c->spare)); A_(alloc_slot(c, c->tmpudv));
+    A_(dalloc(c, &c->T1, n2)); A_(dalloc(c, &c->T2, n2)); A_(dalloc(c, &c->T3, n2)); A_(dalloc(c, &c->T4, n2));
+    A_(dalloc(c, &c->sw.A, n2)); A_(dalloc(c, &c->sw.V, n2));
+    A_(dalloc(c, &c->sw.norms, (size_t)ng)); A_(dalloc(c, &c->sw.rank, (size_t)ng)); A_(dalloc(c, &c->sw.flag, 1));
+    HIPCHK(hipHostMalloc((void**)&c->sw.hflag, sizeof(int)));
+    {
+        int bw = svd_block_cols(ng);
+        int nblk = ng / bw;
+        std::vector<int> rounds;
+        build_tournament(nblk, rounds);
+        int* d_rounds;
+        A_(dalloc(c, &d_rounds, rounds.size()));
+        HIPCHK(hipMemcpy(d_rounds, rounds.data(), rounds.size() * sizeof(int), hipMemcpyHostToDevice));
+        c->sw.rounds = d_rounds; c->sw.nrounds = nblk - 1; c->sw.nblk = nblk;
+    }
+    const int WD = MSF * c->D;
+    A_(dalloc(c, &c->X, (size_t)ng * WD)); A_(dalloc(c, &c->Gr, (size_t)WD * ng)); A_(dalloc(c, &c->W, (size_t)WD * WD));
+    c->uni_cap = (size_t)(p->opdim + 1) * N * p->m + 64;     // one sweep's worst case
+    A_(dalloc(c, &c->uniforms, c->uni_cap));
+    A_(dalloc(c, &c->us, 1));
+    A_(dalloc(c, &c->scalar_out, 8));
+#undef A_
+    DevUpdateState hus;
+    memset(&hus, 0, sizeof(hus));
+    hus.pub.phiDelta = 0.5;                 // AdjustmentData::InitialPhiDelta (detsdwopdim.h:489)
+    hus.pub.targetAccRatio = p->accRatio;
+    hus.slice_done = 1;
+    HIPCHK(hipMemcpy(c->us, &hus, sizeof(hus), hipMemcpyHostToDevice));
+    HIPCHK(hipDeviceSynchronize());
+    *out = c;
+    return DQMC_OK;
+}
+
+extern "C" void dqmc_destroy(dqmc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    if (c->st) (void)hipStreamSynchronize(c->st);
+    for (void* q : c->allocs) (void)hipFree(q);
+    if (c->sw.hflag) (void)hipHostFree(c->sw.hflag);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
+extern "C" int dqmc_synchronize(dqmc_ctx* c) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    HIPCHK(hipStreamSynchronize(c->st));
+    return DQMC_OK;
+}
+extern "C" void* dqmc_stream(dqmc_ctx* c) { return c ? (void*)c->st : nullptr; }
+
+// ---------------------------------------------------------------------------------------------
+// fields
+// ---------------------------------------------------------------------------------------------
+extern "C" int dqmc_set_fields_host(dqmc_ctx* c, const double* phi) {
+    if (!c || !phi) return fail(DQMC_EINVAL, "null argument");
+    const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N;
+    HIPCHK(hipMemcpyAsync(c->phi, phi, nphi * sizeof(double), hipMemcpyHostToDevice, c->st));
+    { ProfScope ps(c, FAM_OTHER, 1); launch_cosh_sinh(c->st, c->hm); }
+    HIPCHK(hipStreamSynchronize(c->st));
+    return DQMC_OK;
+}
+extern "C" int dqmc_get_fields_host(dqmc_ctx* c, double* phi, double* coshT, double* sinhT) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
+    HIPCHK(hipStreamSynchronize(c->st));
+    if (phi) HIPCHK(hipMemcpy(phi, c->phi, nphi * sizeof(double), hipMemcpyDeviceToHost));
+    if (coshT) HIPCHK(hipMemcpy(coshT, c->coshT, ncs * sizeof(double), hipMemcpyDeviceToHost));
+    if (sinhT) HIPCHK(hipMemcpy(sinhT, c->sinhT, ncs * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-side building blocks
+// ---------------------------------------------------------------------------------------------
+// chain order of checkerboard{Left,Right}MultiplyBmat[Inv] (detsdwopdim.cpp:2076-2090, 2172-2186,
+// 2307-2324, 2406-2420)
+static void bmult_dev(dqmc_ctx* c, int side, int inverse, int k2, int k1, cplx* A) {
+    const int count = k2 - k1;
+    if (count <= 0) return;
+    bool ascending = (side == DQMC_LEFT) ? !inverse : (bool)inverse;
+    int kfirst = ascending ? k1 + 1 : k2, kstep = ascending ? 1 : -1;
+    ProfScope ps(c, FAM_BMULT, 1);
+    launch_bmult(c->st, nullptr, c->hm, side, inverse, kfirst, kstep, count, A, c->n_g);
+}
+
+static void gemm_dev(dqmc_ctx* c, int opA, int opB, const cplx* A, const cplx* B, cplx* C,
+                     const double* kscale = nullptr, int kinv = 0, const double* rowscale = nullptr,
+                     const double* colscale = nullptr, int accumulate = 0) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = c->n_g; g.opA = opA; g.B = B; g.ldb = c->n_g; g.opB = opB; g.C = C; g.ldc = c->n_g;
+    g.M = g.N = g.K = c->n_g; g.Kmul = 1;
+    g.kscale = kscale; g.kscale_invert = kinv; g.rowscale = rowscale; g.colscale = colscale; g.accumulate = accumulate;
+    ProfScope ps(c, FAM_GEMM, 1);
+    launch_gemm(c->st, g);
+}
+
+// udvDecompose (udv.h:68-102) of diag(rowscale) M diag(colscale)
+static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, UdVSlot out) {
+    int sweeps;
+    {
+        ProfScope ps(c, FAM_JACOBI, 0);
+        sweeps = run_svd(c->st, c->n_g, M, c->n_g, colscale, rowscale, out.U, out.d, out.Vt, c->sw, c->max_jacobi_sweeps);
+        if (sweeps > 0) c->fam_launches[FAM_JACOBI] += (uint64_t)sweeps * c->sw.nrounds;
+    }
+    if (sweeps == DQMC_ENOCONV) return fail(DQMC_ENOCONV, "SVD failed (Jacobi did not converge)");
+    if (sweeps < 0) return fail(sweeps, std::string("SVD failed: ") + hipGetErrorString(hipGetLastError()));
+    c->last_svd_sweeps = sweeps;
+    return DQMC_OK;
+}
+
+// greenFromUdV (detmodel.h:769-818)
+static int green_from_udv(dqmc_ctx* c, const UdVSlot& L, const UdVSlot& R) {
+    gemm_dev(c, 1, 0, R.U, L.Vt, c->T2);                                  // UtVt_rl = U_r^H V_t_l
+    gemm_dev(c, 1, 0, R.Vt, L.U, c->T2, nullptr, 0, R.d, L.d, 1);         // += diag(d_r) (V_t_r^H U_l) diag(d_l)
+    UdVSlot t = c->tmpudv; t.d = c->sv;
+    int rc = udv_dev(c, c->T2, nullptr, nullptr, t);
+    if (rc) return rc;
+    gemm_dev(c, 0, 0, L.Vt, t.Vt, c->T3);                                 // Vt_product
+    gemm_dev(c, 0, 0, R.U, t.U, c->T4);                                   // U_product
+    gemm_dev(c, 0, 1, c->T3, c->T4, c->G, c->sv, 1);                      // G = Vt_product diag(1/sv) U_product^H
+    return DQMC_OK;
+}
+// greenFromEye_and_UdV (detmodel.h:823-860)
+static int green_from_eye(dqmc_ctx* c, const UdVSlot& R) {
+    gemm_dev(c, 1, 0, R.U, R.Vt, c->T2);
+    { ProfScope ps(c, FAM_OTHER, 1); launch_add_diag(c->st, c->T2, R.d, c->n_g); }
+    UdVSlot t = c->tmpudv; t.d = c->sv;
+    int rc = udv_dev(c, c->T2, nullptr, nullptr, t);
+    if (rc) return rc;
+    gemm_dev(c, 0, 0, R.Vt, t.Vt, c->T3);
+    gemm_dev(c, 0, 0, R.U, t.U, c->T4);
+    gemm_dev(c, 0, 1, c->T3, c->T4, c->G, c->sv, 1);
+    return DQMC_OK;
+}
+
+static int set_slot_identity(dqmc_ctx* c, UdVSlot& sl) {
+    ProfScope ps(c, FAM_OTHER, 2);
+    launch_set_identity(c->st, sl.U, c->n_g);
+    launch_set_identity(c->st, sl.Vt, c->n_g);
+    std::vector<double> ones(c->n_g, 1.0);
+    HIPCHK(hipMemcpyAsync(sl.d, ones.data(), c->n_g * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return DQMC_OK;
+}
+
+// setupUdVStorage_and_calculateGreen_skeleton (detmodel.h:680-713)
+extern "C" int dqmc_udv_setup(dqmc_ctx* c) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->p.device));
+    const int n = c->n, s = c->s, m = c->m, ng = c->n_g;
+    int rc;
+    if ((rc = set_slot_identity(c, c->storage[0]))) return rc;
+    { ProfScope ps(c, FAM_OTHER, 1); launch_set_identity(c->st, c->T1, ng); }
+    bmult_dev(c, DQMC_LEFT, 0, s, 0, c->T1);
+    if ((rc = udv_dev(c, c->T1, nullptr, nullptr, c->storage[1]))) return rc;
+    for (int l = 1; l <= n - 1; ++l) {
+        const int k_l = s * l, k_lp1 = (l < n - 1) ? s * (l + 1) : m;
+        launch_copy(c->st, c->storage[l].U, c->T1, (size_t)ng * ng);
+        bmult_dev(c, DQMC_LEFT, 0, k_lp1, k_l, c->T1);
+        UdVSlot t = c->storage[l + 1]; t.Vt = c->tmpudv.Vt;
+        if ((rc = udv_dev(c, c->T1, c->storage[l].d, nullptr, t))) return rc;
+        gemm_dev(c, 0, 0, c->storage[l].Vt, c->tmpudv.Vt, c->storage[l + 1].Vt);
+    }
+    if ((rc = green_from_eye(c, c->storage[n]))) return rc;
+    c->currentTimeslice = m;
+    return DQMC_OK;
+}
+
+extern "C" int dqmc_reset_storage0(dqmc_ctx* c) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    return set_slot_identity(c, c->storage[0]);
+}
+
+// advanceDownGreen (detmodel.h:956-1017) / advanceUpGreen (detmodel.h:1109-1163)
+extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->p.device));
+    const int n = c->n, s = c->s, m = c->m, ng = c->n_g;
+    int rc;
+    if (dir == DQMC_DOWN) {
+        if (l < 1 || l > n) return fail(DQMC_EINVAL, "advanceDown: l out of range");
+        if (c->currentTimeslice != s * (l - 1)) return fail(DQMC_EINVAL, "advanceDown: currentTimeslice != s*(l-1)");
+        const int k_l = (l < n) ? s * l : m, k_lm1 = s * (l - 1);
+        UdVSlot L = c->spare;
+        if (l < n) {
+            const UdVSlot& st = c->storage[l];
+            { ProfScope ps(c, FAM_OTHER, 1); launch_conj_transpose(c->st, st.Vt, c->T1, ng); }
+            bmult_dev(c, DQMC_RIGHT, 0, k_l, k_lm1, c->T1);
+            UdVSlot t = L; t.U = c->tmpudv.U;
+            if ((rc = udv_dev(c, c->T1, nullptr, st.d, t))) return rc;
+            gemm_dev(c, 0, 0, st.U, c->tmpudv.U, L.U);
+        } else {
+            { ProfScope ps(c, FAM_OTHER, 1); launch_set_identity(c->st, c->T1, ng); }
+            bmult_dev(c, DQMC_RIGHT, 0, k_l, k_lm1, c->T1);
+            if ((rc = udv_dev(c, c->T1, nullptr, nullptr, L))) return rc;
+        }
+        if (l - 1 > 0) rc = green_from_udv(c, L, c->storage[l - 1]);
+        else rc = green_from_eye(c, L);
+        if (rc) return rc;
+        std::swap(c->storage[l - 1], c->spare);          // storage[l-1] = UdV_L
+        c->currentTimeslice = s * (l - 1);
+        return DQMC_OK;
+    } else if (dir == DQMC_UP) {
+        if (l < 0 || l > n - 1) return fail(DQMC_EINVAL, "advanceUp: l out of range");
+        const int k_l = s * l, k_lp1 = (l < n - 1) ? s * (l + 1) : m;
+        if (c->currentTimeslice != k_lp1) return fail(DQMC_EINVAL, "advanceUp: currentTimeslice != k_{l+1}");
+        const UdVSlot& st = c->storage[l];
+        UdVSlot T = c->spare;
+        launch_copy(c->st, st.U, c->T1, (size_t)ng * ng);
+        bmult_dev(c, DQMC_LEFT, 0, k_lp1, k_l, c->T1);
+        UdVSlot t = T; t.Vt = c->tmpudv.Vt;
+        if ((rc = udv_dev(c, c->T1, st.d, nullptr, t))) return rc;
+        gemm_dev(c, 0, 0, st.Vt, c->tmpudv.Vt, T.Vt);
+        if (k_lp1 != m) rc = green_from_udv(c, c->storage[l + 1], T);
+        else rc = green_from_eye(c, T);
+        if (rc) return rc;
+        std::swap(c->storage[l + 1], c->spare);
+        c->currentTimeslice = k_lp1;
+        return DQMC_OK;
+    }
+    return fail(DQMC_EINVAL, "dir must be DQMC_UP or DQMC_DOWN");
+}
+
+// wrapUpGreen / wrapDownGreen (detmodel.h:1236-1259, 1066-1095)
+extern "C" int dqmc_wrap(dqmc_ctx* c, int dir, int k) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    if (c->currentTimeslice != k) return fail(DQMC_EINVAL, "wrap: currentTimeslice != k");
+    if (dir == DQMC_UP) {
+        if (k < 0 || k >= c->m) return fail(DQMC_EINVAL, "wrapUp: k out of range");
+        bmult_dev(c, DQMC_RIGHT, 1, k + 1, k, c->G);
+        bmult_dev(c, DQMC_LEFT, 0, k + 1, k, c->G);
+        c->currentTimeslice = k + 1;
+    } else if (dir == DQMC_DOWN) {
+        if (k < 1 || k > c->m) return fail(DQMC_EINVAL, "wrapDown: k out of range");
+        bmult_dev(c, DQMC_RIGHT, 0, k, k - 1, c->G);
+        bmult_dev(c, DQMC_LEFT, 1, k, k - 1, c->G);
+        c->currentTimeslice = k - 1;
+    } else return fail(DQMC_EINVAL, "dir must be DQMC_UP or DQMC_DOWN");
+    return DQMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// local updates
+// ---------------------------------------------------------------------------------------------
+extern "C" int dqmc_push_uniforms_host(dqmc_ctx* c, const double* u, size_t nvals) {
+    if (!c || (!u && nvals)) return fail(DQMC_EINVAL, "null argument");
+    if (nvals > c->uni_cap) {
+        double* nb;
+        HIPCHK(hipStreamSynchronize(c->st));
+        HIPCHK(hipMalloc((void**)&nb, nvals * sizeof(double)));
+        c->allocs.push_back(nb);
+        c->uniforms = nb; c->uni_cap = nvals;
+    }
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpy(c->uniforms, u, nvals * sizeof(double), hipMemcpyHostToDevice));
+    uint64_t vals[2] = {0, (uint64_t)nvals};
+    HIPCHK(hipMemcpy((char*)c->us + offsetof(DevUpdateState, pub) + offsetof(dqmc_update_state, rng_consumed), vals,
+                     sizeof(vals), hipMemcpyHostToDevice));
+    return DQMC_OK;
+}
+
+extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    if (k < 1 || k > c->m) return fail(DQMC_EINVAL, "updateInSlice: k out of range");
+    if (c->currentTimeslice != k) return fail(DQMC_EINVAL, "updateInSlice: currentTimeslice != k");
+    const int rounds = (c->N + c->D - 1) / c->D;
+    const int WD = c->MSF * c->D;
+    for (int r = 0; r < rounds; ++r) {
+        {
+            ProfScope ps(c, FAM_UPDATE, 2);
+            launch_update_decide(c->st, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, thermalization);
+            launch_update_gather(c->st, c->hm, c->us, c->G, c->W, c->X, c->Gr);
+        }
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = c->X; g.lda = c->n_g; g.opA = 0; g.B = c->Gr; g.ldb = WD; g.opB = 0; g.C = c->G; g.ldc = c->n_g;
+        g.M = g.N = c->n_g; g.K = WD; g.Kdev = &c->us->block_j; g.Kmul = c->MSF; g.accumulate = 1;
+        ProfScope ps(c, FAM_GEMM, 1);
+        launch_gemm(c->st, g);
+    }
+    return DQMC_OK;
+}
+
+extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpy(out, &c->us->pub, sizeof(*out), hipMemcpyDeviceToHost));
+    if (out->error) return fail(out->error, "device ran out of pre-drawn uniforms");
+    return DQMC_OK;
+}
+extern "C" int dqmc_set_update_state_host(dqmc_ctx* c, const dqmc_update_state* in) {
+    if (!c || !in) return fail(DQMC_EINVAL, "null argument");
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpy(&c->us->pub, in, sizeof(*in), hipMemcpyHostToDevice));
+    return DQMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-buffer entry points (tests, measurements, global moves)
+// ---------------------------------------------------------------------------------------------
+extern "C" int dqmc_bmult_host(dqmc_ctx* c, int side, int inverse, int k2, int k1, dqmc_cplx* A) {
+    if (!c || !A) return fail(DQMC_EINVAL, "null argument");
+    if (!(k2 > k1) || k2 > c->m || k1 < 0) return fail(DQMC_EINVAL, "need 0 <= k1 < k2 <= m");
+    const size_t n2 = (size_t)c->n_g * c->n_g;
+    HIPCHK(hipMemcpyAsync(c->T1, A, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
+    bmult_dev(c, side, inverse, k2, k1, c->T1);
+    HIPCHK(hipMemcpyAsync(A, c->T1, n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    return DQMC_OK;
+}
+
+extern "C" int dqmc_udv_decompose_host(dqmc_ctx* c, const dqmc_cplx* M, dqmc_cplx* U, double* d, dqmc_cplx* V_t,
+                                       int* sweeps_used) {
+    if (!c || !M || !U || !d || !V_t) return fail(DQMC_EINVAL, "null argument");
+    const size_t n2 = (size_t)c->n_g * c->n_g;
+    HIPCHK(hipMemcpyAsync(c->T1, M, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
+    int rc = udv_dev(c, c->T1, nullptr, nullptr, c->tmpudv);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpy(U, c->tmpudv.U, n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(d, c->tmpudv.d, c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(V_t, c->tmpudv.Vt, n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    if (sweeps_used) *sweeps_used = c->last_svd_sweeps;
+    return DQMC_OK;
+}
+
+extern "C" int dqmc_gemm_host(dqmc_ctx* c, int opA, int opB, const dqmc_cplx* A, const dqmc_cplx* B, dqmc_cplx* C) {
+    if (!c || !A || !B || !C) return fail(DQMC_EINVAL, "null argument");
+    const size_t n2 = (size_t)c->n_g * c->n_g;
+    HIPCHK(hipMemcpyAsync(c->T1, A, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->T2, B, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
+    gemm_dev(c, opA, opB, c->T1, c->T2, c->T3);
+    HIPCHK(hipMemcpyAsync(C, c->T3, n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    return DQMC_OK;
+}
+
+extern "C" int dqmc_get_green_host(dqmc_ctx* c, dqmc_cplx* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpy(out, c->G, (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+extern "C" int dqmc_set_green_host(dqmc_ctx* c, const dqmc_cplx* in, int currentTimeslice) {
+    if (!c || !in) return fail(DQMC_EINVAL, "null argument");
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpy(c->G, in, (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyHostToDevice));
+    c->currentTimeslice = currentTimeslice;
+    return DQMC_OK;
+}
+extern "C" int dqmc_get_sv_host(dqmc_ctx* c, double* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpy(out, c->sv, c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+extern "C" int dqmc_get_udv_host(dqmc_ctx* c, int l, dqmc_cplx* U, double* d, dqmc_cplx* V_t) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    if (l < 0 || l > c->n) return fail(DQMC_EINVAL, "l out of range");
+    const size_t n2 = (size_t)c->n_g * c->n_g;
+    HIPCHK(hipStreamSynchronize(c->st));
+    if (U) HIPCHK(hipMemcpy(U, c->storage[l].U, n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    if (d) HIPCHK(hipMemcpy(d, c->storage[l].d, c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    if (V_t) HIPCHK(hipMemcpy(V_t, c->storage[l].Vt, n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+extern "C" int dqmc_current_timeslice(dqmc_ctx* c) { return c ? c->currentTimeslice : -1; }
+
+// globalMoveStoreBackups / RestoreBackups (detsdwopdim.cpp:3886-3917): the matrices that are fully
+// recomputed by the move are swapped, the fields copied
+static void swap_state(dqmc_ctx* c) {
+    std::swap(c->G, c->G_bak);
+    std::swap(c->sv, c->sv_bak);
+    std::swap(c->storage, c->storage_bak);
+}
+extern "C" int dqmc_backup(dqmc_ctx* c) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
+    HIPCHK(hipMemcpyAsync(c->phi_bak, c->phi, nphi * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->cosh_bak, c->coshT, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->sinh_bak, c->sinhT, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    swap_state(c);
+    return DQMC_OK;
+}
+extern "C" int dqmc_restore(dqmc_ctx* c) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
+    HIPCHK(hipMemcpyAsync(c->phi, c->phi_bak, nphi * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->coshT, c->cosh_bak, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->sinhT, c->sinh_bak, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    swap_state(c);
+    c->currentTimeslice = c->m;
+    return DQMC_OK;
+}
+
+extern "C" int dqmc_exchange_action_host(dqmc_ctx* c, double* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    { ProfScope ps(c, FAM_OTHER, 1); launch_phi_sq_sum(c->st, c->hm, c->scalar_out); }
+    HIPCHK(hipStreamSynchronize(c->st));
+    double v;
+    HIPCHK(hipMemcpy(&v, c->scalar_out, sizeof(double), hipMemcpyDeviceToHost));
+    *out = 0.5 * c->p.dtau * v;
+    return DQMC_OK;
+}
+
+extern "C" int dqmc_set_exchange_parameter(dqmc_ctx* c, double r) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    c->p.r = r;
+    c->hm.r = r;     // kernels receive the model by value at every launch
+    return DQMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------------------------
+static void prof_collect(dqmc_ctx* c) {
+    (void)hipStreamSynchronize(c->st);
+    for (auto& o : c->ev_open) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[o.second], c->ev_pool[o.second + 1]) == hipSuccess)
+            c->fam_ms[o.first] += ms;
+    }
+    c->ev_open.clear();
+    c->ev_used = 0;
+}
+extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    prof_collect(c);
+    c->prof = on != 0;
+    for (int i = 0; i < FAM_COUNT; ++i) { c->fam_ms[i] = 0; c->fam_launches[i] = 0; }
+    return DQMC_OK;
+}
+extern "C" int dqmc_profile_read(dqmc_ctx* c, double ms[8], uint64_t launches[8]) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    prof_collect(c);
+    for (int i = 0; i < FAM_COUNT; ++i) { if (ms) ms[i] = c->fam_ms[i]; if (launches) launches[i] = c->fam_launches[i]; }
+    return DQMC_OK;
+}

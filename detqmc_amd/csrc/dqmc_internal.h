@@ -1,0 +1,85 @@
+// Internal declarations shared by the HIP kernels and the C-ABI implementation.
+// Not part of the public boundary (that is include/dqmc_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dqmc_hip.h"
+
+typedef double2 cplx;   // .x = re, .y = im; same bytes as dqmc_cplx / std::complex<double>
+
+#define DQMC_MAX_MSF 4
+#define DQMC_MAX_WDIM 64          // MSF * delaySteps <= 64 (W lives in LDS in the decision kernel)
+
+// Everything a kernel needs to know about the model; lives in device memory, one per context.
+struct DevModel {
+    int opdim, MSF, L, N, ng, m, s, n, D, P;   // P = plaquettes per subgroup = N/4
+    int phi2bosons;
+    double dtau, r, c, u, lambda;
+    double ov[2];      // e^{+dtau mu_band}   (detsdwopdim.cpp:2037-2038)
+    double ovinv[2];   // e^{-dtau mu_band}   (detsdwopdim.cpp:2137-2138)
+    // plaquette sites [sub][P][4] (sub 0: even corners, sub 1: odd corners; detsdwopdim.cpp:1776-1785)
+    const int* psites;
+    // 4x4 complex plaquette exponentials [band][signIdx][sub][P][16] row-major; sub 1 holds the
+    // half-step matrices, sub 0 the full-step ones (symmetric break-up, detsdwopdim.cpp:1846-1865);
+    // signIdx 0: e^{-dtau K}, 1: e^{+dtau K}
+    const cplx* pmats;
+    // fields
+    double* phi;       // [m+1][opdim][N]
+    double* coshT;     // [m+1][N]
+    double* sinhT;     // [m+1][N]
+    const int* neigh;  // [4][N]  XPLUS, XMINUS, YPLUS, YMINUS (neighbortable.h:34-36)
+};
+
+struct DevUpdateState {
+    dqmc_update_state pub;   // mirrored to the host on request
+    int site_cursor;         // next site to be proposed in the current slice
+    int acc_count;           // accepted proposals in the current slice
+    int block_j;             // accepted updates in the block the last decision launch produced
+    int slice_done;
+    int block_sites[DQMC_MAX_WDIM];
+};
+
+// ---- launchers (implemented in the kernels_*.hip files) ---------------------------------------
+// checkerboard chain: A <- prod B_k A etc. for k = kfirst, kfirst+kstep, ... (count slices)
+void launch_bmult(hipStream_t st, const DevModel* dm, const DevModel& hm, int side, int inverse,
+                  int kfirst, int kstep, int kcount, cplx* A, int lda);
+
+// C = alpha-less complex GEMM on MFMA f64: C[MxN] (+)= op(A)[MxK] . diag(kscale) . op(B)[KxN]
+struct GemmArgs {
+    const cplx* A; int lda; int opA;      // op: 0 = N, 1 = conjugate transpose
+    const cplx* B; int ldb; int opB;
+    cplx* C; int ldc;
+    int M, N, K;
+    const int* Kdev;            // if non-null: K = min(K, *Kdev * Kmul) read on the device
+    int Kmul;
+    const double* kscale;       // optional scale of the contraction index
+    int kscale_invert;          // use 1/kscale
+    const double* rowscale;     // optional epilogue: acc *= rowscale[i] * colscale[j]
+    const double* colscale;
+    int accumulate;             // C += instead of C =
+};
+void launch_gemm(hipStream_t st, const GemmArgs& a);
+
+// one-sided Jacobi SVD, M = U diag(d) V^H, d descending.  work: A (n*n), V (n*n), norms(n), rank(n),
+// flag (int).  Host-driven sweep loop with one flag read-back per sweep.  Returns sweeps used or <0.
+struct SvdWork {
+    cplx* A; cplx* V; double* norms; int* rank; int* flag; int* hflag /*pinned host*/;
+    const int* rounds; int nrounds; int nblk;   // tournament table [nrounds][nblk/2][2]
+};
+int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscale, const double* rowscale,
+            cplx* U, double* d, cplx* Vt, const SvdWork& w, int max_sweeps);
+int svd_block_cols(int n);      // columns per block used by the Jacobi kernel for this n
+
+// local updates
+void launch_update_decide(hipStream_t st, const DevModel* dm, const DevModel& hm, DevUpdateState* us,
+                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal);
+void launch_update_gather(hipStream_t st, const DevModel& hm, const DevUpdateState* us, const cplx* G,
+                          const cplx* W, cplx* X, cplx* Gr);
+
+// misc elementwise
+void launch_cosh_sinh(hipStream_t st, const DevModel& hm);
+void launch_set_identity(hipStream_t st, cplx* A, int n);
+void launch_conj_transpose(hipStream_t st, const cplx* A, cplx* B, int n);
+void launch_add_diag(hipStream_t st, cplx* A, const double* d, int n);
+void launch_copy(hipStream_t st, const cplx* A, cplx* B, size_t count);
+void launch_phi_sq_sum(hipStream_t st, const DevModel& hm, double* out);

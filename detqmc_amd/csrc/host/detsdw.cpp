@@ -1,0 +1,338 @@
+// Host control flow of one SDW replica (see detsdw.h).  Mirrors, function by function:
+//   createReplica / updateTemperatureParameters / ModelParamsDetSDW::check
+//       src/detsdwopdim.cpp:49-84, src/detmodelparams.h:68-122, src/detsdwparams.cpp:21-140
+//   DetSDW ctor, setupRandomField                      src/detsdwopdim.cpp:158-361, 1099-1113
+//   sweep_skeleton / sweepThermalization_skeleton      src/detmodel.h:1408-1478
+//   sweepDown / sweepUp                                src/detmodel.h:1333-1399 / 1266-1325
+//   globalMove / attemptGlobalShiftMove / phiAction    src/detsdwopdim.cpp:3461-3486, 3565-3644, 4242-4300
+// All numerics go through the C ABI in include/dqmc_hip.h.
+#include "detsdw.h"
+#include <cmath>
+#include <cstring>
+
+namespace detqmc {
+
+void DetSDW::check(int rc, const char* what) {
+    if (rc != DQMC_OK) throw GeneralError(rc, std::string(what) + ": " + dqmc_last_error());
+}
+
+DetSDW::DetSDW(const detsdw_params& in) : pars_(in), rng_(in.rngSeed, (uint32_t)in.simindex + 1u) {   // detqmc.h:181
+    detsdw_params& p = pars_;
+    // --- updateTemperatureParameters (detmodelparams.h:68-122) ---
+    if (!(p.dtau > 0)) throw ParameterWrong("Parameter dtau has incorrect value");
+    if (p.s <= 0) throw ParameterWrong("Parameter s has incorrect value");
+    if (p.beta > 0 && p.m > 0) throw ParameterWrong("Only specify one of the parameters beta and m");
+    if (!(p.beta > 0) && p.m <= 0) throw ParameterWrong("Specify either parameter m or beta");
+    if (p.m > 0) {
+        p.beta = p.m * p.dtau;
+    } else {
+        p.m = (int32_t)std::round(p.beta / p.dtau);
+        p.beta = p.m * p.dtau;
+    }
+    while (p.m <= p.s) p.s -= 1;
+    if (p.s < 1) throw ParameterWrong("Cannot choose parameter s obeying 0 < s < m");
+    // --- ModelParamsDetSDW::check (detsdwparams.cpp:21-140) ---
+    if (!(p.opdim == 1 || p.opdim == 2 || p.opdim == 3)) throw ParameterWrong("Parameter opdim has incorrect value");
+    const std::string bc(p.bc[0] ? p.bc : "pbc");
+    int bcv;
+    if (bc == "pbc") bcv = DQMC_BC_PBC;
+    else if (bc == "apbc-x") bcv = DQMC_BC_APBC_X;
+    else if (bc == "apbc-y") bcv = DQMC_BC_APBC_Y;
+    else if (bc == "apbc-xy") bcv = DQMC_BC_APBC_XY;
+    else throw ParameterWrong("Parameter bc has incorrect value: " + bc);
+    if (p.weakZflux && p.opdim != 2)
+        throw ParameterWrong("Magnetic field specified for opdim=" + std::to_string(p.opdim) +
+                             ", but currently only supported for opdim=2");
+    if (p.updateMethod < 0 || p.updateMethod > 2) throw ParameterWrong("Parameter updateMethod has incorrect value");
+    const int N = p.L * p.L;
+    if (p.updateMethod == 2 && (p.delaySteps <= 0 || p.delaySteps > N))
+        throw ParameterWrong("Parameter delaySteps has incorrect value");
+    if (p.globalShift && p.globalUpdateInterval == 0) throw ParameterWrong("Parameter globalUpdateInterval has incorrect value");
+    if (p.L % 2 != 0) throw ParameterWrong("Checker board decomposition only supported for even linear lattice sizes");
+    if (p.cdwU != 0.0) throw ParameterWrong("cdwU != 0 is not supported by this build");
+    // createReplica (detsdwopdim.cpp:75-79)
+    if (!p.has_mux_muy) { p.mux = p.mu; p.muy = p.mu; }
+
+    N_ = N; opdim_ = p.opdim; MSF_ = (p.opdim == 3) ? 4 : 2; ng_ = MSF_ * N_;
+    m_ = p.m; s_ = p.s; n_ = (m_ + s_ - 1) / s_;
+
+    dqmc_params kp;
+    std::memset(&kp, 0, sizeof(kp));
+    kp.opdim = p.opdim; kp.L = p.L; kp.m = p.m; kp.s = p.s;
+    // iterative / woodbury update the Green's function after every accepted proposal: D = 1
+    kp.delaySteps = (p.updateMethod == 2) ? p.delaySteps : 1;
+    kp.bc = bcv; kp.weakZflux = p.weakZflux; kp.phi2bosons = p.phi2bosons; kp.device = p.device;
+    kp.dtau = p.dtau; kp.r = p.r; kp.c = p.c; kp.u = p.u; kp.lambda = p.lambda;
+    kp.txhor = p.txhor; kp.txver = p.txver; kp.tyhor = p.tyhor; kp.tyver = p.tyver;
+    kp.mux = p.mux; kp.muy = p.muy; kp.accRatio = p.accRatio;
+    check(dqmc_create(&kp, &ctx_), "dqmc_create");
+
+    phi_.assign((size_t)N_ * opdim_ * (m_ + 1), 0.0);
+    setupRandomField();
+    check(dqmc_set_fields_host(ctx_, phi_.data()), "dqmc_set_fields_host");
+    setupUdVStorage_and_calculateGreen();
+}
+
+DetSDW::~DetSDW() { dqmc_destroy(ctx_); }
+
+// detsdwopdim.cpp:1099-1113: k outer, site, dim; one more draw per site for the (unused) cdwl field
+void DetSDW::setupRandomField() {
+    for (int k = 1; k <= m_; ++k)
+        for (int site = 0; site < N_; ++site) {
+            for (int dim = 0; dim < opdim_; ++dim) phi(site, dim, k) = rng_.randRange(-1.0, 1.0);
+            (void)rng_.rand01();
+        }
+}
+
+void DetSDW::setupUdVStorage_and_calculateGreen() {
+    check(dqmc_udv_setup(ctx_), "setupUdVStorage_and_calculateGreen");
+    lastSweepDir_ = Up;                                    // detmodel.h:711
+}
+
+// Ship the worst-case number of upcoming uniforms of this sweep; the device consumes a prefix.
+void DetSDW::beginLocalUpdates() {
+    const size_t need = (size_t)(opdim_ + 1) * N_ * m_;
+    const double* w = rng_.peek(need);
+    check(dqmc_push_uniforms_host(ctx_, w, need), "dqmc_push_uniforms_host");
+}
+void DetSDW::endLocalUpdates() {
+    dqmc_update_state st;
+    check(dqmc_get_update_state_host(ctx_, &st), "dqmc_get_update_state_host");
+    rng_.consume((size_t)st.rng_consumed);
+    phiDelta_ = st.phiDelta;
+    lastAccRatio_ = st.lastAccRatio;
+}
+
+void DetSDW::updateInSlice(int k, bool thermalization) {
+    check(dqmc_update_slice(ctx_, k, thermalization ? 1 : 0), "updateInSlice");
+}
+
+// detmodel.h:1333-1399
+void DetSDW::sweepDown(bool thermalization) {
+    for (int k = m_; k >= (n_ - 1) * s_ + 1; --k) {
+        updateInSlice(k, thermalization);
+        check(dqmc_wrap(ctx_, DQMC_DOWN, k), "wrapDownGreen");
+    }
+    for (int l = n_ - 1; l >= 1; --l) {
+        check(dqmc_advance(ctx_, DQMC_DOWN, l + 1), "advanceDownGreen");
+        for (int k = l * s_; k >= (l - 1) * s_ + 1; --k) {
+            updateInSlice(k, thermalization);
+            check(dqmc_wrap(ctx_, DQMC_DOWN, k), "wrapDownGreen");
+        }
+    }
+    check(dqmc_advance(ctx_, DQMC_DOWN, 1), "advanceDownGreen");
+}
+
+// detmodel.h:1266-1325
+void DetSDW::sweepUp(bool thermalization) {
+    check(dqmc_reset_storage0(ctx_), "reset storage[0]");
+    for (int l = 0; l <= n_ - 2; ++l) {
+        for (int k = l * s_ + 1; k <= (l + 1) * s_; ++k) {
+            check(dqmc_wrap(ctx_, DQMC_UP, k - 1), "wrapUpGreen");
+            updateInSlice(k, thermalization);
+        }
+        check(dqmc_advance(ctx_, DQMC_UP, l), "advanceUpGreen");
+    }
+    for (int k = (n_ - 1) * s_ + 1; k <= m_; ++k) {
+        check(dqmc_wrap(ctx_, DQMC_UP, k - 1), "wrapUpGreen");
+        updateInSlice(k, thermalization);
+    }
+    check(dqmc_advance(ctx_, DQMC_UP, n_ - 1), "advanceUpGreen");
+}
+
+// detmodel.h:1408-1478 and detsdwopdim.cpp:4423-4502
+void DetSDW::sweep_skeleton(bool thermalization) {
+    if (lastSweepDir_ == Up) {
+        globalMove();
+        beginLocalUpdates();
+        sweepDown(thermalization);
+        endLocalUpdates();
+        lastSweepDir_ = Down;
+    } else {
+        beginLocalUpdates();
+        sweepUp(thermalization);
+        endLocalUpdates();
+        lastSweepDir_ = Up;
+    }
+    ++performedSweeps_;
+}
+
+void DetSDW::sweep(bool /*takeMeasurements*/) { sweep_skeleton(false); }
+void DetSDW::sweepThermalization() { sweep_skeleton(true); }
+
+// detsdwopdim.cpp:3461-3486
+void DetSDW::globalMove() {
+    if (pars_.globalShift && pars_.globalUpdateInterval > 0 &&
+        performedSweeps_ % pars_.globalUpdateInterval == 0)
+        attemptGlobalShiftMove();
+}
+
+void DetSDW::syncPhiFromDevice() {
+    check(dqmc_get_fields_host(ctx_, phi_.data(), nullptr, nullptr), "dqmc_get_fields_host");
+}
+
+// detsdwopdim.cpp:4242-4300
+double DetSDW::phiAction() const {
+    const double dtau = pars_.dtau, r = pars_.r, u = pars_.u, c = pars_.c;
+    const int L = pars_.L;
+    double action = 0.0;
+    for (int k = 1; k <= m_; ++k) {
+        const int kprev = (k > 1) ? k - 1 : m_;
+        for (int site = 0; site < N_; ++site) {
+            const int x = site % L, y = site / L;
+            const int xn = y * L + (x + 1) % L, yn = ((y + 1) % L) * L + x;
+            double phisq = 0.0;
+            if (!pars_.phi2bosons) {
+                double td2 = 0.0, xd2 = 0.0, yd2 = 0.0;
+                for (int d = 0; d < opdim_; ++d) {
+                    const double ph = phi(site, d, k);
+                    const double td = (ph - phi(site, d, kprev)) / dtau;
+                    td2 += td * td;
+                    const double xd = ph - phi(xn, d, k);
+                    xd2 += xd * xd;
+                    const double yd = ph - phi(yn, d, k);
+                    yd2 += yd * yd;
+                }
+                action += (dtau / (2.0 * c * c)) * td2;
+                action += 0.5 * dtau * xd2;
+                action += 0.5 * dtau * yd2;
+            }
+            for (int d = 0; d < opdim_; ++d) phisq += phi(site, d, k) * phi(site, d, k);
+            action += 0.5 * dtau * r * phisq;
+            if (!pars_.phi2bosons) action += 0.25 * dtau * u * phisq * phisq;
+        }
+    }
+    return action;
+}
+
+// detsdwopdim.cpp:3565-3644
+void DetSDW::attemptGlobalShiftMove() {
+    syncPhiFromDevice();
+    dqmc_update_state st;
+    check(dqmc_get_update_state_host(ctx_, &st), "dqmc_get_update_state_host");
+    phiDelta_ = st.phiDelta;
+    const double old_scalar_action = phiAction();
+    std::vector<double> old_sv(ng_), new_sv(ng_);
+    check(dqmc_get_sv_host(ctx_, old_sv.data()), "dqmc_get_sv_host");
+    check(dqmc_backup(ctx_), "globalMoveStoreBackups");
+    std::vector<double> phi_backup = phi_;
+    // addGlobalRandomDisplacement (:3755-3763): all slices (incl. the unused slice 0) shifted
+    for (int dim = 0; dim < opdim_; ++dim) {
+        const double rr = rng_.randRange(-phiDelta_, +phiDelta_);
+        for (int k = 0; k <= m_; ++k)
+            for (int site = 0; site < N_; ++site) phi(site, dim, k) += rr;
+    }
+    check(dqmc_set_fields_host(ctx_, phi_.data()), "updateCoshSinhTermsPhi");
+    setupUdVStorage_and_calculateGreen();
+    const double new_scalar_action = phiAction();
+    const double prob_scalar = std::exp(-(new_scalar_action - old_scalar_action));
+    check(dqmc_get_sv_host(ctx_, new_sv.data()), "dqmc_get_sv_host");
+    double log_prob = 0.0;
+    for (int j = 0; j < ng_; ++j) log_prob += std::log(new_sv[j]) - std::log(old_sv[j]);
+    double prob_fermion = std::exp(log_prob);
+    if (opdim_ < 3) prob_fermion = prob_fermion * prob_fermion;
+    const double prob = prob_scalar * prob_fermion;
+    attemptedGlobalShifts_ += 1;
+    if (prob >= 1.0 || rng_.rand01() < prob) {
+        acceptedGlobalShifts_ += 1;
+    } else {
+        check(dqmc_restore(ctx_), "globalMoveRestoreBackups");
+        phi_ = phi_backup;
+    }
+}
+
+void DetSDW::set_exchange_parameter_value(double r) {
+    pars_.r = r;
+    check(dqmc_set_exchange_parameter(ctx_, r), "set_exchange_parameter_value");
+}
+double DetSDW::get_exchange_action_contribution() {
+    double v = 0.0;
+    check(dqmc_exchange_action_host(ctx_, &v), "get_exchange_action_contribution");
+    return v;
+}
+void DetSDW::get_control_data(detsdw_control_data& out) {
+    out.acceptedGlobalShifts = acceptedGlobalShifts_;
+    out.attemptedGlobalShifts = attemptedGlobalShifts_;
+    check(dqmc_get_update_state_host(ctx_, &out.adjust), "get_control_data");
+}
+void DetSDW::set_control_data(const detsdw_control_data& in) {
+    acceptedGlobalShifts_ = in.acceptedGlobalShifts;
+    attemptedGlobalShifts_ = in.attemptedGlobalShifts;
+    dqmc_update_state st = in.adjust;
+    st.rng_consumed = 0; st.rng_avail = 0; st.error = 0;      // the RNG window is per replica, never exchanged
+    check(dqmc_set_update_state_host(ctx_, &st), "set_control_data");
+    phiDelta_ = st.phiDelta;
+    lastAccRatio_ = st.lastAccRatio;
+}
+
+void DetSDW::getInfo(detsdw_info& o) {
+    std::memset(&o, 0, sizeof(o));
+    o.opdim = opdim_; o.L = pars_.L; o.N = N_; o.MSF = MSF_; o.n_g = ng_; o.m = m_; o.s = s_; o.n = n_;
+    o.performedSweeps = performedSweeps_; o.lastSweepDir = (int)lastSweepDir_;
+    o.acceptedGlobalShifts = acceptedGlobalShifts_; o.attemptedGlobalShifts = attemptedGlobalShifts_;
+    o.currentTimeslice = dqmc_current_timeslice(ctx_);
+    o.beta = pars_.beta; o.dtau = pars_.dtau; o.phiDelta = phiDelta_; o.lastAccRatioLocal_phi = lastAccRatio_;
+    o.r = pars_.r; o.rngDrawn = rng_.drawn();
+}
+void DetSDW::getPhi(double* out) {
+    syncPhiFromDevice();
+    std::memcpy(out, phi_.data(), phi_.size() * sizeof(double));
+}
+void DetSDW::setPhi(const double* in) {
+    std::memcpy(phi_.data(), in, phi_.size() * sizeof(double));
+    check(dqmc_set_fields_host(ctx_, phi_.data()), "dqmc_set_fields_host");
+    setupUdVStorage_and_calculateGreen();
+}
+void DetSDW::getGreen(dqmc_cplx* g) { check(dqmc_get_green_host(ctx_, g), "dqmc_get_green_host"); }
+void DetSDW::getGreenInvSv(double* sv) { check(dqmc_get_sv_host(ctx_, sv), "dqmc_get_sv_host"); }
+
+}  // namespace detqmc
+
+// ---------------------------------------------------------------------------------------------
+// C API (include/detsdw_host.h)
+// ---------------------------------------------------------------------------------------------
+using detqmc::DetSDW;
+struct detsdw_replica { DetSDW* impl; };
+static thread_local std::string g_host_err;
+
+#define GUARD(body)                                                          \
+    try { body; return DQMC_OK; }                                            \
+    catch (const detqmc::GeneralError& e) { g_host_err = e.what(); return e.code; } \
+    catch (const std::exception& e) { g_host_err = e.what(); return DQMC_EINVAL; }
+
+extern "C" const char* detsdw_last_error(void) { return g_host_err.c_str(); }
+
+extern "C" int detsdw_create(const detsdw_params* p, detsdw_replica** out) {
+    if (!p || !out) { g_host_err = "null argument"; return DQMC_EINVAL; }
+    *out = nullptr;
+    GUARD({ DetSDW* d = new DetSDW(*p); *out = new detsdw_replica{d}; })
+}
+extern "C" void detsdw_destroy(detsdw_replica* r) { if (r) { delete r->impl; delete r; } }
+extern "C" int detsdw_sweep(detsdw_replica* r, int tm) { GUARD(r->impl->sweep(tm != 0)) }
+extern "C" int detsdw_sweep_thermalization(detsdw_replica* r) { GUARD(r->impl->sweepThermalization()) }
+extern "C" int detsdw_get_info(detsdw_replica* r, detsdw_info* out) { GUARD(r->impl->getInfo(*out)) }
+extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { GUARD(r->impl->getPhi(phi)) }
+extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { GUARD(r->impl->setPhi(phi)) }
+extern "C" int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g) { GUARD(r->impl->getGreen(g)) }
+extern "C" int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv) { GUARD(r->impl->getGreenInvSv(sv)) }
+extern "C" double detsdw_rng_rand01(detsdw_replica* r) { return r->impl->rand01(); }
+extern "C" dqmc_ctx* detsdw_ctx(detsdw_replica* r) { return r ? r->impl->ctx() : nullptr; }
+extern "C" double detsdw_get_exchange_parameter_value(detsdw_replica* r) { return r->impl->get_exchange_parameter_value(); }
+extern "C" int detsdw_set_exchange_parameter_value(detsdw_replica* r, double v) { GUARD(r->impl->set_exchange_parameter_value(v)) }
+extern "C" const char* detsdw_get_exchange_parameter_name(detsdw_replica* r) { return r->impl->get_exchange_parameter_name(); }
+extern "C" int detsdw_get_exchange_action_contribution(detsdw_replica* r, double* out) {
+    GUARD(*out = r->impl->get_exchange_action_contribution())
+}
+extern "C" int detsdw_get_control_data(detsdw_replica* r, detsdw_control_data* out) { GUARD(r->impl->get_control_data(*out)) }
+extern "C" int detsdw_set_control_data(detsdw_replica* r, const detsdw_control_data* in) { GUARD(r->impl->set_control_data(*in)) }
+// detsdwopdim.cpp:5251-5264 (Hukushima & Nemoto 1996)
+extern "C" double detsdw_replica_exchange_probability(double par1, double action1, double par2, double action2) {
+    const double delta = (par1 - par2) * (action2 - action1);
+    return delta <= 0.0 ? 1.0 : std::exp(-delta);
+}
+extern "C" int detsdw_rng_fill(uint32_t seed, uint32_t processIndex, double* out, size_t n) {
+    if (!out) return DQMC_EINVAL;
+    detqmc::RngStream rs(seed, processIndex);
+    for (size_t i = 0; i < n; ++i) out[i] = rs.rand01();
+    return DQMC_OK;
+}

@@ -1,0 +1,293 @@
+// Checkerboard B-matrix multiplication chains for the SDW model on gfx950.
+//
+// Replaces DetSDW::checkerboard{Left,Right}MultiplyBmat[Inv] and the per-slice
+// leftMultiplyBk / leftMultiplyBkInv / rightMultiplyBk / rightMultiplyBkInv
+// (reference src/detsdwopdim.cpp:1996-2420) including the plaquette passes
+// cb_assaad_applyBondFactors{Left,Right}[_precalcedMatrices] (:1688-1756, :1788-1826, :1905-1943).
+//
+// B_k = e^{-dtau V(phi_k)} . diag(e^{dtau mu_band}) . e^{-dtau K}, e^{-dtau K} in the symmetric
+// break-up e^{-dtau K1/2} e^{-dtau K0} e^{-dtau K1/2} per N x N band block.
+//
+// Design (HBM/L2-bound streaming op, no MFMA): a LEFT multiply acts on every column of A
+// independently, a RIGHT multiply on every row.  One workgroup stages a few whole vectors
+// (columns resp. rows) in LDS, applies the whole chain of slices k to them there -- the s slices of
+// a UdV chain cost ONE read and ONE write of A instead of s -- and streams them back.  Column
+// vectors are contiguous in the column-major matrix; row vectors are staged as 64-byte pieces.
+#include "dqmc_internal.h"
+
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cplx cfma(cplx a, cplx b, cplx c) {
+    c.x = fma(a.x, b.x, c.x); c.x = fma(-a.y, b.y, c.x);
+    c.y = fma(a.x, b.y, c.y); c.y = fma(a.y, b.x, c.y);
+    return c;
+}
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return make_double2(a.x * s, a.y * s); }
+
+// e^{sign dtau V} at one site, cdwU == 0: entries as in get_delta_forsite's evMatrix
+// (detsdwopdim.cpp:3188-3229) == the vectors cd/cmd/mbx/mbcx/ax/max of :2001-2030.
+template<int MSF>
+__device__ __forceinline__ void build_V(cplx (&V)[MSF][MSF], double sign, double c, double xs,
+                                        double p0, double p1, double p2) {
+#pragma unroll
+    for (int a = 0; a < MSF; ++a)
+#pragma unroll
+        for (int b = 0; b < MSF; ++b) V[a][b] = make_double2(0.0, 0.0);
+    cplx bx = make_double2(sign * p0 * xs, -sign * p1 * xs);   // sign (phi0 - i phi1) x
+    cplx bcx = make_double2(sign * p0 * xs, sign * p1 * xs);   // sign (phi0 + i phi1) x
+    V[0][0] = make_double2(c, 0.0);
+    V[1][1] = make_double2(c, 0.0);
+    V[0][1] = bx;
+    V[1][0] = bcx;
+    if (MSF == 4) {
+        double ax = sign * p2 * xs;
+        V[2][2] = make_double2(c, 0.0);
+        V[3][3] = make_double2(c, 0.0);
+        V[0][3] = make_double2(ax, 0.0);
+        V[3][0] = make_double2(ax, 0.0);
+        V[1][2] = make_double2(-ax, 0.0);
+        V[2][1] = make_double2(-ax, 0.0);
+        V[3][2] = bx;
+        V[2][3] = bcx;
+    }
+}
+
+template<int MSF, bool RIGHT, bool INV>
+__global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restrict__ A, int lda, int nvec,
+                                                      int kfirst, int kstep, int kcount) {
+    extern __shared__ cplx sm[];
+    const int N = dm.N, ng = dm.ng, P = dm.P;
+    const int v0 = blockIdx.x * nvec;
+    const int nv = min(nvec, ng - v0);
+    if (nv <= 0) return;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    // LDS address of element e of vector v
+    auto addr = [&](int v, int e) -> int { return RIGHT ? (e * nvec + v) : (v * ng + e); };
+
+    // ---- stage in ----
+    if (!RIGHT) {
+        for (int idx = tid; idx < nv * ng; idx += nth) {
+            int v = idx / ng, e = idx - v * ng;
+            sm[v * ng + e] = A[(size_t)(v0 + v) * lda + e];
+        }
+    } else {
+        for (int idx = tid; idx < nvec * ng; idx += nth) {
+            int e = idx / nvec, v = idx - e * nvec;
+            if (v < nv) sm[e * nvec + v] = A[(size_t)e * lda + (v0 + v)];
+        }
+    }
+    __syncthreads();
+
+    constexpr bool PASSES_FIRST = (RIGHT == INV);   // left B, right B^-1: hopping part acts first
+    const int signIdx = INV ? 1 : 0;
+    const double vsign = INV ? +1.0 : -1.0;
+
+    for (int kc = 0; kc < kcount; ++kc) {
+        const int k = kfirst + kc * kstep;
+        for (int stage = 0; stage < 2; ++stage) {
+            const bool do_passes = (stage == 0) == PASSES_FIRST;
+            if (do_passes) {
+                // e^{+-dtau K1/2} e^{+-dtau K0} e^{+-dtau K1/2}: sub 1 (half), sub 0 (full), sub 1 (half)
+                for (int pass = 0; pass < 3; ++pass) {
+                    const int sub = (pass == 1) ? 0 : 1;
+                    const int items = nv * MSF * P;
+                    for (int idx = tid; idx < items; idx += nth) {
+                        int p = idx % P;
+                        int t = idx / P;
+                        int b = t % MSF;
+                        int v = t / MSF;
+                        int band = b & 1;
+                        const cplx* mat = dm.pmats + ((size_t)(((band * 2 + signIdx) * 2 + sub) * P + p)) * 16;
+                        const int* st = dm.psites + (sub * P + p) * 4;
+                        int e[4];
+                        cplx x[4], y[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { e[q] = addr(v, b * N + st[q]); x[q] = sm[e[q]]; }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                cplx mm = RIGHT ? mat[q * 4 + a] : mat[a * 4 + q];
+                                acc = cfma(mm, x[q], acc);
+                            }
+                            y[a] = acc;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sm[e[q]] = y[q];
+                    }
+                    __syncthreads();
+                }
+            } else {
+                // potential part: per-site MSF x MSF mix (+ chemical potential factor of the band index
+                // that faces the hopping part)
+                const int items = nv * N;
+                const double* ph = dm.phi + (size_t)k * dm.opdim * N;
+                for (int idx = tid; idx < items; idx += nth) {
+                    int i = idx % N;
+                    int v = idx / N;
+                    double c = dm.coshT[(size_t)k * N + i], xs = dm.sinhT[(size_t)k * N + i];
+                    double p0 = ph[i];
+                    double p1 = dm.opdim > 1 ? ph[N + i] : 0.0;
+                    double p2 = dm.opdim > 2 ? ph[2 * N + i] : 0.0;
+                    cplx V[MSF][MSF];
+                    build_V<MSF>(V, vsign, c, xs, p0, p1, p2);
+                    cplx in[MSF], out[MSF];
+#pragma unroll
+                    for (int q = 0; q < MSF; ++q) in[q] = sm[addr(v, q * N + i)];
+                    // input-side factor: left B and right B^-1 have the hopping part on the input side
+                    if (PASSES_FIRST) {
+#pragma unroll
+                        for (int q = 0; q < MSF; ++q) in[q] = cscale(in[q], INV ? dm.ovinv[q & 1] : dm.ov[q & 1]);
+                    }
+#pragma unroll
+                    for (int o = 0; o < MSF; ++o) {
+                        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                        for (int q = 0; q < MSF; ++q) {
+                            cplx vv = RIGHT ? V[q][o] : V[o][q];
+                            acc = cfma(vv, in[q], acc);
+                        }
+                        if (!PASSES_FIRST) acc = cscale(acc, INV ? dm.ovinv[o & 1] : dm.ov[o & 1]);
+                        out[o] = acc;
+                    }
+#pragma unroll
+                    for (int q = 0; q < MSF; ++q) sm[addr(v, q * N + i)] = out[q];
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- stage out ----
+    if (!RIGHT) {
+        for (int idx = tid; idx < nv * ng; idx += nth) {
+            int v = idx / ng, e = idx - v * ng;
+            A[(size_t)(v0 + v) * lda + e] = sm[v * ng + e];
+        }
+    } else {
+        for (int idx = tid; idx < nvec * ng; idx += nth) {
+            int e = idx / nvec, v = idx - e * nvec;
+            if (v < nv) A[(size_t)e * lda + (v0 + v)] = sm[e * nvec + v];
+        }
+    }
+}
+
+void launch_bmult(hipStream_t st, const DevModel* /*dm*/, const DevModel& hm, int side, int inverse,
+                  int kfirst, int kstep, int kcount, cplx* A, int lda) {
+    const int ng = hm.ng;
+    const int max_fit = (int)(65536 / ((size_t)ng * sizeof(cplx)));   // keep <= 64 KiB of LDS
+    int nvec;
+    if (side == DQMC_LEFT) {
+        nvec = ng / 256;                 // aim at >= 256 workgroups
+    } else {
+        nvec = 4;                        // 64-byte pieces of each column per row tile
+    }
+    if (nvec > max_fit) nvec = max_fit;
+    if (nvec < 1) nvec = 1;
+    const int grid = (ng + nvec - 1) / nvec;
+    const size_t lds = (size_t)nvec * ng * sizeof(cplx);
+#define LAUNCH(MSFV, R, I)                                                                              \
+    hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I>), dim3(grid), dim3(256), lds, st, hm, A, lda, nvec, \
+                       kfirst, kstep, kcount)
+    if (hm.MSF == 2) {
+        if (side == DQMC_LEFT) { if (!inverse) LAUNCH(2, false, false); else LAUNCH(2, false, true); }
+        else                   { if (!inverse) LAUNCH(2, true, false);  else LAUNCH(2, true, true); }
+    } else {
+        if (side == DQMC_LEFT) { if (!inverse) LAUNCH(4, false, false); else LAUNCH(4, false, true); }
+        else                   { if (!inverse) LAUNCH(4, true, false);  else LAUNCH(4, true, true); }
+    }
+#undef LAUNCH
+}
+
+// ---------------------------------------------------------------------------------------------
+// small elementwise helpers
+// ---------------------------------------------------------------------------------------------
+// updateCoshSinhTermsPhi (detsdwopdim.cpp:1132-1136, 1175-1181)
+__global__ void k_cosh_sinh(DevModel dm) {
+    const int total = dm.m * dm.N;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int k = 1 + idx / dm.N, i = idx % dm.N;
+        double nn = 0.0;
+        for (int d = 0; d < dm.opdim; ++d) {
+            double p = dm.phi[((size_t)k * dm.opdim + d) * dm.N + i];
+            nn += p * p;
+        }
+        double nrm = sqrt(nn);
+        double a = dm.lambda * dm.dtau * nrm;
+        dm.coshT[(size_t)k * dm.N + i] = cosh(a);
+        dm.sinhT[(size_t)k * dm.N + i] = sinh(a) / nrm;
+    }
+}
+void launch_cosh_sinh(hipStream_t st, const DevModel& hm) {
+    int total = hm.m * hm.N;
+    hipLaunchKernelGGL(k_cosh_sinh, dim3((total + 255) / 256), dim3(256), 0, st, hm);
+}
+
+__global__ void k_set_identity(cplx* A, int n) {
+    size_t total = (size_t)n * n;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(idx % n), j = (int)(idx / n);
+        A[idx] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+    }
+}
+void launch_set_identity(hipStream_t st, cplx* A, int n) {
+    hipLaunchKernelGGL(k_set_identity, dim3(1024), dim3(256), 0, st, A, n);
+}
+
+// B = A^H through a 32x32 LDS tile (both sides coalesced)
+__global__ void k_conj_transpose(const cplx* __restrict__ A, cplx* __restrict__ B, int n) {
+    __shared__ cplx tile[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        int i = bx + tx, j = by + r;
+        if (i < n && j < n) tile[r][tx] = A[(size_t)j * n + i];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int i = by + tx, j = bx + r;     // B(i, j) = conj(A(j, i))
+        if (i < n && j < n) {
+            cplx t = tile[tx][r];
+            B[(size_t)j * n + i] = make_double2(t.x, -t.y);
+        }
+    }
+}
+void launch_conj_transpose(hipStream_t st, const cplx* A, cplx* B, int n) {
+    dim3 grid((n + 31) / 32, (n + 31) / 32);
+    hipLaunchKernelGGL(k_conj_transpose, grid, dim3(256), 0, st, A, B, n);
+}
+
+__global__ void k_add_diag(cplx* A, const double* d, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[(size_t)i * n + i].x += d[i];
+}
+void launch_add_diag(hipStream_t st, cplx* A, const double* d, int n) {
+    hipLaunchKernelGGL(k_add_diag, dim3((n + 255) / 256), dim3(256), 0, st, A, d, n);
+}
+
+void launch_copy(hipStream_t st, const cplx* A, cplx* B, size_t count) {
+    (void)hipMemcpyAsync(B, A, count * sizeof(cplx), hipMemcpyDeviceToDevice, st);
+}
+
+// sum over slices 1..m, sites and components of phi^2 (get_exchange_action_contribution,
+// detsdwopdim.cpp:5205-5216); single workgroup, fixed summation order => reproducible
+__global__ void k_phi_sq_sum(DevModel dm, double* out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    size_t total = (size_t)dm.m * dm.opdim * dm.N;
+    const double* p = dm.phi + (size_t)dm.opdim * dm.N;   // skip slice 0
+    for (size_t idx = threadIdx.x; idx < total; idx += 256) acc += p[idx] * p[idx];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+void launch_phi_sq_sum(hipStream_t st, const DevModel& hm, double* out) {
+    hipLaunchKernelGGL(k_phi_sq_sum, dim3(1), dim3(256), 0, st, hm, out);
+}

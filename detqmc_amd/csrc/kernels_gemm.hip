@@ -1,0 +1,125 @@
+// Complex-fp64 GEMM on the CDNA4 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Replaces the zgemm calls behind the reference's Armadillo expressions on the stabilised sweep:
+// UdV chaining U_l*U', V_t_l*V_t' (src/detmodel.h:987, :1143), the five products of greenFromUdV
+// (:784-815) and the delayed-update flush g += X*Y (src/detsdwopdim.cpp:3156).
+//
+//   C[MxN] (+)= rowscale_i * ( op(A)[MxK] . diag(kscale^{+-1}) . op(B)[KxN] ) * colscale_j
+//
+// op = N or conjugate transpose.  A complex product is 4 real MFMAs per 16x16x4 step
+// (re += ar*br - ai*bi, im += ar*bi + ai*br).  Operands are staged through LDS as [k][i] / [k][j]
+// interleaved (re,im) so one ds_read_b128 feeds both the real and the imaginary fragment.  The MFMA
+// is issued with the operand roles swapped (D^T = B^T A^T): the f64 accumulator then holds 16
+// CONSECUTIVE ROWS of one column per register across lanes 0..15 -- a 256-byte contiguous run in the
+// column-major C -- so the epilogue stores coalesce.
+//
+// Workgroup = 4 waves in a 2x2 arrangement, each wave TMxTN MFMA tiles: 32x32 block tiles when
+// n_g = 512 (256 workgroups = one per CU), 64x64 for the large O(3) lattices.
+#include "dqmc_internal.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template<int TM, int TN>
+__global__ __launch_bounds__(256) void k_zgemm(GemmArgs g) {
+    constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16;
+    __shared__ cplx sA[BK][BM + 1];
+    __shared__ cplx sB[BK][BN + 1];
+
+    int K = g.K;
+    if (g.Kdev) { int kd = (*g.Kdev) * g.Kmul; K = kd < K ? kd : K; }
+    if (K <= 0 && g.accumulate) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    v4d acc_re[TM][TN], acc_im[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); }
+
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        // ---- stage op(A) tile: sA[k][i] ----
+        for (int idx = tid; idx < BM * BK; idx += 256) {
+            int i, k;
+            if (g.opA == 0) { i = idx % BM; k = idx / BM; } else { k = idx % BK; i = idx / BK; }
+            cplx v = make_double2(0.0, 0.0);
+            int gi = i0 + i, gk = k0 + k;
+            if (gi < g.M && gk < K) {
+                if (g.opA == 0) v = g.A[(size_t)gk * g.lda + gi];
+                else { cplx t = g.A[(size_t)gi * g.lda + gk]; v = make_double2(t.x, -t.y); }
+                if (g.kscale) {
+                    double sc = g.kscale[gk];
+                    if (g.kscale_invert) sc = 1.0 / sc;
+                    v.x *= sc; v.y *= sc;
+                }
+            }
+            sA[k][i] = v;
+        }
+        // ---- stage op(B) tile: sB[k][j] ----
+        for (int idx = tid; idx < BN * BK; idx += 256) {
+            int j, k;
+            if (g.opB == 0) { k = idx % BK; j = idx / BK; } else { j = idx % BN; k = idx / BN; }
+            cplx v = make_double2(0.0, 0.0);
+            int gj = j0 + j, gk = k0 + k;
+            if (gj < g.N && gk < K) {
+                if (g.opB == 0) v = g.B[(size_t)gj * g.ldb + gk];
+                else { cplx t = g.B[(size_t)gk * g.ldb + gj]; v = make_double2(t.x, -t.y); }
+            }
+            sB[k][j] = v;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            cplx af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = sA[kk + l4][wm * 16 * TM + a * 16 + l15];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = sB[kk + l4][wn * 16 * TN + b * 16 + l15];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    // roles swapped: first operand indexes the OUTPUT "row" (= column j of C)
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bf[b].y, af[a].y, acc_re[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].x, acc_im[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulator element r of lane: out-row (=j) = l4 + 4 r, out-col (=i) = l15 ----
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int gi = i0 + wm * 16 * TM + a * 16 + l15;
+                int gj = j0 + wn * 16 * TN + b * 16 + l4 + 4 * r;
+                if (gi < g.M && gj < g.N) {
+                    double re = acc_re[a][b][r], im = acc_im[a][b][r];
+                    if (g.rowscale) { double sc = g.rowscale[gi] * g.colscale[gj]; re *= sc; im *= sc; }
+                    size_t off = (size_t)gj * g.ldc + gi;
+                    if (g.accumulate) { cplx c = g.C[off]; re += c.x; im += c.y; }
+                    g.C[off] = make_double2(re, im);
+                }
+            }
+}
+
+void launch_gemm(hipStream_t st, const GemmArgs& a) {
+    // fill the chip: 64x64 tiles only when they still give >= 256 workgroups
+    long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    if (tiles64 >= 256) {
+        dim3 grid((a.M + 63) / 64, (a.N + 63) / 64);
+        hipLaunchKernelGGL((k_zgemm<2, 2>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((a.M + 31) / 32, (a.N + 31) / 32);
+        hipLaunchKernelGGL((k_zgemm<1, 1>), grid, dim3(256), 0, st, a);
+    }
+}

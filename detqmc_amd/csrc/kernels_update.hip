@@ -1,0 +1,446 @@
+// Local Metropolis updates of one time slice, device resident (gfx950).
+//
+// Replaces DetSDW::updateInSlice / updateInSlice_delayed / updateInSliceThermalization
+// (reference src/detsdwopdim.cpp:2428-2489, :3023-3175, :3294-3375) with proposeNewPhiBox
+// (:3922-3931), deltaSPhi (:4186-4239) and get_delta_forsite (:3179-3289).
+//
+// Same Markov chain, same block structure (a block ends after delaySteps ACCEPTED updates,
+// :3051-3056) and the same RNG consumption order (OPDIM draws per proposal, then one more only if
+// prob <= 1, :3113), but the bookkeeping is re-derived for the GPU ("sub-matrix" form):
+//
+//   Accepted sites of the block so far: index set I (MSF rows per site), Delta_A = blockdiag(delta_l).
+//   Effective Green's function  G' = G + G[:,I] W (G[I,:] - E_I),   W = Delta_A M_A^-1,
+//   M_A = 1 + (1 - G[I,I]) Delta_A.            (Woodbury; identical to the reference's G + X Y)
+//   For a candidate site c: S = G'[c,c] = G[c,c] + G[c,I] W G[I,c];   M' = 1 + (1 - S) delta';
+//   ratio = det M' (== det of the reference's Mj, :3081-3084).  On acceptance W grows by block
+//   bordering: p = W G[I,c], q = G[c,I] W, F = delta' M'^-1:
+//       W <- [[ W + p F q,  p F ], [ F q, F ]]
+//
+//   => a decision touches only O(MSF*j) scattered entries of G and O((MSF j)^2) flops, never whole
+//   rows/columns; the reference's per-proposal row/column corrections (1.6 M tiny zgemm per 4 sweeps)
+//   disappear.  After the block, X = G[:,I] W and Gr = G[I,:] - E_I are formed by a parallel gather
+//   kernel and G += X Gr is one MFMA GEMM (kernels_gemm.hip).
+//
+// The decision kernel is ONE wavefront: the chain of decisions is strictly sequential, all
+// cross-lane traffic is wave shuffles / a tiny LDS scratch, and no workgroup barrier is ever needed.
+#include "dqmc_internal.h"
+
+__device__ __forceinline__ cplx u_cfma(cplx a, cplx b, cplx c) {
+    c.x = fma(a.x, b.x, c.x); c.x = fma(-a.y, b.y, c.x);
+    c.y = fma(a.x, b.y, c.y); c.y = fma(a.y, b.x, c.y);
+    return c;
+}
+__device__ __forceinline__ cplx u_cmul(cplx a, cplx b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cplx u_csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double u_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// e^{sign dtau V} at one site (detsdwopdim.cpp:3188-3229, cdwU == 0)
+template<int MSF>
+__device__ __forceinline__ void ev_matrix(cplx (&V)[MSF][MSF], double sign, const double* p, int opdim,
+                                          double c, double xs) {
+#pragma unroll
+    for (int a = 0; a < MSF; ++a)
+#pragma unroll
+        for (int b = 0; b < MSF; ++b) V[a][b] = make_double2(0.0, 0.0);
+    double p0 = p[0], p1 = opdim > 1 ? p[1] : 0.0;
+    cplx bx = make_double2(sign * p0 * xs, -sign * p1 * xs);
+    cplx bcx = make_double2(sign * p0 * xs, sign * p1 * xs);
+    V[0][0] = make_double2(c, 0.0);
+    V[1][1] = make_double2(c, 0.0);
+    V[0][1] = bx;
+    V[1][0] = bcx;
+    if (MSF == 4) {
+        double ax = sign * p[2] * xs;
+        V[2][2] = make_double2(c, 0.0);
+        V[3][3] = make_double2(c, 0.0);
+        V[0][3] = make_double2(ax, 0.0);
+        V[3][0] = make_double2(ax, 0.0);
+        V[1][2] = make_double2(-ax, 0.0);
+        V[2][1] = make_double2(-ax, 0.0);
+        V[3][2] = bx;
+        V[2][3] = bcx;
+    }
+}
+
+// determinant and inverse of a small complex matrix by Gauss-Jordan with partial pivoting
+template<int MSF>
+__device__ __forceinline__ cplx small_det_inv(const cplx (&Min)[MSF][MSF], cplx (&Inv)[MSF][MSF]) {
+    if (MSF == 2) {
+        cplx det = u_csub(u_cmul(Min[0][0], Min[1][1]), u_cmul(Min[0][1], Min[1][0]));
+        double dn = det.x * det.x + det.y * det.y;
+        cplx idet = make_double2(det.x / dn, -det.y / dn);
+        Inv[0][0] = u_cmul(Min[1][1], idet);
+        Inv[1][1] = u_cmul(Min[0][0], idet);
+        Inv[0][1] = u_cmul(make_double2(-Min[0][1].x, -Min[0][1].y), idet);
+        Inv[1][0] = u_cmul(make_double2(-Min[1][0].x, -Min[1][0].y), idet);
+        return det;
+    }
+    cplx A[MSF][MSF];
+#pragma unroll
+    for (int i = 0; i < MSF; ++i)
+#pragma unroll
+        for (int j = 0; j < MSF; ++j) {
+            A[i][j] = Min[i][j];
+            Inv[i][j] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+        }
+    cplx det = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int c = 0; c < MSF; ++c) {
+        int piv = c;
+        double best = A[c][c].x * A[c][c].x + A[c][c].y * A[c][c].y;
+#pragma unroll
+        for (int r = c + 1; r < MSF; ++r) {
+            double v = A[r][c].x * A[r][c].x + A[r][c].y * A[r][c].y;
+            if (v > best) { best = v; piv = r; }
+        }
+        if (piv != c) {
+#pragma unroll
+            for (int j = 0; j < MSF; ++j) {
+                cplx t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t;
+                t = Inv[c][j]; Inv[c][j] = Inv[piv][j]; Inv[piv][j] = t;
+            }
+            det = make_double2(-det.x, -det.y);
+        }
+        cplx pv = A[c][c];
+        det = u_cmul(det, pv);
+        double dn = pv.x * pv.x + pv.y * pv.y;
+        cplx ipv = make_double2(pv.x / dn, -pv.y / dn);
+#pragma unroll
+        for (int j = 0; j < MSF; ++j) { A[c][j] = u_cmul(A[c][j], ipv); Inv[c][j] = u_cmul(Inv[c][j], ipv); }
+#pragma unroll
+        for (int r = 0; r < MSF; ++r) {
+            if (r == c) continue;
+            cplx f = A[r][c];
+#pragma unroll
+            for (int j = 0; j < MSF; ++j) {
+                A[r][j] = u_csub(A[r][j], u_cmul(f, A[c][j]));
+                Inv[r][j] = u_csub(Inv[r][j], u_cmul(f, Inv[c][j]));
+            }
+        }
+    }
+    return det;
+}
+
+template<int OPDIM>
+__global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
+                                                       const cplx* __restrict__ G, cplx* __restrict__ Wout,
+                                                       int k, int first, int thermal) {
+    constexpr int MSF = (OPDIM == 3) ? 4 : 2;
+    const int N = dm.N, ng = dm.ng, D = dm.D, m = dm.m;
+    const int WD = MSF * D;
+    extern __shared__ cplx smem[];
+    cplx* W = smem;                       // [WD][WD] row-major: W[i*WD + i']
+    cplx* su = W + WD * WD;               // u[a][i]  = G[c_a, I_i]      [MSF][WD]
+    cplx* sv = su + MSF * WD;             // v[i][b]  = G[I_i, c_b]      [WD][MSF]
+    cplx* sp = sv + WD * MSF;             // p = W v                     [WD][MSF]
+    cplx* sq = sp + WD * MSF;             // q = u W                     [MSF][WD]
+    cplx* spf = sq + MSF * WD;            // p F                         [WD][MSF]
+    __shared__ int isite[DQMC_MAX_WDIM];
+    const int lane = threadIdx.x;
+
+    int site = first ? 0 : us->site_cursor;
+    int acc_count = first ? 0 : us->acc_count;
+    int done = first ? 0 : us->slice_done;
+    if (done || site >= N) {
+        if (lane == 0) { us->block_j = 0; if (first) { us->site_cursor = site; us->acc_count = 0; us->slice_done = done; } }
+        return;
+    }
+    unsigned long long cur = us->pub.rng_consumed;
+    const unsigned long long avail = us->pub.rng_avail;
+    const double phiDelta = us->pub.phiDelta;
+    int err = us->pub.error;
+    double* phik = dm.phi + (size_t)k * OPDIM * N;
+    const int kEarlier = (k > 1) ? k - 1 : m;     // PeriodicChainNearestNeighbors<1> over slices 1..m
+    const int kLater = (k < m) ? k + 1 : 1;
+    const double* phiE = dm.phi + (size_t)kEarlier * OPDIM * N;
+    const double* phiL = dm.phi + (size_t)kLater * OPDIM * N;
+
+    int j = 0;
+    const int dnow = min(D, N - site);            // delayStepsNow (:3052)
+    while (j < dnow && site < N) {
+        if (cur + OPDIM + 1 > avail) { err = DQMC_ERNG; break; }
+        const int nI = MSF * j;
+        // ---- G entries for this candidate (issued first: longest latency) ----
+        for (int t = lane; t < MSF * nI; t += 64) {
+            int a = t / nI, i = t - a * nI;
+            int Ii = isite[i / MSF] + (i % MSF) * N;
+            su[a * WD + i] = G[(size_t)Ii * ng + (site + a * N)];
+            int b = t % MSF, i2 = t / MSF;
+            int Ii2 = isite[i2 / MSF] + (i2 % MSF) * N;
+            sv[i2 * MSF + b] = G[(size_t)(site + b * N) * ng + Ii2];
+        }
+        cplx Gcc[MSF][MSF];
+#pragma unroll
+        for (int a = 0; a < MSF; ++a)
+#pragma unroll
+            for (int b = 0; b < MSF; ++b) Gcc[a][b] = G[(size_t)(site + b * N) * ng + (site + a * N)];
+
+        // ---- proposal, bosonic action, delta (uniform across the wave) ----
+        double oldphi[OPDIM], newphi[OPDIM];
+#pragma unroll
+        for (int d = 0; d < OPDIM; ++d) {
+            oldphi[d] = phik[d * N + site];
+            double low = -phiDelta, high = phiDelta;
+            double r = low + (high - low) * uni[cur + d];           // randRange (rngwrapper.h:59-61)
+            newphi[d] = oldphi[d] + r;
+        }
+        cur += OPDIM;
+        double dsphi;
+        {
+            double oldSq = 0.0, newSq = 0.0;
+#pragma unroll
+            for (int d = 0; d < OPDIM; ++d) { oldSq += oldphi[d] * oldphi[d]; newSq += newphi[d] * newphi[d]; }
+            double phiSqDiff = newSq - oldSq;
+            if (dm.phi2bosons) {
+                dsphi = dm.dtau * 0.5 * dm.r * phiSqDiff;
+            } else {
+                double phiPow4Diff = newSq * newSq - oldSq * oldSq;
+                double dotTime = 0.0, dotSpace = 0.0;
+#pragma unroll
+                for (int d = 0; d < OPDIM; ++d) {
+                    double diff = newphi[d] - oldphi[d];
+                    double tn = phiL[d * N + site] + phiE[d * N + site];
+                    double sn = 0.0;
+#pragma unroll
+                    for (int dir = 0; dir < 4; ++dir) sn += phik[d * N + dm.neigh[dir * N + site]];
+                    dotTime += tn * diff;
+                    dotSpace += sn * diff;
+                }
+                double delta1 = (1.0 / (dm.c * dm.c * dm.dtau)) * (phiSqDiff - dotTime);
+                double delta2 = 0.5 * dm.dtau * (4.0 * phiSqDiff - 2.0 * dotSpace);
+                double delta3 = dm.dtau * (0.5 * dm.r * phiSqDiff + 0.25 * dm.u * phiPow4Diff);
+                dsphi = delta1 + delta2 + delta3;
+            }
+        }
+        const double probSPhi = exp(-dsphi);
+        double coshN, sinhN;
+        {
+            double nn = 0.0;
+#pragma unroll
+            for (int d = 0; d < OPDIM; ++d) nn += newphi[d] * newphi[d];
+            double nrm = sqrt(nn);
+            double arg = dm.lambda * dm.dtau * nrm;
+            coshN = cosh(arg);
+            sinhN = sinh(arg) / nrm;
+        }
+        cplx delta[MSF][MSF];
+        {
+            cplx evOld[MSF][MSF], emvNew[MSF][MSF];
+            ev_matrix<MSF>(evOld, +1.0, oldphi, OPDIM, dm.coshT[(size_t)k * N + site], dm.sinhT[(size_t)k * N + site]);
+            ev_matrix<MSF>(emvNew, -1.0, newphi, OPDIM, coshN, sinhN);
+#pragma unroll
+            for (int a = 0; a < MSF; ++a)
+#pragma unroll
+                for (int b = 0; b < MSF; ++b) {
+                    cplx acc = make_double2(a == b ? -1.0 : 0.0, 0.0);
+#pragma unroll
+                    for (int q = 0; q < MSF; ++q) acc = u_cfma(emvNew[a][q], evOld[q][b], acc);
+                    delta[a][b] = acc;
+                }
+        }
+        __syncthreads();
+        // ---- p = W v ----
+        for (int t = lane; t < nI * MSF; t += 64) {
+            int i = t / MSF, b = t - i * MSF;
+            cplx acc = make_double2(0.0, 0.0);
+            for (int i2 = 0; i2 < nI; ++i2) acc = u_cfma(W[i * WD + i2], sv[i2 * MSF + b], acc);
+            sp[i * MSF + b] = acc;
+        }
+        __syncthreads();
+        // ---- S = Gcc + u p (lane i holds term i, wave reduce) ----
+        cplx S[MSF][MSF];
+#pragma unroll
+        for (int a = 0; a < MSF; ++a)
+#pragma unroll
+            for (int b = 0; b < MSF; ++b) {
+                cplx part = make_double2(0.0, 0.0);
+                for (int i = lane; i < nI; i += 64) part = u_cfma(su[a * WD + i], sp[i * MSF + b], part);
+                S[a][b] = make_double2(Gcc[a][b].x + u_wave_sum(part.x), Gcc[a][b].y + u_wave_sum(part.y));
+            }
+        // ---- M' = 1 + (1 - S) delta ; det ; acceptance ----
+        cplx Mj[MSF][MSF], Minv[MSF][MSF];
+#pragma unroll
+        for (int a = 0; a < MSF; ++a)
+#pragma unroll
+            for (int b = 0; b < MSF; ++b) {
+                cplx acc = make_double2((a == b ? 1.0 : 0.0) + delta[a][b].x, delta[a][b].y);
+#pragma unroll
+                for (int q = 0; q < MSF; ++q)
+                    acc = u_cfma(make_double2(-S[a][q].x, -S[a][q].y), delta[q][b], acc);
+                Mj[a][b] = acc;
+            }
+        cplx det = small_det_inv<MSF>(Mj, Minv);
+        double probSFermion = (OPDIM == 3) ? det.x : (det.x * det.x + det.y * det.y);
+        double prob = probSPhi * probSFermion;
+        bool accept = prob > 1.0;
+        if (!accept) { accept = uni[cur] < prob; cur += 1; }
+        if (accept) {
+            acc_count += 1;
+            if (lane == 0) {
+#pragma unroll
+                for (int d = 0; d < OPDIM; ++d) phik[d * N + site] = newphi[d];
+                dm.coshT[(size_t)k * N + site] = coshN;
+                dm.sinhT[(size_t)k * N + site] = sinhN;
+                isite[j] = site;
+            }
+            // F = delta M'^-1
+            cplx F[MSF][MSF];
+#pragma unroll
+            for (int a = 0; a < MSF; ++a)
+#pragma unroll
+                for (int b = 0; b < MSF; ++b) {
+                    cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int q = 0; q < MSF; ++q) acc = u_cfma(delta[a][q], Minv[q][b], acc);
+                    F[a][b] = acc;
+                }
+            // q = u W ; pF = p F
+            for (int t = lane; t < MSF * nI; t += 64) {
+                int a = t / nI, i = t - a * nI;
+                cplx acc = make_double2(0.0, 0.0);
+                for (int i2 = 0; i2 < nI; ++i2) acc = u_cfma(su[a * WD + i2], W[i2 * WD + i], acc);
+                sq[a * WD + i] = acc;
+            }
+            for (int i = lane; i < nI; i += 64) {
+#pragma unroll
+                for (int b = 0; b < MSF; ++b) {
+                    cplx acc2 = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int q = 0; q < MSF; ++q) acc2 = u_cfma(sp[i * MSF + q], F[q][b], acc2);
+                    spf[i * MSF + b] = acc2;
+                }
+            }
+            __syncthreads();
+            // W11 += pF q
+            for (int t = lane; t < nI * nI; t += 64) {
+                int i = t / nI, i2 = t - i * nI;
+                cplx acc = W[i * WD + i2];
+#pragma unroll
+                for (int q = 0; q < MSF; ++q) acc = u_cfma(spf[i * MSF + q], sq[q * WD + i2], acc);
+                W[i * WD + i2] = acc;
+            }
+            // W12 = pF ; W21 = F q
+            for (int i = lane; i < nI; i += 64) {
+#pragma unroll
+                for (int b = 0; b < MSF; ++b) {
+                    W[i * WD + (nI + b)] = spf[i * MSF + b];
+                    cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int q = 0; q < MSF; ++q) acc = u_cfma(F[b][q], sq[q * WD + i], acc);
+                    W[(nI + b) * WD + i] = acc;
+                }
+            }
+            // W22 = F
+            if (lane == 0) {
+#pragma unroll
+                for (int a = 0; a < MSF; ++a)
+#pragma unroll
+                    for (int b = 0; b < MSF; ++b) W[(nI + a) * WD + (nI + b)] = F[a][b];
+            }
+            j += 1;
+        }
+        site += 1;
+        __syncthreads();
+    }
+
+    // ---- publish block result ----
+    const int nI = MSF * j;
+    for (int t = lane; t < nI * nI; t += 64) {
+        int i = t / nI, i2 = t - i * nI;
+        Wout[(size_t)i2 * WD + i] = W[i * WD + i2];        // column-major, ld = WD
+    }
+    if (lane == 0) {
+        us->site_cursor = site;
+        us->acc_count = acc_count;
+        us->block_j = j;
+        for (int l = 0; l < j; ++l) us->block_sites[l] = isite[l];
+        us->pub.rng_consumed = cur;
+        us->pub.error = err;
+        int sdone = 0;
+        if (site >= N && err == 0) {
+            sdone = 1;
+            double accratio = (double)acc_count / (double)N;            // :3173
+            us->pub.lastAccRatio = accratio;
+            if (thermal) {
+                // RunningAverage::addValue (RunningAverage.h:57-68), sampleSize = 100
+                const int sampleSize = 100;
+                double ra = us->pub.ra_runningAverage;
+                int added = us->pub.ra_samplesAdded, head = us->pub.ra_head;
+                if (added < sampleSize) {
+                    us->pub.ra_values[added] = accratio;
+                    ra += accratio / sampleSize;
+                } else {
+                    ra -= us->pub.ra_values[head] / sampleSize;
+                    us->pub.ra_values[head] = accratio;
+                    head = (head + 1) % sampleSize;
+                    ra += accratio / sampleSize;
+                }
+                added += 1;
+                us->pub.ra_runningAverage = ra;
+                us->pub.ra_samplesAdded = added;
+                us->pub.ra_head = head;
+                if (added % sampleSize == 0) {                          // :3331-3341
+                    double pd = us->pub.phiDelta;
+                    if (ra < us->pub.targetAccRatio) pd *= 0.95;
+                    else if (ra > us->pub.targetAccRatio) pd *= 1.05;
+                    us->pub.phiDelta = pd;
+                }
+            }
+        }
+        us->slice_done = sdone;
+    }
+}
+
+void launch_update_decide(hipStream_t st, const DevModel* /*dm*/, const DevModel& hm, DevUpdateState* us,
+                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal) {
+    const int WD = hm.MSF * hm.D;
+    size_t lds = ((size_t)WD * WD + 5 * (size_t)hm.MSF * WD) * sizeof(cplx);
+    if (hm.opdim == 1)
+        hipLaunchKernelGGL((k_update_decide<1>), dim3(1), dim3(64), lds, st, hm, us, uniforms, G, W, k, first, thermal);
+    else if (hm.opdim == 2)
+        hipLaunchKernelGGL((k_update_decide<2>), dim3(1), dim3(64), lds, st, hm, us, uniforms, G, W, k, first, thermal);
+    else
+        hipLaunchKernelGGL((k_update_decide<3>), dim3(1), dim3(64), lds, st, hm, us, uniforms, G, W, k, first, thermal);
+}
+
+// X[:, i'] = sum_i G[:, I_i] W[i, i']   (n_g x nI, ld n_g);   Gr[i, :] = G[I_i, :] - E   (nI x n_g, ld WD)
+__global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpdateState* __restrict__ us,
+                                                        const cplx* __restrict__ G, const cplx* __restrict__ Wg,
+                                                        cplx* __restrict__ X, cplx* __restrict__ Gr) {
+    extern __shared__ cplx sW[];      // column-major [WD][nI] as stored by the decision kernel
+    const int j = us->block_j;
+    if (j <= 0) return;
+    const int MSF = dm.MSF, N = dm.N, ng = dm.ng, WD = MSF * dm.D;
+    const int nI = MSF * j;
+    __shared__ int sI[DQMC_MAX_WDIM];
+    for (int t = threadIdx.x; t < nI; t += 256) sI[t] = us->block_sites[t / MSF] + (t % MSF) * N;
+    for (int t = threadIdx.x; t < nI * WD; t += 256) sW[t] = Wg[t];
+    __syncthreads();
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    if (r < ng) {
+        for (int i2 = sub; i2 < nI; i2 += 4) {
+            cplx acc = make_double2(0.0, 0.0);
+            for (int i = 0; i < nI; ++i) acc = u_cfma(G[(size_t)sI[i] * ng + r], sW[(size_t)i2 * WD + i], acc);
+            X[(size_t)i2 * ng + r] = acc;
+        }
+        for (int i = sub; i < nI; i += 4) {
+            cplx g = G[(size_t)r * ng + sI[i]];
+            if (r == sI[i]) g.x -= 1.0;
+            Gr[(size_t)r * WD + i] = g;
+        }
+    }
+}
+
+void launch_update_gather(hipStream_t st, const DevModel& hm, const DevUpdateState* us, const cplx* G,
+                          const cplx* W, cplx* X, cplx* Gr) {
+    const int WD = hm.MSF * hm.D;
+    size_t lds = (size_t)WD * WD * sizeof(cplx);
+    hipLaunchKernelGGL(k_update_gather, dim3((hm.ng + 63) / 64), dim3(256), lds, st, hm, us, G, W, X, Gr);
+}

@@ -1,0 +1,338 @@
+"""Thin Python mirrors of the two native layers.
+
+  KernelContext  <-> dqmc_ctx (include/dqmc_hip.h): the kernel-level ABI, method names follow the
+                     reference functions each call replaces (detmodel.h / detsdwopdim.cpp).
+  DetSDW         <-> detqmc::DetSDW (C++ host layer, include/detsdw_host.h): the replica with the
+                     reference's operator surface: sweep(), sweepThermalization(),
+                     get/set_exchange_parameter_value(), get_exchange_action_contribution(), ...
+
+numpy arrays cross the boundary in the reference's layouts: complex128 column-major n_g x n_g
+matrices, phi as (N, OPDIM, m+1) column-major.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, load
+
+BC = {"pbc": 0, "apbc-x": 1, "apbc-y": 2, "apbc-xy": 3}
+UPDATE_METHOD = {"iterative": 0, "woodbury": 1, "delayed": 2}
+LEFT, RIGHT = 0, 1
+UP, DOWN = +1, -1
+
+
+@dataclass
+class SDWParams:
+    """ModelParamsDetSDW (reference src/detsdwparams.h:24-120), defaults of the shipped examples."""
+    opdim: int = 2
+    L: int = 4
+    beta: float = 0.0
+    m: int = 0
+    dtau: float = 0.1
+    s: int = 10
+    r: float = -1.0
+    c: float = 3.0
+    u: float = 1.0
+    lambda_: float = 1.0
+    txhor: float = -1.0
+    txver: float = -0.5
+    tyhor: float = 0.5
+    tyver: float = 1.0
+    mu: float = -0.5
+    mux: float = None
+    muy: float = None
+    accRatio: float = 0.5
+    delaySteps: int = 16
+    updateMethod: str = "delayed"
+    bc: str = "pbc"
+    weakZflux: bool = False
+    globalShift: bool = False
+    globalUpdateInterval: int = 100
+    phi2bosons: bool = False
+    cdwU: float = 0.0
+    rngSeed: int = 1020304050
+    simindex: int = 0
+    device: int = 0
+
+
+def _fmat(a):
+    """complex128, column-major, owned."""
+    return np.array(a, dtype=np.complex128, order="F", copy=True)
+
+
+class KernelContext:
+    """One dqmc_ctx.  Needs a GPU."""
+
+    def __init__(self, opdim, L, m, s, dtau, delaySteps=16, bc="pbc", weakZflux=False, r=-1.0, c=3.0, u=1.0,
+                 lambda_=1.0, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, mux=-0.5, muy=-0.5,
+                 accRatio=0.5, phi2bosons=False, device=0):
+        self.lib = load()
+        p = _lib.dqmc_params(opdim=opdim, L=L, m=m, s=s, delaySteps=delaySteps, bc=BC[bc],
+                             weakZflux=int(weakZflux), phi2bosons=int(phi2bosons), device=device,
+                             dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
+                             tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio)
+        h = C.c_void_p()
+        check(self.lib.dqmc_create(C.byref(p), C.byref(h)))
+        self.h = h
+        self.opdim, self.L, self.m, self.s = opdim, L, m, s
+        self.N = L * L
+        self.MSF = 4 if opdim == 3 else 2
+        self.ng = self.MSF * self.N
+        self.n = -(-m // s)
+
+    def close(self):
+        if self.h:
+            self.lib.dqmc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # fields: phi given/returned as (m+1, N, OPDIM) [oracle layout]; the ABI uses (N, OPDIM, m+1) col-major
+    def set_fields(self, phi_kNd):
+        ref = np.asfortranarray(np.transpose(np.asarray(phi_kNd, dtype=np.float64), (1, 2, 0)))
+        check(self.lib.dqmc_set_fields_host(self.h, ref.ctypes.data_as(_lib._DP)))
+
+    def get_fields(self):
+        phi = np.zeros((self.N, self.opdim, self.m + 1), order="F")
+        ch = np.zeros((self.N, self.m + 1), order="F")
+        sh = np.zeros((self.N, self.m + 1), order="F")
+        check(self.lib.dqmc_get_fields_host(self.h, phi.ctypes.data_as(_lib._DP), ch.ctypes.data_as(_lib._DP),
+                                            sh.ctypes.data_as(_lib._DP)))
+        return np.transpose(phi, (2, 0, 1)).copy(), ch.T.copy(), sh.T.copy()
+
+    def bmult(self, side, inverse, k2, k1, A):
+        a = _fmat(A)
+        check(self.lib.dqmc_bmult_host(self.h, side, int(inverse), k2, k1, a.ctypes.data))
+        return a
+
+    def leftMultiplyBmat(self, A, k2, k1):
+        return self.bmult(LEFT, 0, k2, k1, A)
+
+    def leftMultiplyBmatInv(self, A, k2, k1):
+        return self.bmult(LEFT, 1, k2, k1, A)
+
+    def rightMultiplyBmat(self, A, k2, k1):
+        return self.bmult(RIGHT, 0, k2, k1, A)
+
+    def rightMultiplyBmatInv(self, A, k2, k1):
+        return self.bmult(RIGHT, 1, k2, k1, A)
+
+    def udvDecompose(self, M):
+        a = _fmat(M)
+        U = np.zeros_like(a)
+        Vt = np.zeros_like(a)
+        d = np.zeros(self.ng)
+        sw = C.c_int(0)
+        check(self.lib.dqmc_udv_decompose_host(self.h, a.ctypes.data, U.ctypes.data, d.ctypes.data_as(_lib._DP),
+                                               Vt.ctypes.data, C.byref(sw)))
+        return U, d, Vt, sw.value
+
+    def gemm(self, opA, opB, A, B):
+        a, b = _fmat(A), _fmat(B)
+        c = np.zeros_like(a)
+        check(self.lib.dqmc_gemm_host(self.h, opA, opB, a.ctypes.data, b.ctypes.data, c.ctypes.data))
+        return c
+
+    def setupUdVStorage_and_calculateGreen(self):
+        check(self.lib.dqmc_udv_setup(self.h))
+
+    def advanceDownGreen(self, l):
+        check(self.lib.dqmc_advance(self.h, DOWN, l))
+
+    def advanceUpGreen(self, l):
+        check(self.lib.dqmc_advance(self.h, UP, l))
+
+    def wrapDownGreen(self, k):
+        check(self.lib.dqmc_wrap(self.h, DOWN, k))
+
+    def wrapUpGreen(self, k):
+        check(self.lib.dqmc_wrap(self.h, UP, k))
+
+    def reset_storage0(self):
+        check(self.lib.dqmc_reset_storage0(self.h))
+
+    def push_uniforms(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        check(self.lib.dqmc_push_uniforms_host(self.h, u.ctypes.data_as(_lib._DP), u.size))
+
+    def updateInSlice(self, k, thermalization=False):
+        check(self.lib.dqmc_update_slice(self.h, k, int(thermalization)))
+
+    def update_state(self):
+        st = _lib.dqmc_update_state()
+        check(self.lib.dqmc_get_update_state_host(self.h, C.byref(st)))
+        return st
+
+    def set_update_state(self, st):
+        check(self.lib.dqmc_set_update_state_host(self.h, C.byref(st)))
+
+    @property
+    def g(self):
+        g = np.zeros((self.ng, self.ng), dtype=np.complex128, order="F")
+        check(self.lib.dqmc_get_green_host(self.h, g.ctypes.data))
+        return g
+
+    def set_green(self, g, k):
+        a = _fmat(g)
+        check(self.lib.dqmc_set_green_host(self.h, a.ctypes.data, k))
+
+    @property
+    def g_inv_sv(self):
+        sv = np.zeros(self.ng)
+        check(self.lib.dqmc_get_sv_host(self.h, sv.ctypes.data_as(_lib._DP)))
+        return sv
+
+    def udv(self, l):
+        U = np.zeros((self.ng, self.ng), dtype=np.complex128, order="F")
+        Vt = np.zeros_like(U)
+        d = np.zeros(self.ng)
+        check(self.lib.dqmc_get_udv_host(self.h, l, U.ctypes.data, d.ctypes.data_as(_lib._DP), Vt.ctypes.data))
+        return U, d, Vt
+
+    @property
+    def currentTimeslice(self):
+        return self.lib.dqmc_current_timeslice(self.h)
+
+    def backup(self):
+        check(self.lib.dqmc_backup(self.h))
+
+    def restore(self):
+        check(self.lib.dqmc_restore(self.h))
+
+    def exchange_action(self):
+        v = C.c_double(0)
+        check(self.lib.dqmc_exchange_action_host(self.h, C.byref(v)))
+        return v.value
+
+    def set_exchange_parameter(self, r):
+        check(self.lib.dqmc_set_exchange_parameter(self.h, r))
+
+    def synchronize(self):
+        check(self.lib.dqmc_synchronize(self.h))
+
+    def profile_enable(self, on=True):
+        check(self.lib.dqmc_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        ms = (C.c_double * 8)()
+        ln = (C.c_uint64 * 8)()
+        check(self.lib.dqmc_profile_read(self.h, ms, ln))
+        names = ["bmult", "gemm", "jacobi", "update", "other"]
+        return {nm: (ms[i], int(ln[i])) for i, nm in enumerate(names)}
+
+
+class _CtxView(KernelContext):
+    """Non-owning KernelContext over the dqmc_ctx of a DetSDW replica (profiling, state inspection)."""
+
+    def __init__(self, lib, handle, info):
+        self.lib, self.h = lib, C.c_void_p(handle)
+        self.opdim, self.L, self.m, self.s = info.opdim, info.L, info.m, info.s
+        self.N, self.MSF, self.ng, self.n = info.N, info.MSF, info.n_g, info.n
+
+    def close(self):
+        self.h = None
+
+
+class DetSDW:
+    """The replica (C++ host layer): same method names as the reference's DetSDW / DetModel."""
+
+    def __init__(self, pars: SDWParams):
+        self.lib = load()
+        p = _lib.detsdw_params(
+            opdim=pars.opdim, L=pars.L, m=pars.m, s=pars.s, delaySteps=pars.delaySteps,
+            globalShift=int(pars.globalShift), globalUpdateInterval=pars.globalUpdateInterval,
+            weakZflux=int(pars.weakZflux), phi2bosons=int(pars.phi2bosons), device=pars.device,
+            simindex=pars.simindex, rngSeed=pars.rngSeed,
+            has_mux_muy=int(pars.mux is not None and pars.muy is not None),
+            updateMethod=UPDATE_METHOD[pars.updateMethod], bc=pars.bc.encode(),
+            beta=pars.beta, dtau=pars.dtau, r=pars.r, c=pars.c, u=pars.u, lambda_=pars.lambda_,
+            txhor=pars.txhor, txver=pars.txver, tyhor=pars.tyhor, tyver=pars.tyver,
+            mu=pars.mu, mux=pars.mux or 0.0, muy=pars.muy or 0.0, accRatio=pars.accRatio, cdwU=pars.cdwU)
+        h = C.c_void_p()
+        check(self.lib.detsdw_create(C.byref(p), C.byref(h)), host=True)
+        self.h = h
+        self.pars = pars
+
+    def close(self):
+        if self.h:
+            self.lib.detsdw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sweep(self, takeMeasurements=False):
+        check(self.lib.detsdw_sweep(self.h, int(takeMeasurements)), host=True)
+
+    def sweepThermalization(self):
+        check(self.lib.detsdw_sweep_thermalization(self.h), host=True)
+
+    @property
+    def info(self):
+        i = _lib.detsdw_info()
+        check(self.lib.detsdw_get_info(self.h, C.byref(i)), host=True)
+        return i
+
+    @property
+    def phi(self):
+        """(m+1, N, OPDIM) like the oracle; the ABI hands out the reference layout."""
+        i = self.info
+        a = np.zeros((i.N, i.opdim, i.m + 1), order="F")
+        check(self.lib.detsdw_get_phi(self.h, a.ctypes.data_as(_lib._DP)), host=True)
+        return np.transpose(a, (2, 0, 1)).copy()
+
+    def set_phi(self, phi_kNd):
+        ref = np.asfortranarray(np.transpose(np.asarray(phi_kNd, dtype=np.float64), (1, 2, 0)))
+        check(self.lib.detsdw_set_phi(self.h, ref.ctypes.data_as(_lib._DP)), host=True)
+
+    @property
+    def g(self):
+        n = self.info.n_g
+        g = np.zeros((n, n), dtype=np.complex128, order="F")
+        check(self.lib.detsdw_get_green(self.h, g.ctypes.data), host=True)
+        return g
+
+    @property
+    def g_inv_sv(self):
+        sv = np.zeros(self.info.n_g)
+        check(self.lib.detsdw_get_green_inv_sv(self.h, sv.ctypes.data_as(_lib._DP)), host=True)
+        return sv
+
+    def rand01(self):
+        return self.lib.detsdw_rng_rand01(self.h)
+
+    @property
+    def kernel_context(self):
+        return _CtxView(self.lib, self.lib.detsdw_ctx(self.h), self.info)
+
+    # replica exchange surface (reference src/detsdwopdim.h:116-153)
+    def get_exchange_parameter_value(self):
+        return self.lib.detsdw_get_exchange_parameter_value(self.h)
+
+    def set_exchange_parameter_value(self, v):
+        check(self.lib.detsdw_set_exchange_parameter_value(self.h, v), host=True)
+
+    def get_exchange_parameter_name(self):
+        return self.lib.detsdw_get_exchange_parameter_name(self.h).decode()
+
+    def get_exchange_action_contribution(self):
+        v = C.c_double(0)
+        check(self.lib.detsdw_get_exchange_action_contribution(self.h, C.byref(v)), host=True)
+        return v.value
+
+    def get_control_data(self):
+        cd = _lib.detsdw_control_data()
+        check(self.lib.detsdw_get_control_data(self.h, C.byref(cd)), host=True)
+        return cd
+
+    def set_control_data(self, cd):
+        check(self.lib.detsdw_set_control_data(self.h, C.byref(cd)), host=True)

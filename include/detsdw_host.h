@@ -1,0 +1,110 @@
+/*
+ * detsdw_host.h -- C API of the C++ host layer that sits ABOVE the kernel ABI (dqmc_hip.h).
+ *
+ * The host layer (detqmc_amd/csrc/host/detsdw.{h,cpp}) is the build's DetSDW / DetModelGC
+ * equivalent: it owns the RNG stream, the parameter checks and the control flow of
+ * sweep_skeleton / sweepUp / sweepDown / globalMove (reference src/detmodel.h:1266-1478,
+ * src/detsdwopdim.cpp:3461-3644, 4423-4502) and calls ONLY the C ABI of dqmc_hip.h.  This header
+ * exposes that C++ class with the reference's method names so that harnesses written in C, or
+ * Python through ctypes, can drive it; it mirrors the operator surface DetQMC<Model> /
+ * DetQMCPT<Model> require of a replica (src/detqmc.h:58-156, src/detmodel.h:138-156,
+ * src/detsdwopdim.h:116-153).
+ */
+#ifndef DETSDW_HOST_H_
+#define DETSDW_HOST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include "dqmc_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct detsdw_replica detsdw_replica;
+
+/* ModelParamsDetSDW (src/detsdwparams.h:24-120) + rngSeed/simindex of DetQMCParams
+ * (src/detqmcparams.h) as far as the sweep path uses them.  Unsupported reference options
+ * (cdwU != 0, turnoffFermions, rotate/scale proposals, Wolff cluster moves, CB_NONE) are rejected by
+ * detsdw_create with DQMC_EINVAL and a message naming the option. */
+typedef struct detsdw_params {
+    int32_t opdim;
+    int32_t L;
+    int32_t m;                   /* give m > 0 OR beta > 0, not both (detmodelparams.h:97-110) */
+    int32_t s;
+    int32_t delaySteps;
+    int32_t globalShift;
+    int32_t globalUpdateInterval;
+    int32_t weakZflux;
+    int32_t phi2bosons;
+    int32_t device;
+    int32_t simindex;
+    uint32_t rngSeed;
+    int32_t has_mux_muy;         /* if 0: mux = muy = mu (detsdwopdim.cpp:75-79) */
+    int32_t updateMethod;        /* 0 iterative, 1 woodbury, 2 delayed (all give the same chain; 0/1 run with D = 1) */
+    char bc[16];                 /* "pbc", "apbc-x", "apbc-y", "apbc-xy" */
+    double beta, dtau;
+    double r, c, u, lambda;
+    double txhor, txver, tyhor, tyver;
+    double mu, mux, muy;
+    double accRatio;
+    double cdwU;                 /* must be 0 */
+} detsdw_params;
+
+typedef struct detsdw_info {
+    int32_t opdim, L, N, MSF, n_g, m, s, n;
+    int32_t performedSweeps;
+    int32_t lastSweepDir;        /* +1 up, -1 down */
+    int32_t acceptedGlobalShifts, attemptedGlobalShifts;
+    int32_t currentTimeslice;
+    int32_t reserved;
+    double beta, dtau;
+    double phiDelta, lastAccRatioLocal_phi;
+    double r;                    /* exchange parameter */
+    uint64_t rngDrawn;           /* uniforms consumed from the stream so far */
+} detsdw_info;
+
+/* control data swapped in replica exchange: UpdateStatistics + AdjustmentData
+ * (src/detsdwopdim.cpp:5219-5247), fixed-size POD instead of a boost archive */
+typedef struct detsdw_control_data {
+    int32_t acceptedGlobalShifts, attemptedGlobalShifts;
+    dqmc_update_state adjust;
+} detsdw_control_data;
+
+/* createReplica (src/detsdwopdim.cpp:49-84) + DetSDW ctor (:158-361): checks parameters, seeds the
+ * RNG with (rngSeed, simindex + 1) (src/detqmc.h:181), draws the random field, builds UdV storage and
+ * G(beta) */
+int detsdw_create(const detsdw_params* p, detsdw_replica** out);
+void detsdw_destroy(detsdw_replica* r);
+const char* detsdw_last_error(void);
+
+/* DetModel::sweep / sweepThermalization (src/detmodel.h:138-147, src/detsdwopdim.cpp:4423-4502) */
+int detsdw_sweep(detsdw_replica* r, int takeMeasurements);
+int detsdw_sweep_thermalization(detsdw_replica* r);
+
+int detsdw_get_info(detsdw_replica* r, detsdw_info* out);
+/* phi in the reference layout (N, OPDIM, m+1) column-major */
+int detsdw_get_phi(detsdw_replica* r, double* phi);
+int detsdw_set_phi(detsdw_replica* r, const double* phi);      /* also rebuilds UdV storage and G */
+int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g);
+int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv);
+double detsdw_rng_rand01(detsdw_replica* r);                   /* draws from the replica's stream */
+dqmc_ctx* detsdw_ctx(detsdw_replica* r);
+
+/* replica-exchange surface (src/detsdwopdim.h:116-153, src/detsdwopdim.cpp:5185-5247) */
+double detsdw_get_exchange_parameter_value(detsdw_replica* r);
+int detsdw_set_exchange_parameter_value(detsdw_replica* r, double value);
+const char* detsdw_get_exchange_parameter_name(detsdw_replica* r);
+int detsdw_get_exchange_action_contribution(detsdw_replica* r, double* out);
+int detsdw_get_control_data(detsdw_replica* r, detsdw_control_data* out);
+int detsdw_set_control_data(detsdw_replica* r, const detsdw_control_data* in);
+/* get_replica_exchange_probability<DetSDW> (src/detsdwopdim.cpp:5251-5264) */
+double detsdw_replica_exchange_probability(double par1, double action1, double par2, double action2);
+
+/* RNG restatement, exposed for host-only tests: first n draws of RngWrapper(seed, processIndex) */
+int detsdw_rng_fill(uint32_t seed, uint32_t processIndex, double* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETSDW_HOST_H_ */

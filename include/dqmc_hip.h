@@ -1,0 +1,163 @@
+/*
+ * dqmc_hip.h -- C ABI of the MI355X (gfx950) DQMC sweep kernels.
+ *
+ * This is the drop-in boundary for the reference's DetModelGC/DetSDW hot path
+ * (crstnbr/detqmc).  The reference has NO runtime plugin boundary for this path: DetQMC<Model> is
+ * a class template and DetModelGC::sweep_skeleton takes the B-multiply / update routines as
+ * template callables (src/detqmc.h:58-59, src/detmodel.h:250-265).  Each entry point below
+ * replaces one of those callables / member functions; the reference interface it replaces is
+ * cited as file:line relative to /root/reference/src.  INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - complex fp64, interleaved (re, im) == std::complex<double> == arma::cx_double
+ *   - matrices are n_g x n_g, COLUMN-major, leading dimension n_g, n_g = MSF*N,
+ *     MSF = (opdim == 3 ? 4 : 2) (src/detsdwopdim.h:161), N = L*L, site = y*L + x
+ *   - phi is laid out like the reference's arma::Cube phi(N, OPDIM, m+1): index
+ *     site + N*(dim + OPDIM*k); slice k = 0 is unused (src/detsdwopdim.h:461-466)
+ *   - every function returns 0 on success, a negative DQMC_E* code otherwise; nothing throws
+ *     across the boundary; dqmc_last_error() gives the text
+ *   - one dqmc_ctx == one replica, bound to one device and one HIP stream; not thread-safe;
+ *     different contexts may be driven from different host threads
+ *   - functions whose name ends in _host take/return caller-owned HOST buffers and synchronise;
+ *     all others only enqueue work on the context's stream
+ */
+#ifndef DQMC_HIP_H_
+#define DQMC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dqmc_ctx dqmc_ctx;
+
+typedef struct dqmc_cplx { double re, im; } dqmc_cplx;
+
+enum {
+    DQMC_OK = 0,
+    DQMC_EINVAL = -1,     /* bad argument / unsupported parameter (reference: ParameterWrong) */
+    DQMC_EHIP = -2,       /* HIP runtime error */
+    DQMC_ENOCONV = -3,    /* decomposition did not converge (reference: "SVD failed (std)", udv.h:77-88) */
+    DQMC_ERNG = -4,       /* device ran out of pre-drawn uniforms */
+    DQMC_ENODEV = -5      /* no usable GPU */
+};
+
+enum { DQMC_BC_PBC = 0, DQMC_BC_APBC_X = 1, DQMC_BC_APBC_Y = 2, DQMC_BC_APBC_XY = 3 };
+enum { DQMC_LEFT = 0, DQMC_RIGHT = 1 };
+enum { DQMC_UP = +1, DQMC_DOWN = -1 };
+
+/* ModelParamsDetSDW fields the kernels depend on (src/detsdwparams.h:24-120) */
+typedef struct dqmc_params {
+    int32_t opdim;        /* 1, 2 or 3 */
+    int32_t L;            /* even */
+    int32_t m;            /* time slices */
+    int32_t s;            /* stabilisation interval, s < m */
+    int32_t delaySteps;   /* D, 1..N, MSF*D <= 64 */
+    int32_t bc;           /* DQMC_BC_* */
+    int32_t weakZflux;    /* only with opdim == 2 */
+    int32_t phi2bosons;
+    int32_t device;       /* HIP device ordinal */
+    int32_t reserved;
+    double dtau, r, c, u, lambda;
+    double txhor, txver, tyhor, tyver;
+    double mux, muy;
+    double accRatio;      /* target acceptance for the box step adaptation */
+} dqmc_params;
+
+/* AdjustmentData + slice bookkeeping that lives on the device between calls
+ * (src/detsdwopdim.h:481-577, RunningAverage.h) */
+typedef struct dqmc_update_state {
+    double phiDelta;
+    double targetAccRatio;
+    double lastAccRatio;
+    double ra_runningAverage;
+    double ra_values[100];
+    int32_t ra_samplesAdded;
+    int32_t ra_head;
+    uint64_t rng_consumed;   /* uniforms consumed from the pushed window */
+    uint64_t rng_avail;      /* size of the pushed window */
+    int32_t error;           /* DQMC_ERNG if the window ran dry */
+    int32_t reserved;
+} dqmc_update_state;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* replaces DetSDW ctor set-up of hopping constants / 4-site exponentials
+ * (detsdwopdim.cpp:217-264, :1598-1684) */
+int dqmc_create(const dqmc_params* p, dqmc_ctx** out);
+void dqmc_destroy(dqmc_ctx* ctx);
+const char* dqmc_last_error(void);
+int dqmc_synchronize(dqmc_ctx* ctx);
+/* raw stream handle (hipStream_t) for event timing by the harness */
+void* dqmc_stream(dqmc_ctx* ctx);
+
+/* ---- fields (a22) ---------------------------------------------------------------------- */
+/* upload phi and recompute cosh/sinh caches: updateCoshSinhTermsPhi (detsdwopdim.cpp:1175-1181) */
+int dqmc_set_fields_host(dqmc_ctx* ctx, const double* phi);
+int dqmc_get_fields_host(dqmc_ctx* ctx, double* phi, double* coshTermPhi, double* sinhTermPhi);
+
+/* ---- checkerboard B-multiplies (a10-a14) -------------------------------------------------- */
+/* A <- B(k2,k1) A | B(k2,k1)^-1 A | A B(k2,k1) | A B(k2,k1)^-1 on a HOST matrix:
+ * checkerboard{Left,Right}MultiplyBmat[Inv] (detsdwopdim.cpp:2076-2090, 2172-2186, 2307-2324,
+ * 2406-2420), i.e. the four callables of sweep_skeleton (detmodel.h:256-260). */
+int dqmc_bmult_host(dqmc_ctx* ctx, int side, int inverse, int k2, int k1, dqmc_cplx* A);
+
+/* ---- UdV decomposition and dense products (a2, L1) ---------------------------------------- */
+/* udvDecompose (udv.h:68-102): M = U diag(d) V_t^H, d descending */
+int dqmc_udv_decompose_host(dqmc_ctx* ctx, const dqmc_cplx* M, dqmc_cplx* U, double* d, dqmc_cplx* V_t,
+                            int* sweeps_used);
+/* C = op(A) op(B), op = identity (0) or conjugate transpose (1): the zgemm calls behind
+ * detmodel.h:784-815 */
+int dqmc_gemm_host(dqmc_ctx* ctx, int opA, int opB, const dqmc_cplx* A, const dqmc_cplx* B, dqmc_cplx* C);
+
+/* ---- stabilised Green's function (a3-a8) ---------------------------------------------------- */
+/* setupUdVStorage_and_calculateGreen_skeleton (detmodel.h:680-713): storage[0..n], G(beta) */
+int dqmc_udv_setup(dqmc_ctx* ctx);
+/* advanceUpGreen(l) / advanceDownGreen(l) incl. greenFromUdV / greenFromEye_and_UdV
+ * (detmodel.h:1109-1163, 956-1017, 769-860) */
+int dqmc_advance(dqmc_ctx* ctx, int dir, int l);
+/* wrapUpGreen(k): G <- B_{k+1} G B_{k+1}^-1 ; wrapDownGreen(k): G <- B_k^-1 G B_k
+ * (detmodel.h:1236-1259, 1066-1095) */
+int dqmc_wrap(dqmc_ctx* ctx, int dir, int k);
+/* sweepUp resets storage[0] to the identity (detmodel.h:1293-1295) */
+int dqmc_reset_storage0(dqmc_ctx* ctx);
+
+/* ---- local updates (a17-a20) ---------------------------------------------------------------- */
+/* replace the window of pre-drawn uniforms (0,1) the device consumes in stream order */
+int dqmc_push_uniforms_host(dqmc_ctx* ctx, const double* u, size_t n);
+/* updateInSlice (detsdwopdim.cpp:2428-2489, delayed updates :3023-3175, box proposals :3922-3931,
+ * deltaSPhi :4186-4239, get_delta_forsite :3179-3289); thermalization != 0 adds the step-size
+ * adaptation of updateInSliceThermalization (:3294-3375) */
+int dqmc_update_slice(dqmc_ctx* ctx, int k, int thermalization);
+int dqmc_get_update_state_host(dqmc_ctx* ctx, dqmc_update_state* out);
+int dqmc_set_update_state_host(dqmc_ctx* ctx, const dqmc_update_state* in);
+
+/* ---- state access ------------------------------------------------------------------------------ */
+int dqmc_get_green_host(dqmc_ctx* ctx, dqmc_cplx* out);
+int dqmc_set_green_host(dqmc_ctx* ctx, const dqmc_cplx* in, int currentTimeslice);
+int dqmc_get_sv_host(dqmc_ctx* ctx, double* out);                 /* green_inv_sv (detmodel.h:466) */
+int dqmc_get_udv_host(dqmc_ctx* ctx, int l, dqmc_cplx* U, double* d, dqmc_cplx* V_t);
+int dqmc_current_timeslice(dqmc_ctx* ctx);
+
+/* ---- global-move support (a21) ------------------------------------------------------------------ */
+/* globalMoveStoreBackups / globalMoveRestoreBackups (detsdwopdim.cpp:3886-3917): swap G, sv,
+ * UdV storage, copy fields */
+int dqmc_backup(dqmc_ctx* ctx);
+int dqmc_restore(dqmc_ctx* ctx);
+/* 1/2 dtau sum phi^2 (get_exchange_action_contribution, detsdwopdim.cpp:5205-5216) */
+int dqmc_exchange_action_host(dqmc_ctx* ctx, double* out);
+/* set_exchange_parameter_value (detsdwopdim.cpp:5195-5197): r only enters the bosonic action */
+int dqmc_set_exchange_parameter(dqmc_ctx* ctx, double r);
+
+/* ---- measurement helpers for bench.py -------------------------------------------------------- */
+/* per-kernel-family device time (ms) and launch counts accumulated with HIP events on the context's
+ * stream while profiling is switched on; families: 0 bmult 1 gemm 2 jacobi 3 update 4 other */
+int dqmc_profile_enable(dqmc_ctx* ctx, int on);
+int dqmc_profile_read(dqmc_ctx* ctx, double ms[8], uint64_t launches[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQMC_HIP_H_ */

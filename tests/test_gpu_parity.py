@@ -1,0 +1,364 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against
+  (1) the committed golden fixtures generated from the REAL reference (tests/golden/*.npz), and
+  (2) the CPU oracle (oracle/detsdw_oracle.py) on the same seeded inputs.
+Tolerance: 1e-10 relative for fp64 Green's functions / singular values (BASELINE.json north_star);
+field configurations and the RNG stream position must agree exactly (same Markov chain).
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, oracle_params, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+SMALL = ["o2_L4", "o2_L4_s7", "o2_L4_flux", "o2_L4_apbc", "o1_L4", "o3_L4", "o2_L6_seed"]
+
+
+def _ctx_from_params(a, **over):
+    from detqmc_amd import KernelContext
+    op = oracle_params(a).finalize()
+    kw = dict(opdim=op.opdim, L=op.L, m=op.m, s=op.s, dtau=op.dtau, delaySteps=op.delaySteps, bc=op.bc,
+              weakZflux=op.weakZflux, r=op.r, c=op.c, u=op.u, lambda_=op.lambda_, txhor=op.txhor,
+              txver=op.txver, tyhor=op.tyhor, tyver=op.tyver, mux=op.mux, muy=op.muy, accRatio=op.accRatio)
+    kw.update(over)
+    return KernelContext(**kw), op
+
+
+def _sdw_params(a, **over):
+    from detqmc_amd import SDWParams
+    op = oracle_params(a)
+    kw = dict(opdim=op.opdim, L=op.L, beta=op.beta, dtau=op.dtau, s=op.s, r=op.r, c=op.c, u=op.u,
+              lambda_=op.lambda_, txhor=op.txhor, txver=op.txver, tyhor=op.tyhor, tyver=op.tyver, mu=op.mu,
+              mux=op.mux, muy=op.muy, accRatio=op.accRatio, delaySteps=op.delaySteps, bc=op.bc,
+              weakZflux=op.weakZflux, globalShift=op.globalShift, globalUpdateInterval=op.globalUpdateInterval,
+              rngSeed=op.rngSeed, simindex=op.simindex)
+    kw.update(over)
+    return SDWParams(**kw)
+
+
+def _golden_phi(g, key):
+    return np.transpose(g[key], (2, 0, 1))        # (N, OPDIM, m+1) -> (m+1, N, OPDIM)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense products on the matrix cores
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L", [4, 6, 8])
+def test_gemm_all_ops(L):
+    from detqmc_amd import KernelContext
+    ctx = KernelContext(2, L, 20, 10, 0.1, delaySteps=4)
+    n = ctx.ng
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    B = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    for opA in (0, 1):
+        for opB in (0, 1):
+            ref = (A.conj().T if opA else A) @ (B.conj().T if opB else B)
+            got = ctx.gemm(opA, opB, A, B)
+            assert relerr(got, ref) < 1e-13, (opA, opB)
+    # identity with an asymmetric partner catches transposed fragment layouts
+    I = np.eye(n)
+    assert relerr(ctx.gemm(0, 0, I, B), B) < 1e-15
+    assert relerr(ctx.gemm(0, 0, A, I), A) < 1e-15
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# checkerboard B-multiplies (a10-a14)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"])
+def test_bmult_vs_reference(name):
+    from detsdw_oracle import make_test_matrix
+    g = load_golden(name)
+    ctx, op = _ctx_from_params(g["params"])
+    ctx.set_fields(_golden_phi(g, "init_phi"))
+    phi, ch, sh = ctx.get_fields()
+    assert np.array_equal(phi[1:], _golden_phi(g, "init_phi")[1:])
+    if "init_coshTermPhi" in g:
+        assert relerr(ch[1:], g["init_coshTermPhi"].T[1:]) < 1e-14
+        assert relerr(sh[1:], g["init_sinhTermPhi"].T[1:]) < 1e-14
+    A = make_test_matrix(ctx.ng)
+    k = int(g["bmult_k"][0])
+    assert relerr(ctx.leftMultiplyBmat(A, k, k - 1), g["bmult_left"]) < 1e-12
+    assert relerr(ctx.rightMultiplyBmat(A, k, k - 1), g["bmult_right"]) < 1e-12
+    if "bmult_leftinv" in g:
+        assert relerr(ctx.leftMultiplyBmatInv(A, k, k - 1), g["bmult_leftinv"]) < 1e-12
+        assert relerr(ctx.rightMultiplyBmatInv(A, k, k - 1), g["bmult_rightinv"]) < 1e-12
+    if "bchain_left" in g:
+        k2 = int(g["bchain_k2"][0])
+        assert relerr(ctx.leftMultiplyBmat(A, k2, 0), g["bchain_left"]) < 1e-12
+        assert relerr(ctx.leftMultiplyBmatInv(A, k2, 0), g["bchain_leftinv"]) < 1e-12
+        assert relerr(ctx.rightMultiplyBmat(A, k2, 0), g["bchain_right"]) < 1e-12
+        assert relerr(ctx.rightMultiplyBmatInv(A, k2, 0), g["bchain_rightinv"]) < 1e-12
+    # exact-to-rounding identity of the symmetric break-up: B^-1 B = 1
+    R = ctx.leftMultiplyBmatInv(ctx.leftMultiplyBmat(A, op.m, 0), op.m, 0)
+    assert relerr(R, A) < 1e-9
+    R = ctx.rightMultiplyBmatInv(ctx.rightMultiplyBmat(A, op.m, 0), op.m, 0)
+    assert relerr(R, A) < 1e-9
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# UdV decomposition (a2)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,opdim", [(4, 2), (6, 2), (8, 2), (4, 3)])
+def test_udv_decompose(L, opdim):
+    from detqmc_amd import KernelContext
+    ctx = KernelContext(opdim, L, 20, 10, 0.1, delaySteps=4)
+    n = ctx.ng
+    rng = np.random.default_rng(11)
+    Q1, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    for d_true in (np.linspace(2.0, 0.5, n), np.logspace(12, -12, n)):
+        M = (Q1 * d_true[None, :]) @ Q2.conj().T
+        U, d, Vt, sweeps = ctx.udvDecompose(M)
+        assert np.all(np.diff(d) <= 0), "singular values must be sorted descending like zgesvd"
+        sref = np.linalg.svd(M, compute_uv=False)
+        assert np.max(np.abs(d - sref) / sref[0]) < 1e-13
+        assert relerr(U.conj().T @ U, np.eye(n)) < 1e-12
+        assert relerr(Vt.conj().T @ Vt, np.eye(n)) < 1e-12
+        assert relerr((U * d[None, :]) @ Vt.conj().T, M) < 1e-12
+        assert 1 <= sweeps <= 30
+    # column-graded matrix (the UdV chain's shape): high RELATIVE accuracy of every singular value
+    W = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    dd = np.logspace(10, -10, n)
+    M = W * dd[None, :]
+    U, d, Vt, _ = ctx.udvDecompose(M)
+    import scipy.linalg as sla
+    # reference values from the same matrix with columns rescaled in extended precision is overkill;
+    # one-sided Jacobi in LAPACK (zgesvj) has the same relative-accuracy property
+    sref = sla.svd(M, compute_uv=False, lapack_driver="gesvd")
+    assert np.max(np.abs(d - sref) / sref[0]) < 1e-13
+    assert relerr((U * d[None, :]) @ Vt.conj().T, M) < 1e-12
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# stabilised Green's function from scratch and through advance / wrap (a3-a8)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"])
+def test_green_from_scratch_vs_reference(name):
+    g = load_golden(name)
+    ctx, op = _ctx_from_params(g["params"])
+    ctx.set_fields(_golden_phi(g, "init_phi"))
+    ctx.setupUdVStorage_and_calculateGreen()
+    assert ctx.currentTimeslice == op.m
+    assert relerr(ctx.g, g["init_g"]) < TOL
+    assert relerr(ctx.g_inv_sv, g["init_g_inv_sv"]) < TOL
+    for l in range(op.n + 1):
+        U, d, Vt = ctx.udv(l)
+        assert np.max(np.abs(d - g["init_udv_d"][:, l]) / g["init_udv_d"][:, l]) < 1e-9
+        if f"init_udv_U_{l}" in g and l > 0:
+            # U d V^H is unique even though U, V are only fixed up to phases
+            ref = (g[f"init_udv_U_{l}"] * g["init_udv_d"][:, l][None, :]) @ g[f"init_udv_Vt_{l}"].conj().T
+            assert relerr((U * d[None, :]) @ Vt.conj().T, ref) < 1e-10
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["o2_L4", "o2_L4_s7", "o2_L6_seed", "o3_L4"])
+def test_wrap_advance_without_updates_vs_oracle(name):
+    """One down sweep and one up sweep with the fields frozen: every advance must reproduce the
+    oracle's G; wrapped G must agree with the freshly advanced one (the reference's
+    --logGreenConsistency self-check, detsdwopdim.cpp:4831-4856)."""
+    from detsdw_oracle import DetSDWOracle
+    g = load_golden(name)
+    ctx, op = _ctx_from_params(g["params"])
+    o = DetSDWOracle(oracle_params(g["params"]))
+    ctx.set_fields(o.phi)
+    ctx.setupUdVStorage_and_calculateGreen()
+    n, s, m = op.n, op.s, op.m
+    for k in range(m, (n - 1) * s, -1):
+        ctx.wrapDownGreen(k); o.wrapDownGreen(k)
+    assert relerr(ctx.g, o.g) < TOL
+    for l in range(n - 1, 0, -1):
+        wrapped = ctx.g
+        ctx.advanceDownGreen(l + 1); o.advanceDownGreen(l + 1)
+        assert relerr(ctx.g, o.g) < TOL
+        assert relerr(ctx.g_inv_sv, o.g_inv_sv) < TOL
+        assert relerr(wrapped, ctx.g) < 1e-7
+        for k in range(l * s, (l - 1) * s, -1):
+            ctx.wrapDownGreen(k); o.wrapDownGreen(k)
+    ctx.advanceDownGreen(1); o.advanceDownGreen(1)
+    assert relerr(ctx.g, o.g) < TOL
+    # up
+    ctx.reset_storage0()
+    from detsdw_oracle import UdV
+    o.UdVStorage[0] = UdV.eye(o.ng)
+    for l in range(0, n - 1):
+        for k in range(l * s + 1, (l + 1) * s + 1):
+            ctx.wrapUpGreen(k - 1); o.wrapUpGreen(k - 1)
+        ctx.advanceUpGreen(l); o.advanceUpGreen(l)
+        assert relerr(ctx.g, o.g) < TOL
+    for k in range((n - 1) * s + 1, m + 1):
+        ctx.wrapUpGreen(k - 1); o.wrapUpGreen(k - 1)
+    ctx.advanceUpGreen(n - 1); o.advanceUpGreen(n - 1)
+    assert relerr(ctx.g, o.g) < TOL
+    assert relerr(ctx.g_inv_sv, o.g_inv_sv) < TOL
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# local updates of one slice (a17-a20)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"])
+def test_update_slice_vs_reference(name):
+    from dsfmt_oracle import RngWrapper
+    g = load_golden(name)
+    ctx, op = _ctx_from_params(g["params"])
+    phi0 = _golden_phi(g, "init_phi")
+    ctx.set_fields(phi0)
+    ctx.setupUdVStorage_and_calculateGreen()
+    # the reference's stream: (OPDIM+1) draws per site and slice went into the random field
+    r = RngWrapper(op.rngSeed, op.simindex + 1)
+    for _ in range((op.opdim + 1) * op.N * op.m):
+        r.rand01()
+    window = np.array([r.rand01() for _ in range((op.opdim + 1) * op.N)])
+    ctx.push_uniforms(window)
+    ctx.updateInSlice(op.m, thermalization=True)
+    st = ctx.update_state()
+    phi, ch, sh = ctx.get_fields()
+    assert np.array_equal(phi[op.m], g["slice_phi_m"]), "accept/reject decisions differ from the reference"
+    assert relerr(ctx.g, g["slice_g"]) < TOL
+    assert abs(st.lastAccRatio - g["slice_accRatio"][0]) < 1e-15
+    assert st.ra_samplesAdded == 1
+    # cosh/sinh caches consistent with the new field (reference consistencyCheck, detsdwopdim.cpp:4617-4667)
+    nrm = np.sqrt(np.sum(phi[op.m] ** 2, axis=1))
+    assert relerr(ch[op.m], np.cosh(op.lambda_ * op.dtau * nrm)) < 1e-13
+    assert relerr(sh[op.m], np.sinh(op.lambda_ * op.dtau * nrm) / nrm) < 1e-13
+    ctx.wrapDownGreen(op.m)
+    if "slice_g_wrapped" in g:
+        assert relerr(ctx.g, g["slice_g_wrapped"]) < TOL
+    ctx.close()
+
+
+def test_update_slice_delay_steps_invariance():
+    """The chain must not depend on the delay depth (reference: iterative / woodbury / delayed are
+    alternative update methods for the same move, detsdwopdim.cpp:2493-3175)."""
+    from dsfmt_oracle import RngWrapper
+    g = load_golden("o2_L4")
+    res = []
+    for D in (1, 3, 6, 16):
+        ctx, op = _ctx_from_params(g["params"], delaySteps=D)
+        ctx.set_fields(_golden_phi(g, "init_phi"))
+        ctx.setupUdVStorage_and_calculateGreen()
+        r = RngWrapper(op.rngSeed, op.simindex + 1)
+        for _ in range((op.opdim + 1) * op.N * op.m):
+            r.rand01()
+        ctx.push_uniforms(np.array([r.rand01() for _ in range((op.opdim + 1) * op.N)]))
+        ctx.updateInSlice(op.m, thermalization=False)
+        res.append((ctx.get_fields()[0][op.m], ctx.g, ctx.update_state().rng_consumed))
+        ctx.close()
+    for phi, G, used in res[1:]:
+        assert np.array_equal(phi, res[0][0])
+        assert relerr(G, res[0][1]) < 1e-11
+        assert used == res[0][2]
+    assert np.array_equal(res[0][0], g["slice_phi_m"])
+
+
+def test_rng_window_exhaustion_is_reported():
+    from detqmc_amd import DqmcError
+    g = load_golden("o2_L4")
+    ctx, op = _ctx_from_params(g["params"])
+    ctx.set_fields(_golden_phi(g, "init_phi"))
+    ctx.setupUdVStorage_and_calculateGreen()
+    ctx.push_uniforms(np.full(5, 0.5))
+    ctx.updateInSlice(op.m)
+    with pytest.raises(DqmcError) as e:
+        ctx.update_state()
+    assert e.value.code == -4
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# whole sweeps through the C++ host layer (a9) -- identical Markov chain as the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5", "o2_L4_gshift"])
+def test_replica_trajectory_vs_reference(name):
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    rep = DetSDW(_sdw_params(g["params"]))
+    info = rep.info
+    if "init_phi" in g:
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, "init_phi")[1:])
+        assert relerr(rep.g, g["init_g"]) < TOL
+        assert relerr(rep.g_inv_sv, g["init_g_inv_sv"]) < TOL
+    i = 1
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}: trajectory diverged"
+        assert relerr(rep.g, g[f"sweep{i}_g"]) < TOL, f"sweep {i}"
+        assert relerr(rep.g_inv_sv, g[f"sweep{i}_g_inv_sv"]) < TOL
+        inf = rep.info
+        assert inf.phiDelta == g[f"sweep{i}_phiDelta"][0]
+        assert abs(inf.lastAccRatioLocal_phi - g[f"sweep{i}_lastAccRatio"][0]) < 1e-15
+        assert inf.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert inf.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+        i += 1
+    assert i > 2
+    act = rep.get_exchange_action_contribution()
+    assert abs(act - g["exchange_action"][0]) < 1e-12 * abs(g["exchange_action"][0])
+    nxt = np.array([rep.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"]), "RNG stream position differs from the reference"
+    assert info.n_g == g["init_g"].shape[0]
+    rep.close()
+
+
+def test_measurement_sweeps_do_not_adapt_step_size():
+    from detqmc_amd import DetSDW
+    g = load_golden("o2_L4")
+    rep = DetSDW(_sdw_params(g["params"]))
+    for _ in range(2):
+        rep.sweep(False)
+    assert rep.info.phiDelta == 0.5
+    assert rep.get_control_data().adjust.ra_samplesAdded == 0
+    rep.close()
+
+
+def test_update_methods_give_the_same_chain():
+    from detqmc_amd import DetSDW
+    g = load_golden("o2_L4")
+    out = []
+    for um in ("delayed", "woodbury", "iterative"):
+        rep = DetSDW(_sdw_params(g["params"], updateMethod=um))
+        rep.sweepThermalization()
+        rep.sweepThermalization()
+        out.append((rep.phi, rep.g))
+        rep.close()
+    for phi, G in out[1:]:
+        assert np.array_equal(phi, out[0][0])
+        assert relerr(G, out[0][1]) < TOL
+    assert np.array_equal(out[0][0][1:], _golden_phi(g, "sweep2_phi")[1:])
+
+
+# ------------------------------------------------------------------------------------------------
+# headline size (BASELINE config 3): checksums from the reference + size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_headline_size_vs_reference_checksums():
+    from detqmc_amd import DetSDW
+    from detsdw_oracle import make_test_matrix
+    g = load_golden("o2_L16_b10")
+    rep = DetSDW(_sdw_params(g["params"]))
+    G = rep.g
+    assert relerr(G[::16, ::16], g["init_g_sub16"]) < TOL
+    assert relerr(np.diag(G), g["init_g_diag"]) < TOL
+    assert abs(np.linalg.norm(G) - g["init_g_fro"][0]) < TOL * g["init_g_fro"][0]
+    assert relerr(rep.g_inv_sv, g["init_g_inv_sv"]) < TOL
+    for i in (1, 2):
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}"
+        G = rep.g
+        assert relerr(G[::16, ::16], g[f"sweep{i}_g_sub16"]) < TOL
+        assert relerr(np.diag(G), g[f"sweep{i}_g_diag"]) < TOL
+        assert relerr(rep.g_inv_sv, g[f"sweep{i}_g_inv_sv"]) < TOL
+    # properties that need no reference data
+    ctx = rep.kernel_context
+    A = make_test_matrix(ctx.ng)
+    assert relerr(ctx.leftMultiplyBmatInv(ctx.leftMultiplyBmat(A, 10, 0), 10, 0), A) < 1e-10
+    assert relerr(ctx.rightMultiplyBmat(ctx.rightMultiplyBmatInv(A, 100, 90), 100, 90), A) < 1e-10
+    U, d, Vt = ctx.udv(5)
+    I = np.eye(ctx.ng)
+    assert relerr(U.conj().T @ U, I) < 1e-11 and relerr(Vt.conj().T @ Vt, I) < 1e-11
+    assert np.all(np.diff(d) <= 0)
+    rep.close()
