@@ -41,8 +41,11 @@ struct dqmc_ctx {
     UdVSlot spare{}, tmpudv{};
     cplx *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *T4 = nullptr;
     SvdWork sw{};
-    int max_jacobi_sweeps = 40;
+    int max_jacobi_sweeps = 80;
     int last_svd_sweeps = 0;
+    double last_svd_residual = 0.0;
+    uint64_t svd_calls = 0, svd_sweeps_total = 0;
+    int svd_sweeps_max = 0;
     // updates
     cplx *X = nullptr, *Gr = nullptr, *W = nullptr;
     double* uniforms = nullptr;
@@ -278,7 +281,8 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     A_(dalloc(c, &c->T1, n2)); A_(dalloc(c, &c->T2, n2)); A_(dalloc(c, &c->T3, n2)); A_(dalloc(c, &c->T4, n2));
     A_(dalloc(c, &c->sw.A, n2)); A_(dalloc(c, &c->sw.V, n2));
     A_(dalloc(c, &c->sw.norms, (size_t)ng)); A_(dalloc(c, &c->sw.rank, (size_t)ng)); A_(dalloc(c, &c->sw.flag, 1));
-    HIPCHK(hipHostMalloc((void**)&c->sw.hflag, sizeof(int)));
+    HIPCHK(hipHostMalloc((void**)&c->sw.hflag, sizeof(unsigned long long)));
+    c->sw.last_residual = &c->last_svd_residual;
     {
         int bw = svd_block_cols(ng);
         int nblk = ng / bw;
@@ -383,6 +387,8 @@ static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
     if (sweeps == DQMC_ENOCONV) return fail(DQMC_ENOCONV, "SVD failed (Jacobi did not converge)");
     if (sweeps < 0) return fail(sweeps, std::string("SVD failed: ") + hipGetErrorString(hipGetLastError()));
     c->last_svd_sweeps = sweeps;
+    c->svd_calls += 1; c->svd_sweeps_total += sweeps;
+    if (sweeps > c->svd_sweeps_max) c->svd_sweeps_max = sweeps;
     return DQMC_OK;
 }
 
@@ -708,11 +714,13 @@ extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
     prof_collect(c);
     c->prof = on != 0;
     for (int i = 0; i < FAM_COUNT; ++i) { c->fam_ms[i] = 0; c->fam_launches[i] = 0; }
+    c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0;
     return DQMC_OK;
 }
 extern "C" int dqmc_profile_read(dqmc_ctx* c, double ms[8], uint64_t launches[8]) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
     prof_collect(c);
     for (int i = 0; i < FAM_COUNT; ++i) { if (ms) ms[i] = c->fam_ms[i]; if (launches) launches[i] = c->fam_launches[i]; }
+    if (launches) { launches[5] = c->svd_calls; launches[6] = c->svd_sweeps_total; launches[7] = (uint64_t)c->svd_sweeps_max; }
     return DQMC_OK;
 }

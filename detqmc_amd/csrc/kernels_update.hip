@@ -40,6 +40,15 @@ __device__ __forceinline__ double u_wave_sum(double v) {
     return v;
 }
 
+// phi + randRange(low, high) with every operation rounded on its own, as on the CPU reference
+__device__ __forceinline__ double propose_component(double phi_old, double low, double high, double u) {
+#pragma clang fp contract(off)
+    double span = high - low;
+    double t = span * u;
+    double r = low + t;
+    return phi_old + r;
+}
+
 // e^{sign dtau V} at one site (detsdwopdim.cpp:3188-3229, cdwU == 0)
 template<int MSF>
 __device__ __forceinline__ void ev_matrix(cplx (&V)[MSF][MSF], double sign, const double* p, int opdim,
@@ -187,8 +196,9 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
         for (int d = 0; d < OPDIM; ++d) {
             oldphi[d] = phik[d * N + site];
             double low = -phiDelta, high = phiDelta;
-            double r = low + (high - low) * uni[cur + d];           // randRange (rngwrapper.h:59-61)
-            newphi[d] = oldphi[d] + r;
+            // randRange (rngwrapper.h:59-61); separately rounded mul and add like the CPU reference --
+            // a contracted fma would change the proposed field in the last bit
+            newphi[d] = propose_component(oldphi[d], low, high, uni[cur + d]);
         }
         cur += OPDIM;
         double dsphi;

@@ -224,7 +224,9 @@ class KernelContext:
         ln = (C.c_uint64 * 8)()
         check(self.lib.dqmc_profile_read(self.h, ms, ln))
         names = ["bmult", "gemm", "jacobi", "update", "other"]
-        return {nm: (ms[i], int(ln[i])) for i, nm in enumerate(names)}
+        out = {nm: (ms[i], int(ln[i])) for i, nm in enumerate(names)}
+        out["svd_calls"], out["svd_sweeps_total"], out["svd_sweeps_max"] = int(ln[5]), int(ln[6]), int(ln[7])
+        return out
 
 
 class _CtxView(KernelContext):

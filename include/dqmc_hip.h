@@ -153,7 +153,8 @@ int dqmc_set_exchange_parameter(dqmc_ctx* ctx, double r);
 
 /* ---- measurement helpers for bench.py -------------------------------------------------------- */
 /* per-kernel-family device time (ms) and launch counts accumulated with HIP events on the context's
- * stream while profiling is switched on; families: 0 bmult 1 gemm 2 jacobi 3 update 4 other */
+ * stream while profiling is switched on; families: 0 bmult 1 gemm 2 jacobi 3 update 4 other;
+ * launches[5..7] = UdV decompositions done, Jacobi sweeps in total, most sweeps one of them took */
 int dqmc_profile_enable(dqmc_ctx* ctx, int on);
 int dqmc_profile_read(dqmc_ctx* ctx, double ms[8], uint64_t launches[8]);
 
