@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Benchmark harness: DQMC sweeps/sec for the BASELINE.json headline workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One process per GPU (for N > 1 launched by torch.distributed.run).  A "step" is one
+sweepThermalization() of one replica: SDW O(2), L=16, beta=10, dtau=0.1 (m=100), s=10, checkerboard,
+delayed updates (delaySteps=16), no fermion measurements.  Each rank runs an
+independent Markov chain (simindex = rank, as the reference's DetQMC does per process); there is no
+data-path collective, so the value is the sum over ranks and scaling is weak.  Rank 0 prints ONE
+JSON line with `roofline` (dominant kernel, timed live with HIP events on the kernel's own stream)
+and, at N=1, `cpu_baseline` (the real reference binary from oracle/_ref when it runs on this host,
+else the numpy oracle port) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=16, r=-1.0, c=3.0, u=1.0, lambda_=1.0,
+                mu=-0.5, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, bc="pbc", accRatio=0.5,
+                rngSeed=1020304050)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(max_seconds=200):
+    """Reference CPU sweeps/s on this host for the same workload (bounded sample)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_fast_o2")
+    args = ["L=16", "beta=10", "dtau=0.1", "s=10", "delaySteps=16", "opdim=2", "mode=time", "warmup=0", "sweeps=1"]
+    if os.path.exists(exe):
+        try:
+            env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+            out = subprocess.run([exe, "/tmp"] + args, capture_output=True, text=True, timeout=max_seconds, env=env)
+            for line in out.stdout.splitlines():
+                if line.startswith("REF_TIMING"):
+                    kv = dict(tok.split("=") for tok in line.split()[1:])
+                    return {"value": float(kv["sweeps_per_s"]), "unit": "sweeps/s", "cores": 1, "kind": "reference",
+                            "sample": "crstnbr/detqmc DetSDW<CB_ASSAAD_BERG,2> built from the reference sources "
+                                      "(-O3 -ffast-math -mavx2 -mfma, MKL 1 thread): 1 sweepThermalization() after "
+                                      "init, %s s" % kv["seconds"]}
+        except Exception as e:                      # binary cannot run on this host: use the port
+            sys.stderr.write("reference binary unusable (%r), timing the oracle port instead\n" % (e,))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))   # cpu_baseline leg: the oracle is what is timed here
+    from detsdw_oracle import DetSDWOracle, SDWParams as OP
+    kw = {k: v for k, v in WORKLOAD.items() if k in OP.__dataclass_fields__}
+    o = DetSDWOracle(OP(**kw))
+    t0 = time.time()
+    o.sweepThermalization()
+    dt = time.time() - t0
+    import threadpoolctl
+    thr = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
+    return {"value": 1.0 / dt, "unit": "sweeps/s", "cores": thr, "kind": "port",
+            "sample": "oracle/detsdw_oracle.py (numpy + scipy zgesvd): 1 sweepThermalization() after init, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from detqmc_amd import DetSDW, SDWParams
+    rep = DetSDW(SDWParams(device=local, simindex=rank, **WORKLOAD))
+    ctx = rep.kernel_context
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        rep.sweepThermalization()
+    ctx.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rep.sweepThermalization()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        info = rep.info
+        n = info.n_g
+        # dominant kernel: one Jacobi round = every column of A and of V read once and written once
+        jac_ms, jac_launches = prof["jacobi"]
+        bytes_per_launch = 4.0 * n * n * 16.0
+        fam = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items() if isinstance(v, tuple)}
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_jacobi.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        avg_us = 1e3 * jac_ms / max(jac_launches, 1)
+        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9 if jac_launches else 0.0
+        res = {
+            "metric": "DQMC sweeps/sec (SDW-O2 L=16 beta=10 fp64)",
+            "value": world * a.steps / dt,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (random initial field, fixed seed)",
+            "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(16) "
+                                   "sweepThermalization, one independent chain per GPU",
+                       "n_g": n, "m": info.m, "replicas_per_gpu": 1},
+            "roofline": {"kernel": "k_jacobi_round<8,2>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us,
+                         "launches": jac_launches},
+            "device_ms_by_family": fam,
+            "svd": {"calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
+                    "max_sweeps": prof["svd_sweeps_max"]},
+            "acceptance": info.lastAccRatioLocal_phi,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    rep.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

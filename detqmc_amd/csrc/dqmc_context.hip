@@ -377,13 +377,24 @@ static void gemm_dev(dqmc_ctx* c, int opA, int opB, const cplx* A, const cplx* B
 }
 
 // udvDecompose (udv.h:68-102) of diag(rowscale) M diag(colscale)
+static void svd_prof_begin(void* u) {
+    dqmc_ctx* c = (dqmc_ctx*)u;
+    if (c->ev_used + 2 > c->ev_pool.size())
+        for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
+    (void)hipEventRecord(c->ev_pool[c->ev_used], c->st);
+    c->ev_open.push_back({FAM_JACOBI, (int)c->ev_used});
+    c->ev_used += 2;
+}
+static void svd_prof_end(void* u, int launches) {
+    dqmc_ctx* c = (dqmc_ctx*)u;
+    (void)hipEventRecord(c->ev_pool[c->ev_open.back().second + 1], c->st);
+    c->fam_launches[FAM_JACOBI] += launches;
+}
 static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, UdVSlot out) {
-    int sweeps;
-    {
-        ProfScope ps(c, FAM_JACOBI, 0);
-        sweeps = run_svd(c->st, c->n_g, M, c->n_g, colscale, rowscale, out.U, out.d, out.Vt, c->sw, c->max_jacobi_sweeps);
-        if (sweeps > 0) c->fam_launches[FAM_JACOBI] += (uint64_t)sweeps * c->sw.nrounds;
-    }
+    SvdProfHooks hooks{svd_prof_begin, svd_prof_end, c};
+    int sweeps = run_svd(c->st, c->n_g, M, c->n_g, colscale, rowscale, out.U, out.d, out.Vt, c->sw, c->max_jacobi_sweeps,
+                         c->prof ? &hooks : nullptr);
+    if (!c->prof && sweeps > 0) c->fam_launches[FAM_JACOBI] += (uint64_t)sweeps * c->sw.nrounds;
     if (sweeps == DQMC_ENOCONV) return fail(DQMC_ENOCONV, "SVD failed (Jacobi did not converge)");
     if (sweeps < 0) return fail(sweeps, std::string("SVD failed: ") + hipGetErrorString(hipGetLastError()));
     c->last_svd_sweeps = sweeps;

@@ -67,8 +67,10 @@ struct SvdWork {
     unsigned long long* flag; unsigned long long* hflag /*pinned host*/; double* last_residual;
     const int* rounds; int nrounds; int nblk;   // tournament table [nrounds][nblk/2][2]
 };
+// optional timing hooks around each batch of back-to-back round launches (one Jacobi sweep)
+struct SvdProfHooks { void (*begin)(void* user); void (*end)(void* user, int launches); void* user; };
 int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscale, const double* rowscale,
-            cplx* U, double* d, cplx* Vt, const SvdWork& w, int max_sweeps);
+            cplx* U, double* d, cplx* Vt, const SvdWork& w, int max_sweeps, const SvdProfHooks* hooks = nullptr);
 int svd_block_cols(int n);      // columns per block used by the Jacobi kernel for this n
 
 // local updates

@@ -280,7 +280,7 @@ static void launch_round(hipStream_t st, cplx* A, cplx* V, int n, const int* pai
 }
 
 int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscale, const double* rowscale,
-            cplx* U, double* d, cplx* Vt, const SvdWork& w, int max_sweeps) {
+            cplx* U, double* d, cplx* Vt, const SvdWork& w, int max_sweeps, const SvdProfHooks* hooks) {
     const int* perm = nullptr;
     if (g_jacobi_sort) {
         hipLaunchKernelGGL(k_scaled_col_norms, dim3((n + 3) / 4), dim3(256), 0, st, M, ldm, colscale, rowscale, n, w.norms);
@@ -298,6 +298,7 @@ int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscal
     double res = 0.0;
     for (; sweeps < max_sweeps && !converged;) {
         (void)hipMemsetAsync(w.flag, 0, sizeof(unsigned long long), st);
+        if (hooks) hooks->begin(hooks->user);
         for (int r = 0; r < w.nrounds; ++r) {
             const int* pairs = w.rounds + (size_t)r * nwg * 2;
             if (w.nblk * 4 == n) {          // NCOL = 8
@@ -319,6 +320,7 @@ int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscal
                 }
             }
         }
+        if (hooks) hooks->end(hooks->user, w.nrounds);
         ++sweeps;
         if (hipMemcpyAsync(w.hflag, w.flag, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess) return DQMC_EHIP;
         if (hipStreamSynchronize(st) != hipSuccess) return DQMC_EHIP;
