@@ -280,7 +280,7 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     A_(alloc_slot(c, c->spare)); A_(alloc_slot(c, c->tmpudv));
     A_(dalloc(c, &c->T1, n2)); A_(dalloc(c, &c->T2, n2)); A_(dalloc(c, &c->T3, n2)); A_(dalloc(c, &c->T4, n2));
     A_(dalloc(c, &c->sw.A, n2)); A_(dalloc(c, &c->sw.V, n2));
-    A_(dalloc(c, &c->sw.norms, (size_t)ng)); A_(dalloc(c, &c->sw.rank, (size_t)ng)); A_(dalloc(c, &c->sw.flag, 1));
+    A_(dalloc(c, &c->sw.norms, (size_t)ng)); A_(dalloc(c, &c->sw.rnorms, (size_t)ng)); A_(dalloc(c, &c->sw.flagT, 1)); A_(dalloc(c, &c->sw.rank, (size_t)ng)); A_(dalloc(c, &c->sw.flag, 1));
     HIPCHK(hipHostMalloc((void**)&c->sw.hflag, sizeof(unsigned long long)));
     c->sw.last_residual = &c->last_svd_residual;
     {

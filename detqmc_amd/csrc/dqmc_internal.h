@@ -63,7 +63,7 @@ void launch_gemm(hipStream_t st, const GemmArgs& a);
 // one-sided Jacobi SVD, M = U diag(d) V^H, d descending.  work: A (n*n), V (n*n), norms(n), rank(n),
 // flag (int).  Host-driven sweep loop with one flag read-back per sweep.  Returns sweeps used or <0.
 struct SvdWork {
-    cplx* A; cplx* V; double* norms; int* rank;
+    cplx* A; cplx* V; double* norms; double* rnorms; int* rank; int* flagT;
     unsigned long long* flag; unsigned long long* hflag /*pinned host*/; double* last_residual;
     const int* rounds; int nrounds; int nblk;   // tournament table [nrounds][nblk/2][2]
 };

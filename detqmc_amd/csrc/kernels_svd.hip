@@ -28,6 +28,7 @@
 
 static const bool g_svd_debug = getenv("DQMC_DEBUG_SVD") != nullptr;
 static const int g_jacobi_npass = getenv("DQMC_JACOBI_NPASS") ? atoi(getenv("DQMC_JACOBI_NPASS")) : 1;
+static const int g_jacobi_transpose = getenv("DQMC_JACOBI_TRANSPOSE") ? atoi(getenv("DQMC_JACOBI_TRANSPOSE")) : -1;
 static const bool g_jacobi_sort = getenv("DQMC_JACOBI_SORT") ? atoi(getenv("DQMC_JACOBI_SORT")) != 0 : true;
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -196,21 +197,77 @@ __global__ __launch_bounds__(256) void k_jacobi_round(cplx* __restrict__ A, cplx
     if (body.maxres2 > 0.0 && tid == 0) atomicMax(flag, (unsigned long long)__double_as_longlong(body.maxres2));
 }
 
-// A[:, perm[j]] <- diag(rowscale) M[:, j] colscale_j,  V <- the same column permutation of the identity
-// (perm == nullptr: identity).  Starting from columns sorted by decreasing norm shortens the Jacobi
-// iteration on graded matrices (de Rijk).
+// Working matrix W = Ms (flagT == 0) or Ms^H (flagT == 1), Ms = diag(rowscale) M diag(colscale);
+// A[:, perm[j]] <- W[:, j], V <- the same column permutation of the identity (perm == nullptr: identity).
+// Starting from columns sorted by decreasing norm shortens the Jacobi iteration on graded matrices
+// (de Rijk); working on Ms^H when the ROWS of Ms are the strongly graded ones keeps the grading on the
+// columns, where one-sided Jacobi tolerates it (otherwise 50-70 sweeps instead of ~10).
 __global__ void k_svd_init(const cplx* __restrict__ M, int ldm, const double* colscale, const double* rowscale,
-                           const int* __restrict__ perm, cplx* __restrict__ A, cplx* __restrict__ V, int n) {
+                           const int* __restrict__ perm, const int* __restrict__ flagT,
+                           cplx* __restrict__ A, cplx* __restrict__ V, int n) {
+    const bool T = flagT && *flagT;
     size_t total = (size_t)n * n;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        int i = (int)(idx % n), j = (int)(idx / n);
-        cplx v = M[(size_t)j * ldm + i];
+        int i = (int)(idx % n), j = (int)(idx / n);      // element (i, j) of W
+        int mi = T ? j : i, mj = T ? i : j;              // element (mi, mj) of M
+        cplx v = M[(size_t)mj * ldm + mi];
         double sc = 1.0;
-        if (colscale) sc *= colscale[j];
-        if (rowscale) sc *= rowscale[i];
+        if (colscale) sc *= colscale[mj];
+        if (rowscale) sc *= rowscale[mi];
         int dst = perm ? perm[j] : j;
-        A[(size_t)dst * n + i] = make_double2(v.x * sc, v.y * sc);
+        A[(size_t)dst * n + i] = make_double2(v.x * sc, T ? -v.y * sc : v.y * sc);
         V[(size_t)dst * n + i] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+    }
+}
+
+// norms of the rows of diag(rowscale) M diag(colscale)
+__global__ __launch_bounds__(256) void k_scaled_row_norms(const cplx* __restrict__ M, int ldm, const double* colscale,
+                                                           const double* rowscale, int n, double* norms) {
+    __shared__ double part[4][64];
+    int row = blockIdx.x * 64 + (threadIdx.x & 63);
+    int q = threadIdx.x >> 6;
+    double s = 0.0;
+    if (row < n)
+        for (int j = q; j < n; j += 4) {
+            cplx a = M[(size_t)j * ldm + row];
+            double sc = colscale ? colscale[j] : 1.0;
+            s += (a.x * a.x + a.y * a.y) * sc * sc;
+        }
+    part[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && row < n) {
+        double t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        norms[row] = sqrt(t) * (rowscale ? fabs(rowscale[row]) : 1.0);
+    }
+}
+
+// flagT = 1 if the rows span more decades than the columns (mode: -1 auto, 0 never, 1 always)
+__global__ __launch_bounds__(256) void k_choose_orientation(const double* __restrict__ cn, const double* __restrict__ rn,
+                                                             int n, int mode, int* flagT) {
+    __shared__ double red[4][256];
+    double cmax = 0.0, cmin = 1e300, rmax = 0.0, rmin = 1e300;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double c = cn[i], r = rn[i];
+        cmax = fmax(cmax, c); rmax = fmax(rmax, r);
+        if (c > 0.0) cmin = fmin(cmin, c);
+        if (r > 0.0) rmin = fmin(rmin, r);
+    }
+    red[0][threadIdx.x] = cmax; red[1][threadIdx.x] = cmin; red[2][threadIdx.x] = rmax; red[3][threadIdx.x] = rmin;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) {
+            red[0][threadIdx.x] = fmax(red[0][threadIdx.x], red[0][threadIdx.x + s2]);
+            red[1][threadIdx.x] = fmin(red[1][threadIdx.x], red[1][threadIdx.x + s2]);
+            red[2][threadIdx.x] = fmax(red[2][threadIdx.x], red[2][threadIdx.x + s2]);
+            red[3][threadIdx.x] = fmin(red[3][threadIdx.x], red[3][threadIdx.x + s2]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int f = 0;
+        if (mode == 1) f = 1;
+        else if (mode < 0) f = (red[2][0] / red[3][0]) > (red[0][0] / red[1][0]);
+        *flagT = f;
     }
 }
 
@@ -241,10 +298,12 @@ __global__ __launch_bounds__(256) void k_col_norms(const cplx* __restrict__ A, i
     if (lane == 0) norms[col] = sqrt(s);
 }
 
-// rank by counting (descending, index as tie-break) and scatter d
-__global__ void k_rank(const double* __restrict__ norms, int n, int* rank, double* d) {
+// rank by counting (descending, index as tie-break) and scatter d; norms_T is used when *flagT != 0
+__global__ void k_rank(const double* __restrict__ norms_N, const double* __restrict__ norms_T,
+                       const int* __restrict__ flagT, int n, int* rank, double* d) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const double* norms = (flagT && *flagT) ? norms_T : norms_N;
     double si = norms[i];
     int rk = 0;
     for (int j = 0; j < n; ++j) {
@@ -258,7 +317,9 @@ __global__ void k_rank(const double* __restrict__ norms, int n, int* rank, doubl
 // U[:, rank[c]] = A[:, c] / sigma_c ; Vt[:, rank[c]] = V[:, c]
 __global__ __launch_bounds__(256) void k_svd_scatter(const cplx* __restrict__ A, const cplx* __restrict__ V,
                                                       const double* __restrict__ norms, const int* __restrict__ rank,
-                                                      int n, cplx* __restrict__ U, cplx* __restrict__ Vt) {
+                                                      int n, const int* __restrict__ flagT,
+                                                      cplx* __restrict__ U, cplx* __restrict__ Vt) {
+    if (flagT && *flagT) { cplx* t = U; U = Vt; Vt = t; }     // W = Ms^H: the roles of U and V swap
     int c = blockIdx.x;
     int dst = rank[c];
     double inv = 1.0 / norms[c];
@@ -281,13 +342,16 @@ static void launch_round(hipStream_t st, cplx* A, cplx* V, int n, const int* pai
 
 int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscale, const double* rowscale,
             cplx* U, double* d, cplx* Vt, const SvdWork& w, int max_sweeps, const SvdProfHooks* hooks) {
+    // orientation (Ms or Ms^H) and initial column order are chosen on the device: no host round trip
+    hipLaunchKernelGGL(k_scaled_col_norms, dim3((n + 3) / 4), dim3(256), 0, st, M, ldm, colscale, rowscale, n, w.norms);
+    hipLaunchKernelGGL(k_scaled_row_norms, dim3((n + 63) / 64), dim3(256), 0, st, M, ldm, colscale, rowscale, n, w.rnorms);
+    hipLaunchKernelGGL(k_choose_orientation, dim3(1), dim3(256), 0, st, w.norms, w.rnorms, n, g_jacobi_transpose, w.flagT);
     const int* perm = nullptr;
     if (g_jacobi_sort) {
-        hipLaunchKernelGGL(k_scaled_col_norms, dim3((n + 3) / 4), dim3(256), 0, st, M, ldm, colscale, rowscale, n, w.norms);
-        hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, st, w.norms, n, w.rank, d);
+        hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, st, w.norms, w.rnorms, w.flagT, n, w.rank, d);
         perm = w.rank;
     }
-    hipLaunchKernelGGL(k_svd_init, dim3(1024), dim3(256), 0, st, M, ldm, colscale, rowscale, perm, w.A, w.V, n);
+    hipLaunchKernelGGL(k_svd_init, dim3(1024), dim3(256), 0, st, M, ldm, colscale, rowscale, perm, w.flagT, w.A, w.V, n);
     // rotation threshold on |a_p^H a_q| / (|a_p| |a_q|): a few rounding errors of an n-term dot product
     const double tol = 4.0 * sqrt((double)n) * 2.220446049250313e-16;
     const double tol2 = tol * tol;
@@ -335,8 +399,8 @@ int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscal
     if (!converged && !(res <= 1e-12)) return DQMC_ENOCONV;
     if (w.last_residual) *w.last_residual = res;
     hipLaunchKernelGGL(k_col_norms, dim3((n + 3) / 4), dim3(256), 0, st, w.A, n, w.norms);
-    hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, st, w.norms, n, w.rank, d);
-    hipLaunchKernelGGL(k_svd_scatter, dim3(n), dim3(256), 0, st, w.A, w.V, w.norms, w.rank, n, U, Vt);
+    hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, st, w.norms, w.norms, nullptr, n, w.rank, d);
+    hipLaunchKernelGGL(k_svd_scatter, dim3(n), dim3(256), 0, st, w.A, w.V, w.norms, w.rank, n, w.flagT, U, Vt);
     return sweeps;
 }
 
