@@ -1,0 +1,77 @@
+"""Worker for tests/test_pt_gloo.py: one rank of a 2-rank replica-exchange run on CPU (gloo).
+The replica is a stand-in built on the CPU oracle (tests may use the oracle); the exchange logic under
+test is detqmc_amd/pt.py, exactly what the GPU ranks run with backend nccl."""
+import json
+import os
+import struct
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+class OracleReplica:
+    """Exchange surface of the reference's DetSDW (src/detsdwopdim.h:116-153) on top of the oracle."""
+
+    def __init__(self, rank, rvalue, seed=4242, simindex=0):
+        from detsdw_oracle import DetSDWOracle, SDWParams
+        from dsfmt_oracle import RngWrapper
+        rng = RngWrapper(seed, (simindex + 1) * (rank + 1))          # src/detqmcpt.h:301
+        self.o = DetSDWOracle(SDWParams(opdim=2, L=4, beta=1.0, s=5, delaySteps=6, r=rvalue), rng=rng)
+
+    def sweepThermalization(self):
+        self.o.sweepThermalization()
+
+    def get_exchange_parameter_value(self):
+        return self.o.pars.r
+
+    def set_exchange_parameter_value(self, v):
+        self.o.pars.r = v
+
+    def get_exchange_action_contribution(self):
+        return self.o.get_exchange_action_contribution()
+
+    def get_control_data(self):
+        return struct.pack("<iidd", self.o.acceptedGlobalShifts, self.o.attemptedGlobalShifts, self.o.phiDelta,
+                           self.o.lastAccRatioLocal_phi)
+
+    def set_control_data(self, blob):
+        a, b, pd, la = struct.unpack("<iidd", blob)
+        self.o.acceptedGlobalShifts, self.o.attemptedGlobalShifts, self.o.phiDelta = a, b, pd
+        self.o.lastAccRatioLocal_phi = la
+
+    def rand01(self):
+        return self.o.rng.rand01()
+
+
+def main():
+    import torch.distributed as dist
+    from detqmc_amd.pt import ExchangeState, replica_exchange_step, replica_exchange_consistency_check
+    out = sys.argv[1]
+    rvalues = json.loads(sys.argv[2])
+    steps = int(sys.argv[3])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rep = OracleReplica(rank, rvalues[rank])
+    rep.o.phiDelta = 0.5 + 0.1 * rank             # make the control data distinguishable
+    st = ExchangeState.create(rvalues, rank, world)
+    hist = []
+    for it in range(steps):
+        rep.sweepThermalization()
+        idx = replica_exchange_step(rep, st, dist)
+        replica_exchange_consistency_check(rep, st, dist)
+        hist.append(dict(index=idx, r=rep.get_exchange_parameter_value(), phiDelta=rep.o.phiDelta,
+                         action=rep.get_exchange_action_contribution()))
+    res = dict(rank=rank, hist=hist)
+    if rank == 0:
+        res["proposed"] = st.par_swapUpProposed
+        res["accepted"] = st.par_swapUpAccepted
+        res["process_par"] = st.current_process_par
+    json.dump(res, open(os.path.join(out, "rank%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the replica-exchange step: detqmc_amd/pt.py against a
+serial restatement of the reference's replicaExchangeStep (src/detqmcpt.h:963-1118)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _serial_expectation(rvalues, steps):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from pt_worker import OracleReplica
+    from detsdw_oracle import replica_exchange_probability
+    world = len(rvalues)
+    reps = [OracleReplica(p, rvalues[p]) for p in range(world)]
+    for p, r in enumerate(reps):
+        r.o.phiDelta = 0.5 + 0.1 * p
+    process_par = list(range(world))
+    par_process = list(range(world))
+    hist = [[] for _ in range(world)]
+    for it in range(steps):
+        for r in reps:
+            r.sweepThermalization()
+        actions = [r.get_exchange_action_contribution() for r in reps]
+        blobs = [r.get_control_data() for r in reps]
+        for c1 in range(world - 1):
+            c2 = c1 + 1
+            p1, p2 = par_process[c1], par_process[c2]
+            prob = replica_exchange_probability(rvalues[c1], actions[p1], rvalues[c2], actions[p2])
+            if prob >= 1 or reps[0].rand01() <= prob:
+                process_par[p1], process_par[p2] = c2, c1
+                par_process[c1], par_process[c2] = p2, p1
+                blobs[p1], blobs[p2] = blobs[p2], blobs[p1]
+        for p, r in enumerate(reps):
+            r.set_exchange_parameter_value(rvalues[process_par[p]])
+            r.set_control_data(blobs[p])
+            hist[p].append(dict(index=process_par[p], r=r.get_exchange_parameter_value(), phiDelta=r.o.phiDelta))
+    return hist
+
+
+@pytest.mark.parametrize("rvalues", [[-1.0, -0.9], [0.5, -2.5]])
+def test_replica_exchange_two_ranks_gloo(tmp_path, rvalues):
+    steps = 3
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 500)), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "pt_worker.py"), str(tmp_path),
+           json.dumps(rvalues), str(steps)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    got = [json.load(open(tmp_path / ("rank%d.json" % p))) for p in range(2)]
+    want = _serial_expectation(rvalues, steps)
+    swapped = False
+    for p in range(2):
+        for it in range(steps):
+            g, w = got[p]["hist"][it], want[p][it]
+            assert g["index"] == w["index"] and g["r"] == w["r"] and g["phiDelta"] == w["phiDelta"], (p, it, g, w)
+            swapped |= g["index"] != p
+        # every parameter value is held by exactly one rank after each step
+    for it in range(steps):
+        assert sorted(got[p]["hist"][it]["index"] for p in range(2)) == [0, 1]
+    assert got[0]["proposed"] == [steps, 0]
+    assert got[0]["accepted"][0] >= (1 if swapped else 0)
+    # control data travels with the PARAMETER, not with the rank (src/detqmcpt.h:1048-1050)
+    for p in range(2):
+        last = got[p]["hist"][-1]
+        assert abs(last["phiDelta"] - (0.5 + 0.1 * last["index"])) < 0.11
+
+
+def test_rank_count_must_match_parameter_count():
+    from detqmc_amd.pt import ExchangeState
+    with pytest.raises(ValueError):
+        ExchangeState.create([-1.0, -0.5, 0.0], rank=0, world=2)
