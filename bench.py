@@ -4,7 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One process per GPU (for N > 1 launched by torch.distributed.run).  A "step" is one
-sweepThermalization() of one replica: SDW O(2), L=16, beta=10, dtau=0.1 (m=100), s=10, checkerboard,
+sweepThermalization() of every replica the rank drives (--replicas R independent chains per GPU, each
+in its own worker process = own HIP runtime and hardware queues; value = all sweeps of all chains / time;
+`sweeps_per_s_per_chain` is the single-chain rate): SDW O(2), L=16, beta=10, dtau=0.1 (m=100), s=10, checkerboard,
 delayed updates (delaySteps=16), no fermion measurements.  Each rank runs an
 independent Markov chain (simindex = rank, as the reference's DetQMC does per process); there is no
 data-path collective, so the value is the sum over ranks and scaling is weak.  Rank 0 prints ONE
@@ -26,6 +28,7 @@ WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=16, r=-1.0,
                 mu=-0.5, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, bc="pbc", accRatio=0.5,
                 rngSeed=1020304050)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DEFAULT_REPLICAS = 4           # chains per GPU; a Jacobi round occupies 64 of the 256 CUs
 
 
 def cpu_baseline(max_seconds=200):
@@ -58,56 +61,108 @@ def cpu_baseline(max_seconds=200):
             "sample": "oracle/detsdw_oracle.py (numpy + scipy zgesvd): 1 sweepThermalization() after init, %.1f s" % dt}
 
 
+def worker(a):
+    """One chain in its own process (own HIP runtime / queues): build, warm up, wait for GO, run, report."""
+    from detqmc_amd import DetSDW, SDWParams
+    rep = DetSDW(SDWParams(device=a.device, simindex=a.simindex, **WORKLOAD))
+    ctx = rep.kernel_context
+    for _ in range(a.warmup):
+        rep.sweepThermalization()
+    if a.profile:
+        ctx.profile_enable(True)
+    ctx.synchronize()
+    print("READY", flush=True)
+    if sys.stdin.readline().strip() != "GO":
+        return
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rep.sweepThermalization()
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    info = rep.info
+    out = {"dt": dt, "n_g": info.n_g, "m": info.m, "acceptance": info.lastAccRatioLocal_phi}
+    if a.profile:
+        prof = ctx.profile_read()
+        out["prof"] = {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}
+    print("RESULT " + json.dumps(out), flush=True)
+    rep.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicas", type=int, default=int(os.environ.get("DQMC_REPLICAS_PER_GPU", str(DEFAULT_REPLICAS))),
+                    help="independent Markov chains per GPU, one worker process each")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--simindex", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--profile", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.worker:
+        return worker(a)
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    if world == 1 and a.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
     dist = None
+    torch = None
     if world > 1:
+        import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from detqmc_amd import DetSDW, SDWParams
-    rep = DetSDW(SDWParams(device=local, simindex=rank, **WORKLOAD))
-    ctx = rep.kernel_context
-
     def fence():
-        ctx.synchronize()
-        torch.cuda.synchronize()
         if dist is not None:
+            torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        rep.sweepThermalization()
-    ctx.profile_enable(True)
+    R = max(1, a.replicas)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
+              "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    procs = []
+    for i in range(R):
+        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--device", str(local), "--simindex",
+               str(rank * R + i), "--steps", str(a.steps), "--warmup", str(a.warmup)] + (["--profile"] if i == 0 else [])
+        procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env))
+
+    def read_tag(p, tag):
+        while True:
+            line = p.stdout.readline()
+            if not line:
+                raise SystemExit("bench worker died (exit code %s)" % p.poll())
+            if line.startswith(tag):
+                return line[len(tag):].strip()
+
+    for p in procs:
+        read_tag(p, "READY")            # replicas built, warm-up sweeps done, devices idle
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        rep.sweepThermalization()
+    for p in procs:
+        p.stdin.write("GO\n")
+        p.stdin.flush()
+    results = [json.loads(read_tag(p, "RESULT")) for p in procs]    # each worker synchronised its stream
     fence()
     dt = time.perf_counter() - t0
-    prof = ctx.profile_read()
+    for p in procs:
+        p.wait()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank == 0:
-        info = rep.info
-        n = info.n_g
+        r0 = results[0]
+        prof = {k: (tuple(v) if isinstance(v, list) else v) for k, v in r0["prof"].items()}
+        n = r0["n_g"]
         # dominant kernel: one Jacobi round = every column of A and of V read once and written once
         jac_ms, jac_launches = prof["jacobi"]
         bytes_per_launch = 4.0 * n * n * 16.0
@@ -123,33 +178,33 @@ def main():
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9 if jac_launches else 0.0
         res = {
             "metric": "DQMC sweeps/sec (SDW-O2 L=16 beta=10 fp64)",
-            "value": world * a.steps / dt,
+            "value": world * R * a.steps / dt,
             "unit": "sweeps/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps,
+            "sweeps_per_s_per_chain": a.steps / dt,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (random initial field, fixed seed)",
             "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(16) "
-                                   "sweepThermalization, one independent chain per GPU",
-                       "n_g": n, "m": info.m, "replicas_per_gpu": 1},
+                                   "sweepThermalization, %d independent chains per GPU (one process each)" % R,
+                       "n_g": n, "m": r0["m"], "replicas_per_gpu": R},
             "roofline": {"kernel": "k_jacobi_round<8,2>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us,
                          "launches": jac_launches},
-            "device_ms_by_family": fam,
-            "svd": {"calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
-                    "max_sweeps": prof["svd_sweeps_max"]},
-            "acceptance": info.lastAccRatioLocal_phi,
+            "device_ms_by_family_chain0": fam,
+            "svd_chain0": {"calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
+                           "max_sweeps": prof["svd_sweeps_max"]},
+            "acceptance": r0["acceptance"],
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    rep.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

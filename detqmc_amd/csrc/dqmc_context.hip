@@ -44,6 +44,8 @@ struct dqmc_ctx {
     int max_jacobi_sweeps = 80;
     int last_svd_sweeps = 0;
     double last_svd_residual = 0.0;
+    hipGraphExec_t jacobi_graph = nullptr;
+    unsigned long long jacobi_host_seq = 0;
     uint64_t svd_calls = 0, svd_sweeps_total = 0;
     int svd_sweeps_max = 0;
     // updates
@@ -281,8 +283,14 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     A_(dalloc(c, &c->T1, n2)); A_(dalloc(c, &c->T2, n2)); A_(dalloc(c, &c->T3, n2)); A_(dalloc(c, &c->T4, n2));
     A_(dalloc(c, &c->sw.A, n2)); A_(dalloc(c, &c->sw.V, n2));
     A_(dalloc(c, &c->sw.norms, (size_t)ng)); A_(dalloc(c, &c->sw.rnorms, (size_t)ng)); A_(dalloc(c, &c->sw.flagT, 1)); A_(dalloc(c, &c->sw.rank, (size_t)ng)); A_(dalloc(c, &c->sw.flag, 1));
-    HIPCHK(hipHostMalloc((void**)&c->sw.hflag, sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc((void**)&c->sw.hflag, 2 * sizeof(unsigned long long), hipHostMallocMapped));
+    c->sw.hflag[0] = 0; c->sw.hflag[1] = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&c->sw.hslot_dev, c->sw.hflag, 0));
+    A_(dalloc(c, &c->sw.seqctr, 1));
+    HIPCHK(hipMemset(c->sw.seqctr, 0, sizeof(unsigned long long)));
+    c->sw.host_seq = &c->jacobi_host_seq;
     c->sw.last_residual = &c->last_svd_residual;
+    c->sw.sweep_graph = &c->jacobi_graph;
     {
         int bw = svd_block_cols(ng);
         int nblk = ng / bw;
@@ -316,6 +324,7 @@ extern "C" void dqmc_destroy(dqmc_ctx* c) {
     (void)hipSetDevice(c->p.device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     for (void* q : c->allocs) (void)hipFree(q);
+    if (c->jacobi_graph) (void)hipGraphExecDestroy(c->jacobi_graph);
     if (c->sw.hflag) (void)hipHostFree(c->sw.hflag);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->st) (void)hipStreamDestroy(c->st);
@@ -324,6 +333,7 @@ extern "C" void dqmc_destroy(dqmc_ctx* c) {
 
 extern "C" int dqmc_synchronize(dqmc_ctx* c) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
     return DQMC_OK;
 }
@@ -334,6 +344,7 @@ extern "C" void* dqmc_stream(dqmc_ctx* c) { return c ? (void*)c->st : nullptr; }
 // ---------------------------------------------------------------------------------------------
 extern "C" int dqmc_set_fields_host(dqmc_ctx* c, const double* phi) {
     if (!c || !phi) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N;
     HIPCHK(hipMemcpyAsync(c->phi, phi, nphi * sizeof(double), hipMemcpyHostToDevice, c->st));
     { ProfScope ps(c, FAM_OTHER, 1); launch_cosh_sinh(c->st, c->hm); }
@@ -342,6 +353,7 @@ extern "C" int dqmc_set_fields_host(dqmc_ctx* c, const double* phi) {
 }
 extern "C" int dqmc_get_fields_host(dqmc_ctx* c, double* phi, double* coshT, double* sinhT) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
     HIPCHK(hipStreamSynchronize(c->st));
     if (phi) HIPCHK(hipMemcpy(phi, c->phi, nphi * sizeof(double), hipMemcpyDeviceToHost));
@@ -463,6 +475,7 @@ extern "C" int dqmc_udv_setup(dqmc_ctx* c) {
 
 extern "C" int dqmc_reset_storage0(dqmc_ctx* c) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     return set_slot_identity(c, c->storage[0]);
 }
 
@@ -519,6 +532,7 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
 // wrapUpGreen / wrapDownGreen (detmodel.h:1236-1259, 1066-1095)
 extern "C" int dqmc_wrap(dqmc_ctx* c, int dir, int k) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     if (c->currentTimeslice != k) return fail(DQMC_EINVAL, "wrap: currentTimeslice != k");
     if (dir == DQMC_UP) {
         if (k < 0 || k >= c->m) return fail(DQMC_EINVAL, "wrapUp: k out of range");
@@ -539,6 +553,7 @@ extern "C" int dqmc_wrap(dqmc_ctx* c, int dir, int k) {
 // ---------------------------------------------------------------------------------------------
 extern "C" int dqmc_push_uniforms_host(dqmc_ctx* c, const double* u, size_t nvals) {
     if (!c || (!u && nvals)) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     if (nvals > c->uni_cap) {
         double* nb;
         HIPCHK(hipStreamSynchronize(c->st));
@@ -556,6 +571,7 @@ extern "C" int dqmc_push_uniforms_host(dqmc_ctx* c, const double* u, size_t nval
 
 extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     if (k < 1 || k > c->m) return fail(DQMC_EINVAL, "updateInSlice: k out of range");
     if (c->currentTimeslice != k) return fail(DQMC_EINVAL, "updateInSlice: currentTimeslice != k");
     const int rounds = (c->N + c->D - 1) / c->D;
@@ -578,6 +594,7 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
 
 extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipMemcpy(out, &c->us->pub, sizeof(*out), hipMemcpyDeviceToHost));
     if (out->error) return fail(out->error, "device ran out of pre-drawn uniforms");
@@ -585,6 +602,7 @@ extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
 }
 extern "C" int dqmc_set_update_state_host(dqmc_ctx* c, const dqmc_update_state* in) {
     if (!c || !in) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipMemcpy(&c->us->pub, in, sizeof(*in), hipMemcpyHostToDevice));
     return DQMC_OK;
@@ -595,6 +613,7 @@ extern "C" int dqmc_set_update_state_host(dqmc_ctx* c, const dqmc_update_state* 
 // ---------------------------------------------------------------------------------------------
 extern "C" int dqmc_bmult_host(dqmc_ctx* c, int side, int inverse, int k2, int k1, dqmc_cplx* A) {
     if (!c || !A) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     if (!(k2 > k1) || k2 > c->m || k1 < 0) return fail(DQMC_EINVAL, "need 0 <= k1 < k2 <= m");
     const size_t n2 = (size_t)c->n_g * c->n_g;
     HIPCHK(hipMemcpyAsync(c->T1, A, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
@@ -608,6 +627,7 @@ extern "C" int dqmc_bmult_host(dqmc_ctx* c, int side, int inverse, int k2, int k
 extern "C" int dqmc_udv_decompose_host(dqmc_ctx* c, const dqmc_cplx* M, dqmc_cplx* U, double* d, dqmc_cplx* V_t,
                                        int* sweeps_used) {
     if (!c || !M || !U || !d || !V_t) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     const size_t n2 = (size_t)c->n_g * c->n_g;
     HIPCHK(hipMemcpyAsync(c->T1, M, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
     int rc = udv_dev(c, c->T1, nullptr, nullptr, c->tmpudv);
@@ -622,6 +642,7 @@ extern "C" int dqmc_udv_decompose_host(dqmc_ctx* c, const dqmc_cplx* M, dqmc_cpl
 
 extern "C" int dqmc_gemm_host(dqmc_ctx* c, int opA, int opB, const dqmc_cplx* A, const dqmc_cplx* B, dqmc_cplx* C) {
     if (!c || !A || !B || !C) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     const size_t n2 = (size_t)c->n_g * c->n_g;
     HIPCHK(hipMemcpyAsync(c->T1, A, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->T2, B, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
@@ -634,12 +655,14 @@ extern "C" int dqmc_gemm_host(dqmc_ctx* c, int opA, int opB, const dqmc_cplx* A,
 
 extern "C" int dqmc_get_green_host(dqmc_ctx* c, dqmc_cplx* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipMemcpy(out, c->G, (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 extern "C" int dqmc_set_green_host(dqmc_ctx* c, const dqmc_cplx* in, int currentTimeslice) {
     if (!c || !in) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipMemcpy(c->G, in, (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyHostToDevice));
     c->currentTimeslice = currentTimeslice;
@@ -647,12 +670,14 @@ extern "C" int dqmc_set_green_host(dqmc_ctx* c, const dqmc_cplx* in, int current
 }
 extern "C" int dqmc_get_sv_host(dqmc_ctx* c, double* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipMemcpy(out, c->sv, c->n_g * sizeof(double), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 extern "C" int dqmc_get_udv_host(dqmc_ctx* c, int l, dqmc_cplx* U, double* d, dqmc_cplx* V_t) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     if (l < 0 || l > c->n) return fail(DQMC_EINVAL, "l out of range");
     const size_t n2 = (size_t)c->n_g * c->n_g;
     HIPCHK(hipStreamSynchronize(c->st));
@@ -672,6 +697,7 @@ static void swap_state(dqmc_ctx* c) {
 }
 extern "C" int dqmc_backup(dqmc_ctx* c) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
     HIPCHK(hipMemcpyAsync(c->phi_bak, c->phi, nphi * sizeof(double), hipMemcpyDeviceToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->cosh_bak, c->coshT, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
@@ -681,6 +707,7 @@ extern "C" int dqmc_backup(dqmc_ctx* c) {
 }
 extern "C" int dqmc_restore(dqmc_ctx* c) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
     HIPCHK(hipMemcpyAsync(c->phi, c->phi_bak, nphi * sizeof(double), hipMemcpyDeviceToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->coshT, c->cosh_bak, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
@@ -692,6 +719,7 @@ extern "C" int dqmc_restore(dqmc_ctx* c) {
 
 extern "C" int dqmc_exchange_action_host(dqmc_ctx* c, double* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
     { ProfScope ps(c, FAM_OTHER, 1); launch_phi_sq_sum(c->st, c->hm, c->scalar_out); }
     HIPCHK(hipStreamSynchronize(c->st));
     double v;
@@ -722,6 +750,7 @@ static void prof_collect(dqmc_ctx* c) {
 }
 extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     prof_collect(c);
     c->prof = on != 0;
     for (int i = 0; i < FAM_COUNT; ++i) { c->fam_ms[i] = 0; c->fam_launches[i] = 0; }
@@ -730,6 +759,7 @@ extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
 }
 extern "C" int dqmc_profile_read(dqmc_ctx* c, double ms[8], uint64_t launches[8]) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
     prof_collect(c);
     for (int i = 0; i < FAM_COUNT; ++i) { if (ms) ms[i] = c->fam_ms[i]; if (launches) launches[i] = c->fam_launches[i]; }
     if (launches) { launches[5] = c->svd_calls; launches[6] = c->svd_sweeps_total; launches[7] = (uint64_t)c->svd_sweeps_max; }

@@ -64,8 +64,13 @@ void launch_gemm(hipStream_t st, const GemmArgs& a);
 // flag (int).  Host-driven sweep loop with one flag read-back per sweep.  Returns sweeps used or <0.
 struct SvdWork {
     cplx* A; cplx* V; double* norms; double* rnorms; int* rank; int* flagT;
-    unsigned long long* flag; unsigned long long* hflag /*pinned host*/; double* last_residual;
+    unsigned long long* flag; double* last_residual;
+    unsigned long long* hflag;       // mapped pinned host memory: [0] sequence number, [1] residual bits
+    unsigned long long* hslot_dev;   // device alias of hflag
+    unsigned long long* seqctr;      // device-side publish counter
+    unsigned long long* host_seq;    // host-side expectation
     const int* rounds; int nrounds; int nblk;   // tournament table [nrounds][nblk/2][2]
+    hipGraphExec_t* sweep_graph;                // lazily captured: memset + all rounds of one Jacobi sweep
 };
 // optional timing hooks around each batch of back-to-back round launches (one Jacobi sweep)
 struct SvdProfHooks { void (*begin)(void* user); void (*end)(void* user, int launches); void* user; };

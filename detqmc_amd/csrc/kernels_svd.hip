@@ -28,6 +28,7 @@
 
 static const bool g_svd_debug = getenv("DQMC_DEBUG_SVD") != nullptr;
 static const int g_jacobi_npass = getenv("DQMC_JACOBI_NPASS") ? atoi(getenv("DQMC_JACOBI_NPASS")) : 1;
+static const bool g_jacobi_graph = getenv("DQMC_JACOBI_GRAPH") ? atoi(getenv("DQMC_JACOBI_GRAPH")) != 0 : true;
 static const int g_jacobi_transpose = getenv("DQMC_JACOBI_TRANSPOSE") ? atoi(getenv("DQMC_JACOBI_TRANSPOSE")) : -1;
 static const bool g_jacobi_sort = getenv("DQMC_JACOBI_SORT") ? atoi(getenv("DQMC_JACOBI_SORT")) != 0 : true;
 
@@ -57,34 +58,73 @@ struct JacobiSteps<NCOL, RPT, NCOL - 1> {
     template<class F> __device__ static __forceinline__ void run(F&&) {}
 };
 
+// ---- wavefront sum of a double with DPP row operations (no LDS traffic): total ends up in lane 63 ----
+template<int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+    int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double readlane_d(double x, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v = dpp_add<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    v = dpp_add<0x114, 0xf>(v);    // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);    // row_shr:8   -> lanes 12..15 of each row hold the row sum
+    v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return readlane_d(v, 63);
+}
+// 1/sqrt(y) to full double precision: hardware estimate + two Newton steps
+__device__ __forceinline__ double rsqrt_full(double y) {
+    double x = __builtin_amdgcn_rsq(y);
+    x = x * (1.5 - 0.5 * y * x * x);
+    x = x * (1.5 - 0.5 * y * x * x);
+    return x;
+}
+
 template<int NCOL, int RPT>
 struct JacobiBody {
+    static constexpr int NP = NCOL / 2;       // simultaneous rotations per step
     cplx a[RPT][NCOL];
     cplx v[RPT][NCOL];
-    double (*red)[4][2 * NCOL];   // [parity][wave][NCOL norms + NCOL/2 complex gammas]
+    double nrm2[NCOL];                        // squared column norms, tracked through the rotations
+    double (*red)[4][NCOL];                   // [parity][wave][value] cross-wave scratch
     int lane, wave;
     double tol2;
     double maxres2;      // largest |gamma|^2 / (alpha beta) seen by this workgroup
 
+    // column norms from the data (once per visit)
+    __device__ __forceinline__ void init_norms() {
+        double part[NCOL];
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) s += a[r][c].x * a[r][c].x + a[r][c].y * a[r][c].y;
+            part[c] = wave_total(s);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) red[1][wave][c] = part[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) nrm2[c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+
     template<int P, int Q>
-    __device__ __forceinline__ void rotate(double alpha, double beta, double gre, double gim) {
-        double g2 = gre * gre + gim * gim;
-        if (alpha == 0.0 || beta == 0.0) return;
-        double rel2 = g2 / (alpha * beta);
-        if (!(rel2 > tol2)) return;
-        maxres2 = fmax(maxres2, rel2);
-        double absg = sqrt(g2);
-        double phr = gre / absg, phi = gim / absg;          // e^{i theta}
-        double zeta = (beta - alpha) / (2.0 * absg);
-        double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        double cs = 1.0 / sqrt(1.0 + t * t);
-        double sn = cs * t;
+    __device__ __forceinline__ void apply_rotation(double cs, double sn, double phr, double phi) {
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             {
                 cplx ap = a[r][P], aq = a[r][Q];
-                // aq~ = conj(e^{i theta}) aq
-                double qr = phr * aq.x + phi * aq.y, qi = phr * aq.y - phi * aq.x;
+                double qr = phr * aq.x + phi * aq.y, qi = phr * aq.y - phi * aq.x;   // conj(e^{i theta}) aq
                 a[r][P] = make_double2(cs * ap.x - sn * qr, cs * ap.y - sn * qi);
                 a[r][Q] = make_double2(sn * ap.x + cs * qr, sn * ap.y + cs * qi);
             }
@@ -98,7 +138,7 @@ struct JacobiBody {
     }
 
     template<int STEP, int I>
-    __device__ __forceinline__ void partial_gamma(double (&part)[2 * NCOL]) {
+    __device__ __forceinline__ void partial_gamma(double (&part)[NCOL]) {
         constexpr int P = rr_first(NCOL, STEP, I), Q = rr_second(NCOL, STEP, I);
         double gr = 0.0, gi = 0.0;
 #pragma unroll
@@ -106,45 +146,65 @@ struct JacobiBody {
             gr += a[r][P].x * a[r][Q].x + a[r][P].y * a[r][Q].y;
             gi += a[r][P].x * a[r][Q].y - a[r][P].y * a[r][Q].x;
         }
-        part[NCOL + 2 * I] = gr;
-        part[NCOL + 2 * I + 1] = gi;
+        part[2 * I] = wave_total(gr);
+        part[2 * I + 1] = wave_total(gi);
     }
+
     template<int STEP, int I>
-    __device__ __forceinline__ void apply_pair(const double (&tot)[2 * NCOL]) {
+    __device__ __forceinline__ void finish_pair(int rot, double cs, double sn, double phr, double phi, double tg, double rel2) {
         constexpr int P = rr_first(NCOL, STEP, I), Q = rr_second(NCOL, STEP, I);
-        rotate<P, Q>(tot[P], tot[Q], tot[NCOL + 2 * I], tot[NCOL + 2 * I + 1]);
+        // lane I computed the parameters of pair I; hand them to every lane as wave-uniform values
+        if (__builtin_amdgcn_readlane(rot, I)) {
+            apply_rotation<P, Q>(readlane_d(cs, I), readlane_d(sn, I), readlane_d(phr, I), readlane_d(phi, I));
+            double d = readlane_d(tg, I);
+            nrm2[P] -= d;                      // |a_p'|^2 = alpha - t |gamma|,  |a_q'|^2 = beta + t |gamma|
+            nrm2[Q] += d;
+            maxres2 = fmax(maxres2, readlane_d(rel2, I));
+        }
     }
 
     template<int STEP>
     __device__ __forceinline__ void step() {
-        double part[2 * NCOL];
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c) {
-            double s = 0.0;
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) s += a[r][c].x * a[r][c].x + a[r][c].y * a[r][c].y;
-            part[c] = s;
-        }
-        if constexpr (NCOL >= 2) partial_gamma<STEP, 0>(part);
-        if constexpr (NCOL >= 4) partial_gamma<STEP, 1>(part);
-        if constexpr (NCOL >= 6) partial_gamma<STEP, 2>(part);
-        if constexpr (NCOL >= 8) partial_gamma<STEP, 3>(part);
-#pragma unroll
-        for (int c = 0; c < 2 * NCOL; ++c) part[c] = wave_sum(part[c]);
+        double part[NCOL];
+        if constexpr (NP >= 1) partial_gamma<STEP, 0>(part);
+        if constexpr (NP >= 2) partial_gamma<STEP, 1>(part);
+        if constexpr (NP >= 3) partial_gamma<STEP, 2>(part);
+        if constexpr (NP >= 4) partial_gamma<STEP, 3>(part);
         const int par = STEP & 1;
         if (lane == 0) {
 #pragma unroll
-            for (int c = 0; c < 2 * NCOL; ++c) red[par][wave][c] = part[c];
+            for (int c = 0; c < NCOL; ++c) red[par][wave][c] = part[c];
         }
         __syncthreads();
-        double tot[2 * NCOL];
+        // lane l works out the rotation of pair l % NP (all lanes busy on the same instruction stream, so
+        // four pairs cost what one costs)
+        const int me = lane % NP;
+        double alpha = 0.0, beta = 0.0, gre = 0.0, gim = 0.0;
 #pragma unroll
-        for (int c = 0; c < 2 * NCOL; ++c)
-            tot[c] = (red[par][0][c] + red[par][1][c]) + (red[par][2][c] + red[par][3][c]);
-        if constexpr (NCOL >= 2) apply_pair<STEP, 0>(tot);
-        if constexpr (NCOL >= 4) apply_pair<STEP, 1>(tot);
-        if constexpr (NCOL >= 6) apply_pair<STEP, 2>(tot);
-        if constexpr (NCOL >= 8) apply_pair<STEP, 3>(tot);
+        for (int i = 0; i < NP; ++i) {
+            const int P = rr_first(NCOL, STEP, i), Q = rr_second(NCOL, STEP, i);
+            double g_re = (red[par][0][2 * i] + red[par][1][2 * i]) + (red[par][2][2 * i] + red[par][3][2 * i]);
+            double g_im = (red[par][0][2 * i + 1] + red[par][1][2 * i + 1]) + (red[par][2][2 * i + 1] + red[par][3][2 * i + 1]);
+            if (me == i) { alpha = nrm2[P]; beta = nrm2[Q]; gre = g_re; gim = g_im; }
+        }
+        double g2 = gre * gre + gim * gim;
+        double ab = alpha * beta;
+        int rot = (ab > 0.0) && (g2 > tol2 * ab);
+        double ig = rsqrt_full(rot ? g2 : 1.0);             // 1 / |gamma|
+        double absg = g2 * ig;
+        double phr = gre * ig, phi = gim * ig;              // e^{i theta}
+        double da = beta - alpha, db = 2.0 * absg;
+        // t = sign(da) db / (|da| + sqrt(da^2 + db^2))  (smaller root: keeps the larger column larger)
+        double hyp = sqrt(da * da + db * db);
+        double t = (da >= 0.0 ? db : -db) / (fabs(da) + hyp);
+        double cs = rsqrt_full(1.0 + t * t);
+        double sn = cs * t;
+        double tg = t * absg;
+        double rel2 = g2 * __builtin_amdgcn_rcp(rot ? ab : 1.0);
+        if constexpr (NP >= 1) finish_pair<STEP, 0>(rot, cs, sn, phr, phi, tg, rel2);
+        if constexpr (NP >= 2) finish_pair<STEP, 1>(rot, cs, sn, phr, phi, tg, rel2);
+        if constexpr (NP >= 3) finish_pair<STEP, 2>(rot, cs, sn, phr, phi, tg, rel2);
+        if constexpr (NP >= 4) finish_pair<STEP, 3>(rot, cs, sn, phr, phi, tg, rel2);
     }
 };
 
@@ -152,7 +212,7 @@ template<int NCOL, int RPT>
 __global__ __launch_bounds__(256) void k_jacobi_round(cplx* __restrict__ A, cplx* __restrict__ V, int n,
                                                        const int* __restrict__ pairs, unsigned long long* flag, double tol2, int npass) {
     constexpr int BW = NCOL / 2;
-    __shared__ double red[2][4][2 * NCOL];
+    __shared__ double red[2][4][NCOL];
     const int tid = threadIdx.x;
     const int bA = pairs[2 * blockIdx.x], bB = pairs[2 * blockIdx.x + 1];
     JacobiBody<NCOL, RPT> body;
@@ -178,6 +238,7 @@ __global__ __launch_bounds__(256) void k_jacobi_round(cplx* __restrict__ A, cplx
             }
         }
     }
+    body.init_norms();
     for (int ps = 0; ps < npass; ++ps) {
         JacobiSteps<NCOL, RPT, 0>::run(body);
         __syncthreads();     // the LDS parity slots of the next pass must not overtake slow readers
@@ -335,6 +396,18 @@ int svd_block_cols(int n) {
     return (n <= 1024) ? 4 : 2;
 }
 
+// last node of a Jacobi sweep: hand the residual to the host through mapped pinned memory so the host
+// can spin on it without entering the HIP runtime (hipStreamSynchronize from several host threads
+// serialises on runtime locks: 4 chains per process ran at 2.3x instead of 4x)
+__global__ void k_publish_residual(const unsigned long long* __restrict__ flag, unsigned long long* seqctr,
+                                   volatile unsigned long long* host_slot) {
+    unsigned long long seq = *seqctr + 1ULL;
+    *seqctr = seq;
+    host_slot[1] = *flag;
+    __threadfence_system();
+    host_slot[0] = seq;
+}
+
 template<int NCOL, int RPT>
 static void launch_round(hipStream_t st, cplx* A, cplx* V, int n, const int* pairs, int nwg, unsigned long long* flag, double tol2) {
     hipLaunchKernelGGL((k_jacobi_round<NCOL, RPT>), dim3(nwg), dim3(256), 0, st, A, V, n, pairs, flag, tol2, g_jacobi_npass);
@@ -360,9 +433,8 @@ int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscal
     int sweeps = 0;
     bool converged = false;
     double res = 0.0;
-    for (; sweeps < max_sweeps && !converged;) {
+    auto enqueue_sweep = [&]() -> int {
         (void)hipMemsetAsync(w.flag, 0, sizeof(unsigned long long), st);
-        if (hooks) hooks->begin(hooks->user);
         for (int r = 0; r < w.nrounds; ++r) {
             const int* pairs = w.rounds + (size_t)r * nwg * 2;
             if (w.nblk * 4 == n) {          // NCOL = 8
@@ -384,14 +456,55 @@ int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscal
                 }
             }
         }
+        hipLaunchKernelGGL(k_publish_residual, dim3(1), dim3(1), 0, st, w.flag, w.seqctr, w.hslot_dev);
+        return 0;
+    };
+    // A Jacobi sweep is always the same n_blk - 1 launches with the same arguments: capture it once per
+    // context into a hipGraph and replay it, so the host issues one call per sweep instead of ~128.
+    if (g_jacobi_graph && w.sweep_graph && !*w.sweep_graph) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = enqueue_sweep();
+            hipError_t e = hipStreamEndCapture(st, &graph);
+            if (rc == 0 && e == hipSuccess && graph) {
+                hipGraphExec_t exec = nullptr;
+                if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) *w.sweep_graph = exec;
+                if (g_svd_debug) fprintf(stderr, "[svd] sweep graph %s\n", *w.sweep_graph ? "instantiated" : "FAILED");
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        (void)hipGetLastError();
+    }
+    for (; sweeps < max_sweeps && !converged;) {
+        if (hooks) hooks->begin(hooks->user);
+        if (g_jacobi_graph && w.sweep_graph && *w.sweep_graph) {
+            if (hipGraphLaunch(*w.sweep_graph, st) != hipSuccess) return DQMC_EHIP;
+        } else {
+            int rc = enqueue_sweep();
+            if (rc) return rc;
+        }
         if (hooks) hooks->end(hooks->user, w.nrounds);
         ++sweeps;
-        if (hipMemcpyAsync(w.hflag, w.flag, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess) return DQMC_EHIP;
-        if (hipStreamSynchronize(st) != hipSuccess) return DQMC_EHIP;
+        // wait for this sweep's publish node: spin on host-visible memory, no runtime call
+        const unsigned long long want = ++(*w.host_seq);
+        {
+            volatile unsigned long long* slot = w.hflag;
+            unsigned long spins = 0;
+            while (slot[0] != want) {
+                if ((++spins & 0xFFFFF) == 0 && hipStreamQuery(st) != hipErrorNotReady && slot[0] != want) {
+                    // stream drained (or failed) without publishing: do not spin forever
+                    if (slot[0] != want) return DQMC_EHIP;
+                }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+        }
+        unsigned long long bits = ((volatile unsigned long long*)w.hflag)[1];
         double r2;
-        memcpy(&r2, w.hflag, sizeof(double));
+        memcpy(&r2, &bits, sizeof(double));
         res = sqrt(r2);
-        converged = (*w.hflag == 0ULL);
+        converged = (bits == 0ULL);
         if (g_svd_debug) fprintf(stderr, "[svd n=%d] sweep %d residual %.3e\n", n, sweeps, res);
     }
     // a sweep that still rotated but only at the 1e-12 level is orthogonal far beyond what the
