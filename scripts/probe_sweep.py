@@ -1,6 +1,6 @@
 """Developer probe: per-family device time and Jacobi statistics of a few sweeps."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from detqmc_amd import DetSDW, SDWParams
 
