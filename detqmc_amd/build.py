@@ -19,6 +19,7 @@ SOURCES = [
     "kernels_gemm.hip",
     "kernels_svd.hip",
     "kernels_update.hip",
+    "kernels_qr.hip",
     "dqmc_context.hip",
     os.path.join("host", "dsfmt19937.cpp"),
     os.path.join("host", "detsdw.cpp"),

@@ -41,6 +41,12 @@ struct dqmc_ctx {
     UdVSlot spare{}, tmpudv{};
     cplx *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *T4 = nullptr;
     SvdWork sw{};
+    int stab = 0;                       // DQMC_STAB_SVD / DQMC_STAB_QR
+    QrWork qw{};
+    int* qr_perm = nullptr;
+    double *rmax_inv = nullptr, *rmin = nullptr, *lmax_inv = nullptr, *lmin = nullptr;
+    UdVSlot eye{};
+    uint64_t qr_calls = 0;
     int max_jacobi_sweeps = 80;
     int last_svd_sweeps = 0;
     double last_svd_residual = 0.0;
@@ -92,6 +98,7 @@ struct ProfScope {
 };
 
 extern "C" const char* dqmc_last_error(void) { return g_err.c_str(); }
+static int set_slot_identity(dqmc_ctx* c, UdVSlot& sl);
 
 // ---------------------------------------------------------------------------------------------
 // model set-up on the host: plaquette tables (detsdwopdim.cpp:217-260, :1598-1684, :1788-1826)
@@ -229,6 +236,7 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     if (p->delaySteps < 1 || p->delaySteps > N) return fail(DQMC_EINVAL, "delaySteps must be in 1..N");
     if (MSF * p->delaySteps > DQMC_MAX_WDIM) return fail(DQMC_EINVAL, "MSF*delaySteps must be <= 64 on this build");
     if (p->bc < 0 || p->bc > 3) return fail(DQMC_EINVAL, "bc");
+    if (p->stabilisation != DQMC_STAB_SVD && p->stabilisation != DQMC_STAB_QR) return fail(DQMC_EINVAL, "stabilisation");
     if (!(p->dtau > 0)) return fail(DQMC_EINVAL, "dtau");
     const int ng = MSF * N;
     if (ng > 2304) return fail(DQMC_EINVAL, "n_g > 2304 not supported by the Jacobi kernel instantiations");
@@ -301,6 +309,18 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
         HIPCHK(hipMemcpy(d_rounds, rounds.data(), rounds.size() * sizeof(int), hipMemcpyHostToDevice));
         c->sw.rounds = d_rounds; c->sw.nrounds = nblk - 1; c->sw.nblk = nblk;
     }
+    c->stab = p->stabilisation;
+    if (c->stab == DQMC_STAB_QR) {
+        if (ng > 1024) { dqmc_destroy(c); return fail(DQMC_EINVAL, "QR stabilisation supports n_g <= 1024 on this build"); }
+        const int np = (ng + 15) / 16;
+        A_(dalloc(c, &c->qw.V, n2)); A_(dalloc(c, &c->qw.T, (size_t)np * 2 * 256));
+        A_(dalloc(c, &c->qw.W, (size_t)16 * ng)); A_(dalloc(c, &c->qw.W2, (size_t)16 * ng)); A_(dalloc(c, &c->qw.Rneg, (size_t)16 * ng));
+        A_(dalloc(c, &c->qr_perm, (size_t)ng));
+        A_(dalloc(c, &c->rmax_inv, (size_t)ng)); A_(dalloc(c, &c->rmin, (size_t)ng));
+        A_(dalloc(c, &c->lmax_inv, (size_t)ng)); A_(dalloc(c, &c->lmin, (size_t)ng));
+        HIPCHK(hipMemset(c->qw.V, 0, n2 * sizeof(cplx)));
+    }
+    A_(alloc_slot(c, c->eye));
     const int WD = MSF * c->D;
     A_(dalloc(c, &c->X, (size_t)ng * WD)); A_(dalloc(c, &c->Gr, (size_t)WD * ng)); A_(dalloc(c, &c->W, (size_t)WD * WD));
     c->uni_cap = (size_t)(p->opdim + 1) * N * p->m + 64;     // one sweep's worst case
@@ -314,6 +334,7 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     hus.pub.targetAccRatio = p->accRatio;
     hus.slice_done = 1;
     HIPCHK(hipMemcpy(c->us, &hus, sizeof(hus), hipMemcpyHostToDevice));
+    { int rc2 = set_slot_identity(c, c->eye); if (rc2) { dqmc_destroy(c); return rc2; } }
     HIPCHK(hipDeviceSynchronize());
     *out = c;
     return DQMC_OK;
@@ -415,8 +436,73 @@ static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
     return DQMC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// QR ("UDT") stabilisation mode.  Chain factors keep the reference's convention M = U diag(d) V_t^H:
+//   R-type (chains built upwards, B(tau,0)):   Ms P = Q R   ->  U = Q (unitary), V_t = (D^-1 R P^T)^H
+//   L-type (chains built downwards, B(beta,tau), row graded): the same on Ms^H with the roles swapped
+//           ->  V_t = Q (unitary), U = (D^-1 R P^T)^H
+// so in  G = [1 + U_r d_r V_r^H U_l d_l V_l^H]^-1 = V_l [U_r^H V_l + d_r (V_r^H U_l) d_l]^-1 U_r^H
+// exactly the two factors that must be unitary (U_r, V_l) are (cf. detmodel.h:762-767).
+// ---------------------------------------------------------------------------------------------
+enum { KIND_R = 0, KIND_L = 1 };
+
+static int udt_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, int kind, UdVSlot out) {
+    const int n = c->n_g;
+    const int transpose = (kind == KIND_L);
+    ProfScope ps(c, FAM_JACOBI, 0);
+    launch_scaled_norms_rank(c->st, M, n, colscale, rowscale, transpose, n, c->sw.norms, c->qr_perm, c->sw.rnorms);
+    launch_udt_init(c->st, M, n, colscale, rowscale, c->qr_perm, transpose, c->sw.A, n);
+    cplx* Q = transpose ? out.Vt : out.U;
+    cplx* Tt = transpose ? out.U : out.Vt;
+    int launches = run_qr(c->st, n, c->sw.A, Q, c->qw);
+    launch_udt_diag(c->st, c->sw.A, n, out.d);
+    launch_udt_tmat(c->st, c->sw.A, out.d, c->qr_perm, n, Tt);
+    c->fam_launches[FAM_JACOBI] += launches + 5;
+    c->qr_calls += 1;
+    return DQMC_OK;
+}
+
+// G from an L-type and an R-type factorisation (nullptr = identity), with the scales split into their
+// parts > 1 and <= 1 so that the matrix that is actually inverted,
+//   Z = Drmax^-1 (U_r^H V_l) Dlmax^-1 + Drmin (V_r^H U_l) Dlmin,
+// has entries O(1):  G = (V_l Dlmax^-1) Z^-1 (U_r Drmax^-1)^H,  Z P = Q R  =>  Z^-1 = P R^-1 Q^H.
+static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
+    const int n = c->n_g;
+    const UdVSlot& L = Lp ? *Lp : c->eye;
+    const UdVSlot& R = Rp ? *Rp : c->eye;
+    {
+        ProfScope ps(c, FAM_OTHER, 2);
+        launch_split_scales(c->st, R.d, n, c->rmax_inv, c->rmin);
+        launch_split_scales(c->st, L.d, n, c->lmax_inv, c->lmin);
+    }
+    gemm_dev(c, 1, 0, R.U, L.Vt, c->T2, nullptr, 0, c->rmax_inv, c->lmax_inv, 0);
+    gemm_dev(c, 1, 0, R.Vt, L.U, c->T2, nullptr, 0, c->rmin, c->lmin, 1);
+    {
+        ProfScope ps(c, FAM_JACOBI, 0);
+        launch_scaled_norms_rank(c->st, c->T2, n, nullptr, nullptr, 0, n, c->sw.norms, c->qr_perm, c->sw.rnorms);
+        launch_udt_init(c->st, c->T2, n, nullptr, nullptr, c->qr_perm, 0, c->sw.A, n);
+        int launches = run_qr(c->st, n, c->sw.A, c->T1, c->qw);          // sw.A = R factor, T1 = Q
+        launch_permute_scale_cols(c->st, L.Vt, c->lmax_inv, c->qr_perm, n, c->T3);
+        launches += run_trsm_right_upper(c->st, n, c->sw.A, c->T3, c->qw);   // T3 = (V_l Dlmax^-1 P) R^-1
+        launch_logdet_vector(c->st, c->sw.A, c->rmax_inv, c->lmax_inv, n, c->sv);
+        c->fam_launches[FAM_JACOBI] += launches + 5;
+        c->qr_calls += 1;
+    }
+    gemm_dev(c, 0, 0, R.U, c->T1, c->T4, c->rmax_inv, 0);                  // T4 = U_r Drmax^-1 Q
+    gemm_dev(c, 0, 1, c->T3, c->T4, c->G);                                 // G = T3 T4^H
+    return DQMC_OK;
+}
+
+// mode dispatch --------------------------------------------------------------------------------
+static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, UdVSlot out);
+static int decompose(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, int kind, UdVSlot out) {
+    if (c->stab == DQMC_STAB_QR) return udt_dev(c, M, colscale, rowscale, kind, out);
+    return udv_dev(c, M, colscale, rowscale, out);
+}
+
 // greenFromUdV (detmodel.h:769-818)
 static int green_from_udv(dqmc_ctx* c, const UdVSlot& L, const UdVSlot& R) {
+    if (c->stab == DQMC_STAB_QR) return green_qr(c, &L, &R);
     gemm_dev(c, 1, 0, R.U, L.Vt, c->T2);                                  // UtVt_rl = U_r^H V_t_l
     gemm_dev(c, 1, 0, R.Vt, L.U, c->T2, nullptr, 0, R.d, L.d, 1);         // += diag(d_r) (V_t_r^H U_l) diag(d_l)
     UdVSlot t = c->tmpudv; t.d = c->sv;
@@ -427,8 +513,9 @@ static int green_from_udv(dqmc_ctx* c, const UdVSlot& L, const UdVSlot& R) {
     gemm_dev(c, 0, 1, c->T3, c->T4, c->G, c->sv, 1);                      // G = Vt_product diag(1/sv) U_product^H
     return DQMC_OK;
 }
-// greenFromEye_and_UdV (detmodel.h:823-860)
-static int green_from_eye(dqmc_ctx* c, const UdVSlot& R) {
+// greenFromEye_and_UdV (detmodel.h:823-860); kind tells whether the factorisation is R-type or L-type
+static int green_from_eye(dqmc_ctx* c, const UdVSlot& R, int kind) {
+    if (c->stab == DQMC_STAB_QR) return (kind == KIND_R) ? green_qr(c, nullptr, &R) : green_qr(c, &R, nullptr);
     gemm_dev(c, 1, 0, R.U, R.Vt, c->T2);
     { ProfScope ps(c, FAM_OTHER, 1); launch_add_diag(c->st, c->T2, R.d, c->n_g); }
     UdVSlot t = c->tmpudv; t.d = c->sv;
@@ -459,16 +546,16 @@ extern "C" int dqmc_udv_setup(dqmc_ctx* c) {
     if ((rc = set_slot_identity(c, c->storage[0]))) return rc;
     { ProfScope ps(c, FAM_OTHER, 1); launch_set_identity(c->st, c->T1, ng); }
     bmult_dev(c, DQMC_LEFT, 0, s, 0, c->T1);
-    if ((rc = udv_dev(c, c->T1, nullptr, nullptr, c->storage[1]))) return rc;
+    if ((rc = decompose(c, c->T1, nullptr, nullptr, KIND_R, c->storage[1]))) return rc;
     for (int l = 1; l <= n - 1; ++l) {
         const int k_l = s * l, k_lp1 = (l < n - 1) ? s * (l + 1) : m;
         launch_copy(c->st, c->storage[l].U, c->T1, (size_t)ng * ng);
         bmult_dev(c, DQMC_LEFT, 0, k_lp1, k_l, c->T1);
         UdVSlot t = c->storage[l + 1]; t.Vt = c->tmpudv.Vt;
-        if ((rc = udv_dev(c, c->T1, c->storage[l].d, nullptr, t))) return rc;
+        if ((rc = decompose(c, c->T1, c->storage[l].d, nullptr, KIND_R, t))) return rc;
         gemm_dev(c, 0, 0, c->storage[l].Vt, c->tmpudv.Vt, c->storage[l + 1].Vt);
     }
-    if ((rc = green_from_eye(c, c->storage[n]))) return rc;
+    if ((rc = green_from_eye(c, c->storage[n], KIND_R))) return rc;
     c->currentTimeslice = m;
     return DQMC_OK;
 }
@@ -495,15 +582,15 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
             { ProfScope ps(c, FAM_OTHER, 1); launch_conj_transpose(c->st, st.Vt, c->T1, ng); }
             bmult_dev(c, DQMC_RIGHT, 0, k_l, k_lm1, c->T1);
             UdVSlot t = L; t.U = c->tmpudv.U;
-            if ((rc = udv_dev(c, c->T1, nullptr, st.d, t))) return rc;
+            if ((rc = decompose(c, c->T1, nullptr, st.d, KIND_L, t))) return rc;
             gemm_dev(c, 0, 0, st.U, c->tmpudv.U, L.U);
         } else {
             { ProfScope ps(c, FAM_OTHER, 1); launch_set_identity(c->st, c->T1, ng); }
             bmult_dev(c, DQMC_RIGHT, 0, k_l, k_lm1, c->T1);
-            if ((rc = udv_dev(c, c->T1, nullptr, nullptr, L))) return rc;
+            if ((rc = decompose(c, c->T1, nullptr, nullptr, KIND_L, L))) return rc;
         }
         if (l - 1 > 0) rc = green_from_udv(c, L, c->storage[l - 1]);
-        else rc = green_from_eye(c, L);
+        else rc = green_from_eye(c, L, KIND_L);
         if (rc) return rc;
         std::swap(c->storage[l - 1], c->spare);          // storage[l-1] = UdV_L
         c->currentTimeslice = s * (l - 1);
@@ -517,10 +604,10 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
         launch_copy(c->st, st.U, c->T1, (size_t)ng * ng);
         bmult_dev(c, DQMC_LEFT, 0, k_lp1, k_l, c->T1);
         UdVSlot t = T; t.Vt = c->tmpudv.Vt;
-        if ((rc = udv_dev(c, c->T1, st.d, nullptr, t))) return rc;
+        if ((rc = decompose(c, c->T1, st.d, nullptr, KIND_R, t))) return rc;
         gemm_dev(c, 0, 0, st.Vt, c->tmpudv.Vt, T.Vt);
         if (k_lp1 != m) rc = green_from_udv(c, c->storage[l + 1], T);
-        else rc = green_from_eye(c, T);
+        else rc = green_from_eye(c, T, KIND_R);
         if (rc) return rc;
         std::swap(c->storage[l + 1], c->spare);
         c->currentTimeslice = k_lp1;
@@ -630,7 +717,7 @@ extern "C" int dqmc_udv_decompose_host(dqmc_ctx* c, const dqmc_cplx* M, dqmc_cpl
     (void)hipSetDevice(c->p.device);
     const size_t n2 = (size_t)c->n_g * c->n_g;
     HIPCHK(hipMemcpyAsync(c->T1, M, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
-    int rc = udv_dev(c, c->T1, nullptr, nullptr, c->tmpudv);
+    int rc = decompose(c, c->T1, nullptr, nullptr, KIND_R, c->tmpudv);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipMemcpy(U, c->tmpudv.U, n2 * sizeof(cplx), hipMemcpyDeviceToHost));
@@ -754,7 +841,7 @@ extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
     prof_collect(c);
     c->prof = on != 0;
     for (int i = 0; i < FAM_COUNT; ++i) { c->fam_ms[i] = 0; c->fam_launches[i] = 0; }
-    c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0;
+    c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0; c->qr_calls = 0;
     return DQMC_OK;
 }
 extern "C" int dqmc_profile_read(dqmc_ctx* c, double ms[8], uint64_t launches[8]) {
@@ -762,6 +849,6 @@ extern "C" int dqmc_profile_read(dqmc_ctx* c, double ms[8], uint64_t launches[8]
     (void)hipSetDevice(c->p.device);
     prof_collect(c);
     for (int i = 0; i < FAM_COUNT; ++i) { if (ms) ms[i] = c->fam_ms[i]; if (launches) launches[i] = c->fam_launches[i]; }
-    if (launches) { launches[5] = c->svd_calls; launches[6] = c->svd_sweeps_total; launches[7] = (uint64_t)c->svd_sweeps_max; }
+    if (launches) { launches[5] = c->svd_calls + c->qr_calls; launches[6] = c->svd_sweeps_total; launches[7] = (uint64_t)c->svd_sweeps_max; }
     return DQMC_OK;
 }

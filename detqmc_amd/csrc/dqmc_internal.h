@@ -91,3 +91,18 @@ void launch_conj_transpose(hipStream_t st, const cplx* A, cplx* B, int n);
 void launch_add_diag(hipStream_t st, cplx* A, const double* d, int n);
 void launch_copy(hipStream_t st, const cplx* A, cplx* B, size_t count);
 void launch_phi_sq_sum(hipStream_t st, const DevModel& hm, double* out);
+
+// ---- QR / UDT building blocks (kernels_qr.hip) ------------------------------------------------
+struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; };
+int run_qr(hipStream_t st, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit
+int run_trsm_right_upper(hipStream_t st, int n, const cplx* R, cplx* C, const QrWork& w);   // C <- C R^-1
+void launch_udt_init(hipStream_t st, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,
+                     int transpose, cplx* W, int n);
+void launch_udt_diag(hipStream_t st, const cplx* R, int n, double* d);
+void launch_udt_tmat(hipStream_t st, const cplx* R, const double* d, const int* perm, int n, cplx* Tt);
+void launch_permute_scale_cols(hipStream_t st, const cplx* X, const double* cs, const int* perm, int n, cplx* Y);
+void launch_split_scales(hipStream_t st, const double* d, int n, double* dmax_inv, double* dmin);
+void launch_logdet_vector(hipStream_t st, const cplx* R, const double* a, const double* b, int n, double* sv);
+// column norms / ranks shared with the SVD path (kernels_svd.hip)
+void launch_scaled_norms_rank(hipStream_t st, const cplx* M, int ldm, const double* cs, const double* rs, int transpose,
+                              int n, double* norms, int* rank, double* scratch_d);

@@ -65,6 +65,8 @@ DetSDW::DetSDW(const detsdw_params& in) : pars_(in), rng_(in.rngSeed, (uint32_t)
     kp.dtau = p.dtau; kp.r = p.r; kp.c = p.c; kp.u = p.u; kp.lambda = p.lambda;
     kp.txhor = p.txhor; kp.txver = p.txver; kp.tyhor = p.tyhor; kp.tyver = p.tyver;
     kp.mux = p.mux; kp.muy = p.muy; kp.accRatio = p.accRatio;
+    if (p.stabilisation != 0 && p.stabilisation != 1) throw ParameterWrong("Parameter stabilisation has incorrect value");
+    kp.stabilisation = p.stabilisation;
     check(dqmc_create(&kp, &ctx_), "dqmc_create");
 
     phi_.assign((size_t)N_ * opdim_ * (m_ + 1), 0.0);

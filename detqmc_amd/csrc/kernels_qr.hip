@@ -1,0 +1,469 @@
+// Householder QR on gfx950 (complex fp64) -- the factorisation behind the "qr" stabilisation mode.
+//
+// The reference stabilises B-matrix chains with udvDecompose = full SVD (src/udv.h:68-102); its own
+// header keeps a QR variant as dead code (src/udv.h:150-159) and BASELINE.json's north star asks for a
+// QR-based UDV.  In "qr" mode a chain matrix M (columns graded by the previous scales) is decomposed as
+//        M P = Q R,   d = |diag R|,   T = D^-1 R P^T        =>   M = Q D T
+// with P a column pre-pivoting (columns sorted by decreasing norm, decided on the device), Q unitary,
+// and T well conditioned.  G is decomposition independent, so it agrees with the SVD path / the reference
+// to rounding (tests: 1e-10), at a fraction of the cost of a Jacobi SVD.
+//
+// Blocked right-looking algorithm, panel width NB = 16:
+//   k_qr_panel    one workgroup factors a (rows x 16) panel held in REGISTERS (each thread owns RPT rows
+//                 of all 16 columns): per column one norm reduction and one batched reduction of the
+//                 v^H a_c' / v_k^H v_c dot products (DPP wave sums + one LDS hop), then the rank-1 update of
+//                 the rest of the panel; also builds the compact-WY factor T (zlarft) on the fly.
+//   trailing update and formation of Q: three small GEMMs per panel on the MFMA kernel
+//                 (W = V^H C, W <- -T^(H) W, C += V W).
+#include "dqmc_internal.h"
+#include <cstring>
+
+#define QR_NB 16
+
+template<int CTRL, int ROWMASK>
+__device__ __forceinline__ double q_dpp_add(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+    int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double q_readlane_d(double x, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double q_wave_total(double v) {
+    v = q_dpp_add<0xB1, 0xf>(v);
+    v = q_dpp_add<0x4E, 0xf>(v);
+    v = q_dpp_add<0x114, 0xf>(v);
+    v = q_dpp_add<0x118, 0xf>(v);
+    v = q_dpp_add<0x142, 0xa>(v);
+    v = q_dpp_add<0x143, 0xc>(v);
+    return q_readlane_d(v, 63);
+}
+__device__ __forceinline__ cplx q_cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// One column step of the panel factorisation (C = column index inside the panel, compile time).
+template<int RPT, int C>
+struct QrPanelStep {
+    template<class S> __device__ static __forceinline__ void run(S& s) {
+        s.template column<C>();
+        QrPanelStep<RPT, C + 1>::run(s);
+    }
+};
+template<int RPT>
+struct QrPanelStep<RPT, QR_NB> {
+    template<class S> __device__ static __forceinline__ void run(S&) {}
+};
+
+template<int RPT>
+struct QrPanelState {
+    cplx a[RPT][QR_NB];          // rows tid + r*256 (relative to the panel's first row) of the panel
+    double (*red)[4][2 * QR_NB]; // [parity][wave][...] cross-wave scratch
+    cplx* sT;                    // [NB][NB] compact-WY factor, column major in LDS
+    cplx* sTau;                  // [NB]
+    double* sBeta;               // [NB]  diagonal of R
+    cplx* sAlpha;                // broadcast slot for the pivot element
+    int tid, lane, wave, rows, ncols;
+
+    template<int C>
+    __device__ __forceinline__ void column() {
+        if (C >= ncols) return;                     // short last panel (n not a multiple of NB)
+        // ---- pivot element and norm of the part below it ----
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            int row = tid + r * 256;
+            if (row > C && row < rows) part += a[r][C].x * a[r][C].x + a[r][C].y * a[r][C].y;
+        }
+        part = q_wave_total(part);
+        if (tid == C) *sAlpha = a[0][C];            // row C lives in thread C, r = 0 (NB <= 256)
+        if (lane == 0) red[0][wave][0] = part;
+        __syncthreads();
+        const double xnorm2 = (red[0][0][0] + red[0][1][0]) + (red[0][2][0] + red[0][3][0]);
+        const cplx alpha = *sAlpha;
+        // zlarfg: beta = -sign(Re alpha) sqrt(|alpha|^2 + xnorm^2), tau = (beta - alpha)/beta, v = x/(alpha - beta)
+        cplx tau = make_double2(0.0, 0.0), scal = make_double2(0.0, 0.0);
+        double beta = alpha.x;
+        const bool trivial = (xnorm2 == 0.0 && alpha.y == 0.0);
+        if (!trivial) {
+            double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2);
+            beta = (alpha.x >= 0.0) ? -nrm : nrm;
+            tau = make_double2((beta - alpha.x) / beta, -alpha.y / beta);
+            double dr = alpha.x - beta, di = alpha.y, dn = dr * dr + di * di;
+            scal = make_double2(dr / dn, -di / dn);                 // 1 / (alpha - beta)
+        }
+        // ---- v in place (zeros above row C, one at row C) ----
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            int row = tid + r * 256;
+            if (row > C) a[r][C] = q_cmul(a[r][C], scal);
+        }
+        // the thread owning row C keeps R[C][C] = beta aside; its v entry is 1
+        cplx vpiv = make_double2(1.0, 0.0);
+        // ---- batched dot products: w[c'] = v^H a_c' (c' > C) and z[k] = v_k^H v_C (k < C) ----
+        double pr[QR_NB], pi[QR_NB];
+#pragma unroll
+        for (int c = 0; c < QR_NB; ++c) { pr[c] = 0.0; pi[c] = 0.0; }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            int row = tid + r * 256;
+            if (row >= C && row < rows) {
+                cplx v = (row == C) ? vpiv : a[r][C];
+#pragma unroll
+                for (int c = 0; c < QR_NB; ++c) {
+                    if (c == C) continue;
+                    // columns c < C hold earlier reflectors v_c below their diagonal (rows > c); row == c is 1,
+                    // rows < c are R entries and do not belong to v_c.  Since row >= C > c here, a[r][c] is v_c.
+                    cplx x = a[r][c];
+                    if (c > C) {            // conj(v) * a
+                        pr[c] += v.x * x.x + v.y * x.y;
+                        pi[c] += v.x * x.y - v.y * x.x;
+                    } else {                // conj(v_c) * v
+                        pr[c] += x.x * v.x + x.y * v.y;
+                        pi[c] += x.x * v.y - x.y * v.x;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < QR_NB; ++c) {
+            if (c == C) continue;
+            pr[c] = q_wave_total(pr[c]);
+            pi[c] = q_wave_total(pi[c]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < QR_NB; ++c) {
+                if (c == C) continue;
+                red[1][wave][2 * c] = pr[c];
+                red[1][wave][2 * c + 1] = pi[c];
+            }
+        }
+        __syncthreads();
+        cplx w[QR_NB];
+#pragma unroll
+        for (int c = 0; c < QR_NB; ++c) {
+            if (c == C) { w[c] = make_double2(0.0, 0.0); continue; }
+            w[c] = make_double2((red[1][0][2 * c] + red[1][1][2 * c]) + (red[1][2][2 * c] + red[1][3][2 * c]),
+                                (red[1][0][2 * c + 1] + red[1][1][2 * c + 1]) + (red[1][2][2 * c + 1] + red[1][3][2 * c + 1]));
+        }
+        // ---- apply H^H = I - conj(tau) v v^H to the rest of the panel ----
+        const cplx ctau = make_double2(tau.x, -tau.y);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            int row = tid + r * 256;
+            if (row >= C && row < rows) {
+                cplx v = (row == C) ? vpiv : a[r][C];
+                cplx tv = q_cmul(ctau, v);
+#pragma unroll
+                for (int c = C + 1; c < QR_NB; ++c) {
+                    cplx t = q_cmul(tv, w[c]);
+                    a[r][c].x -= t.x;
+                    a[r][c].y -= t.y;
+                }
+            }
+        }
+        // ---- compact WY factor (zlarft, forward/columnwise): T[0:C,C] = -tau T[0:C,0:C] z, T[C,C] = tau ----
+        if (tid < QR_NB) {
+            int i = tid;
+            cplx t = make_double2(0.0, 0.0);
+            if (i < C) {
+                cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int k = 0; k < QR_NB; ++k) {
+                    if (k < C && k >= i) {
+                        cplx tik = sT[k * QR_NB + i];
+                        cplx t2 = q_cmul(tik, w[k]);
+                        acc.x += t2.x; acc.y += t2.y;
+                    }
+                }
+                cplx t3 = q_cmul(tau, acc);
+                t = make_double2(-t3.x, -t3.y);
+            } else if (i == C) {
+                t = tau;
+            }
+            sT[C * QR_NB + i] = t;
+            if (i == C) { sTau[C] = tau; sBeta[C] = beta; }
+        }
+        __syncthreads();
+    }
+};
+
+// Factor the panel A[j0:n, j0:j0+NB]:  R (upper part) goes back into A, the reflectors into Vp (unit lower
+// trapezoidal, zeros above the diagonal, same position as in A), T into Tp[NB*NB] (column major) and
+// -T into Tn[NB*NB].
+template<int RPT>
+__global__ __launch_bounds__(256) void k_qr_panel(cplx* __restrict__ A, int lda, int n, int j0,
+                                                   cplx* __restrict__ Vp, cplx* __restrict__ Tp, cplx* __restrict__ Tn) {
+    __shared__ double red[2][4][2 * QR_NB];
+    __shared__ cplx sT[QR_NB * QR_NB];
+    __shared__ cplx sTau[QR_NB];
+    __shared__ double sBeta[QR_NB];
+    __shared__ cplx sAlpha;
+    QrPanelState<RPT> s;
+    s.red = red; s.sT = sT; s.sTau = sTau; s.sBeta = sBeta; s.sAlpha = &sAlpha;
+    s.tid = threadIdx.x; s.lane = threadIdx.x & 63; s.wave = threadIdx.x >> 6;
+    s.rows = n - j0;
+    s.ncols = (n - j0 < QR_NB) ? (n - j0) : QR_NB;
+    for (int i = threadIdx.x; i < QR_NB * QR_NB; i += 256) sT[i] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        int row = s.tid + r * 256;
+#pragma unroll
+        for (int c = 0; c < QR_NB; ++c)
+            s.a[r][c] = (row < s.rows && c < s.ncols) ? A[(size_t)(j0 + c) * lda + (j0 + row)] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    QrPanelStep<RPT, 0>::run(s);
+    // ---- write back ----
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        int row = s.tid + r * 256;
+        if (row < s.rows) {
+#pragma unroll
+            for (int c = 0; c < QR_NB; ++c) {
+                if (c >= s.ncols) continue;
+                size_t off = (size_t)(j0 + c) * lda + (j0 + row);
+                cplx x = s.a[r][c];
+                if (row < c) {                 // strictly upper part of the top block: R
+                    A[off] = x;
+                    Vp[off] = make_double2(0.0, 0.0);
+                } else if (row == c) {
+                    A[off] = make_double2(sBeta[c], 0.0);
+                    Vp[off] = make_double2(1.0, 0.0);
+                } else {
+                    A[off] = make_double2(0.0, 0.0);
+                    Vp[off] = x;
+                }
+            }
+        }
+    }
+    for (int i = threadIdx.x; i < QR_NB * QR_NB; i += 256) {
+        cplx t = sT[i];
+        Tp[i] = t;
+        Tn[i] = make_double2(-t.x, -t.y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// driver: A (n x n, ld n) -> R in place (strict lower part zeroed), Q explicit; V/T workspace
+// ---------------------------------------------------------------------------------------------
+static void gemm_small(hipStream_t st, int opA, int opB, const cplx* A, int lda, const cplx* B, int ldb, cplx* C, int ldc,
+                       int M, int N, int K, int accumulate) {
+    GemmArgs g = GemmArgs();
+    g.A = A; g.lda = lda; g.opA = opA; g.B = B; g.ldb = ldb; g.opB = opB; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.Kmul = 1; g.accumulate = accumulate;
+    launch_gemm(st, g);
+}
+
+static void launch_panel(hipStream_t st, cplx* A, int n, int j0, cplx* V, cplx* Tp, cplx* Tn) {
+    const int rows = n - j0;
+    const int rpt = (rows + 255) / 256;
+    switch (rpt) {
+        case 1: hipLaunchKernelGGL((k_qr_panel<1>), dim3(1), dim3(256), 0, st, A, n, n, j0, V, Tp, Tn); break;
+        case 2: hipLaunchKernelGGL((k_qr_panel<2>), dim3(1), dim3(256), 0, st, A, n, n, j0, V, Tp, Tn); break;
+        case 3: hipLaunchKernelGGL((k_qr_panel<3>), dim3(1), dim3(256), 0, st, A, n, n, j0, V, Tp, Tn); break;
+        case 4: hipLaunchKernelGGL((k_qr_panel<4>), dim3(1), dim3(256), 0, st, A, n, n, j0, V, Tp, Tn); break;
+        default: break;     // n <= 1024 enforced by the caller
+    }
+}
+
+// returns number of kernel launches issued (for the profiling counters)
+int run_qr(hipStream_t st, int n, cplx* A, cplx* Q, const QrWork& w) {
+    int launches = 0;
+    const int np = (n + QR_NB - 1) / QR_NB;
+    for (int p = 0; p < np; ++p) {
+        const int j0 = p * QR_NB;
+        const int nb = (n - j0 < QR_NB) ? (n - j0) : QR_NB;   // n is a multiple of 8: a last half panel is padded by the kernel guards
+        cplx* Tp = w.T + (size_t)p * 2 * QR_NB * QR_NB;
+        cplx* Tn = Tp + QR_NB * QR_NB;
+        launch_panel(st, A, n, j0, w.V, Tp, Tn);
+        ++launches;
+        const int rows = n - j0, ntrail = n - j0 - nb;
+        if (ntrail > 0) {
+            const cplx* Vp = w.V + (size_t)j0 * n + j0;
+            cplx* C = A + (size_t)(j0 + nb) * n + j0;
+            // W = V^H C ; W2 = (-T)^H W ; C += V W2        (apply Q_p^H = I - V T^H V^H)
+            gemm_small(st, 1, 0, Vp, n, C, n, w.W, QR_NB, nb, ntrail, rows, 0);
+            gemm_small(st, 1, 0, Tn, QR_NB, w.W, QR_NB, w.W2, QR_NB, nb, ntrail, nb, 0);
+            gemm_small(st, 0, 0, Vp, n, w.W2, QR_NB, C, n, rows, ntrail, nb, 1);
+            launches += 3;
+        }
+    }
+    // ---- Q = H_0 H_1 ... applied to the identity, block reflectors in reverse order (zungqr) ----
+    launch_set_identity(st, Q, n);
+    ++launches;
+    for (int p = np - 1; p >= 0; --p) {
+        const int j0 = p * QR_NB;
+        const int nb = (n - j0 < QR_NB) ? (n - j0) : QR_NB;
+        const int rows = n - j0, ncols = n - j0;
+        const cplx* Vp = w.V + (size_t)j0 * n + j0;
+        const cplx* Tn = w.T + (size_t)p * 2 * QR_NB * QR_NB + QR_NB * QR_NB;
+        cplx* C = Q + (size_t)j0 * n + j0;
+        // C <- (I - V T V^H) C :  W = V^H C ; W2 = (-T) W ; C += V W2
+        gemm_small(st, 1, 0, Vp, n, C, n, w.W, QR_NB, nb, ncols, rows, 0);
+        gemm_small(st, 0, 0, Tn, QR_NB, w.W, QR_NB, w.W2, QR_NB, nb, ncols, nb, 0);
+        gemm_small(st, 0, 0, Vp, n, w.W2, QR_NB, C, n, rows, ncols, nb, 1);
+        launches += 3;
+    }
+    return launches;
+}
+
+// ---------------------------------------------------------------------------------------------
+// right-hand triangular solve  Y R = C  (R upper triangular n x n), in place on C, blocked by NB:
+//   for each column block J:  C_J -= Y_{<J} R_{<J,J}  (GEMM);  C_J <- C_J R_JJ^-1  (one thread per row)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm_block(cplx* __restrict__ C, int ldc, const cplx* __restrict__ R, int ldr,
+                                                     int n, int j0, int nb) {
+    __shared__ cplx sR[QR_NB][QR_NB + 1];
+    for (int i = threadIdx.x; i < QR_NB * QR_NB; i += 256) {
+        int r = i % QR_NB, c = i / QR_NB;
+        sR[r][c] = (r < nb && c < nb && r <= c) ? R[(size_t)(j0 + c) * ldr + (j0 + r)] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    cplx y[QR_NB];
+#pragma unroll
+    for (int c = 0; c < QR_NB; ++c) y[c] = (c < nb) ? C[(size_t)(j0 + c) * ldc + row] : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int c = 0; c < QR_NB; ++c) {
+        if (c < nb) {
+            cplx acc = y[c];
+#pragma unroll
+            for (int k = 0; k < QR_NB; ++k) {
+                if (k < c) {
+                    cplx t = q_cmul(y[k], sR[k][c]);
+                    acc.x -= t.x; acc.y -= t.y;
+                }
+            }
+            cplx d = sR[c][c];
+            double dn = d.x * d.x + d.y * d.y;
+            y[c] = make_double2((acc.x * d.x + acc.y * d.y) / dn, (acc.y * d.x - acc.x * d.y) / dn);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < QR_NB; ++c)
+        if (c < nb) C[(size_t)(j0 + c) * ldc + row] = y[c];
+}
+
+__global__ void k_negate_copy_block(const cplx* __restrict__ R, int ldr, int rows, int cols, cplx* __restrict__ out, int ldo) {
+    size_t total = (size_t)rows * cols;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(idx % rows), j = (int)(idx / rows);
+        cplx v = R[(size_t)j * ldr + i];
+        out[(size_t)j * ldo + i] = make_double2(-v.x, -v.y);
+    }
+}
+
+int run_trsm_right_upper(hipStream_t st, int n, const cplx* R, cplx* C, const QrWork& w) {
+    int launches = 0;
+    for (int j0 = 0; j0 < n; j0 += QR_NB) {
+        const int nb = (n - j0 < QR_NB) ? (n - j0) : QR_NB;
+        if (j0 > 0) {
+            // C_J += Y_{<J} (-R_{<J,J})
+            hipLaunchKernelGGL(k_negate_copy_block, dim3((j0 * nb + 255) / 256), dim3(256), 0, st,
+                               R + (size_t)j0 * n, n, j0, nb, w.Rneg, n);
+            gemm_small(st, 0, 0, C, n, w.Rneg, n, C + (size_t)j0 * n, n, n, nb, j0, 1);
+            launches += 2;
+        }
+        hipLaunchKernelGGL(k_trsm_block, dim3((n + 255) / 256), dim3(256), 0, st, C, n, R, n, n, j0, nb);
+        ++launches;
+    }
+    return launches;
+}
+
+// ---------------------------------------------------------------------------------------------
+// glue for the UDT decomposition  Ms P = Q R  ->  (Q, d, T^H) resp. (T^H, d, Q)
+// ---------------------------------------------------------------------------------------------
+// W[:, perm[j]] = Ms[:, j] (or Ms^H when T != 0), Ms = diag(rowscale) M diag(colscale)
+__global__ void k_udt_init(const cplx* __restrict__ M, int ldm, const double* colscale, const double* rowscale,
+                           const int* __restrict__ perm, int transpose, cplx* __restrict__ W, int n) {
+    size_t total = (size_t)n * n;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(idx % n), j = (int)(idx / n);
+        int mi = transpose ? j : i, mj = transpose ? i : j;
+        cplx v = M[(size_t)mj * ldm + mi];
+        double sc = 1.0;
+        if (colscale) sc *= colscale[mj];
+        if (rowscale) sc *= rowscale[mi];
+        W[(size_t)perm[j] * n + i] = make_double2(v.x * sc, transpose ? -v.y * sc : v.y * sc);
+    }
+}
+
+// d[k] = |R[k,k]|
+__global__ void k_udt_diag(const cplx* __restrict__ R, int n, double* d) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { cplx r = R[(size_t)k * n + k]; d[k] = sqrt(r.x * r.x + r.y * r.y); }
+}
+
+// Tt[j, k] = conj(R[k, perm[j]]) / d[k]   (= (D^-1 R P^T)^H); zero where R is zero
+__global__ void k_udt_tmat(const cplx* __restrict__ R, const double* __restrict__ d, const int* __restrict__ perm,
+                           int n, cplx* __restrict__ Tt) {
+    size_t total = (size_t)n * n;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int j = (int)(idx % n), k = (int)(idx / n);           // Tt(j, k), column major: contiguous in j
+        int c = perm[j];
+        cplx v = make_double2(0.0, 0.0);
+        if (c >= k) {
+            cplx r = R[(size_t)c * n + k];
+            double inv = 1.0 / d[k];
+            v = make_double2(r.x * inv, -r.y * inv);
+        }
+        Tt[idx] = v;
+    }
+}
+
+// Y[:, perm[j]] = X[:, j] * colscale[j]
+__global__ void k_permute_scale_cols(const cplx* __restrict__ X, const double* colscale, const int* __restrict__ perm,
+                                     int n, cplx* __restrict__ Y) {
+    size_t total = (size_t)n * n;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(idx % n), j = (int)(idx / n);
+        cplx v = X[idx];
+        double sc = colscale ? colscale[j] : 1.0;
+        Y[(size_t)perm[j] * n + i] = make_double2(v.x * sc, v.y * sc);
+    }
+}
+
+// scale splitting of the UdV singular scales: dmax_inv = 1/max(d,1), dmin = min(d,1)
+__global__ void k_split_scales(const double* __restrict__ d, int n, double* dmax_inv, double* dmin) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        double x = d[k];
+        dmax_inv[k] = (x > 1.0) ? 1.0 / x : 1.0;
+        dmin[k] = (x > 1.0) ? 1.0 : x;
+    }
+}
+
+// sv[k] = |R[k,k]| * max(d_r[k],1) * max(d_l[k],1): its log-sum is log|det G^-1| (the only thing the
+// global moves use, detsdwopdim.cpp:3613-3620)
+__global__ void k_logdet_vector(const cplx* __restrict__ R, const double* __restrict__ drmax_inv,
+                                const double* __restrict__ dlmax_inv, int n, double* sv) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        cplx r = R[(size_t)k * n + k];
+        sv[k] = sqrt(r.x * r.x + r.y * r.y) / (drmax_inv[k] * dlmax_inv[k]);
+    }
+}
+
+void launch_udt_init(hipStream_t st, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,
+                     int transpose, cplx* W, int n) {
+    hipLaunchKernelGGL(k_udt_init, dim3(1024), dim3(256), 0, st, M, ldm, cs, rs, perm, transpose, W, n);
+}
+void launch_udt_diag(hipStream_t st, const cplx* R, int n, double* d) {
+    hipLaunchKernelGGL(k_udt_diag, dim3((n + 255) / 256), dim3(256), 0, st, R, n, d);
+}
+void launch_udt_tmat(hipStream_t st, const cplx* R, const double* d, const int* perm, int n, cplx* Tt) {
+    hipLaunchKernelGGL(k_udt_tmat, dim3(1024), dim3(256), 0, st, R, d, perm, n, Tt);
+}
+void launch_permute_scale_cols(hipStream_t st, const cplx* X, const double* cs, const int* perm, int n, cplx* Y) {
+    hipLaunchKernelGGL(k_permute_scale_cols, dim3(1024), dim3(256), 0, st, X, cs, perm, n, Y);
+}
+void launch_split_scales(hipStream_t st, const double* d, int n, double* dmax_inv, double* dmin) {
+    hipLaunchKernelGGL(k_split_scales, dim3((n + 255) / 256), dim3(256), 0, st, d, n, dmax_inv, dmin);
+}
+void launch_logdet_vector(hipStream_t st, const cplx* R, const double* a, const double* b, int n, double* sv) {
+    hipLaunchKernelGGL(k_logdet_vector, dim3((n + 255) / 256), dim3(256), 0, st, R, a, b, n, sv);
+}

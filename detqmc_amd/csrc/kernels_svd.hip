@@ -391,6 +391,16 @@ __global__ __launch_bounds__(256) void k_svd_scatter(const cplx* __restrict__ A,
     }
 }
 
+// ranks (0 = largest) of the column norms of Ms (transpose == 0) or of its row norms (transpose != 0)
+void launch_scaled_norms_rank(hipStream_t st, const cplx* M, int ldm, const double* cs, const double* rs, int transpose,
+                              int n, double* norms, int* rank, double* scratch_d) {
+    if (!transpose)
+        hipLaunchKernelGGL(k_scaled_col_norms, dim3((n + 3) / 4), dim3(256), 0, st, M, ldm, cs, rs, n, norms);
+    else
+        hipLaunchKernelGGL(k_scaled_row_norms, dim3((n + 63) / 64), dim3(256), 0, st, M, ldm, cs, rs, n, norms);
+    hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, st, norms, norms, nullptr, n, rank, scratch_d);
+}
+
 int svd_block_cols(int n) {
     // columns per block; the kernel holds 2 blocks = NCOL columns.  n <= 1024: 4 (NCOL 8), else 2.
     return (n <= 1024) ? 4 : 2;

@@ -19,6 +19,7 @@ from ._lib import check, load
 
 BC = {"pbc": 0, "apbc-x": 1, "apbc-y": 2, "apbc-xy": 3}
 UPDATE_METHOD = {"iterative": 0, "woodbury": 1, "delayed": 2}
+STABILISATION = {"svd": 0, "qr": 1}
 LEFT, RIGHT = 0, 1
 UP, DOWN = +1, -1
 
@@ -55,6 +56,7 @@ class SDWParams:
     rngSeed: int = 1020304050
     simindex: int = 0
     device: int = 0
+    stabilisation: str = "svd"   # "svd": UdV = SVD like the reference; "qr": pre-pivoted Householder UDT
 
 
 def _fmat(a):
@@ -67,11 +69,11 @@ class KernelContext:
 
     def __init__(self, opdim, L, m, s, dtau, delaySteps=16, bc="pbc", weakZflux=False, r=-1.0, c=3.0, u=1.0,
                  lambda_=1.0, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, mux=-0.5, muy=-0.5,
-                 accRatio=0.5, phi2bosons=False, device=0):
+                 accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd"):
         self.lib = load()
         p = _lib.dqmc_params(opdim=opdim, L=L, m=m, s=s, delaySteps=delaySteps, bc=BC[bc],
                              weakZflux=int(weakZflux), phi2bosons=int(phi2bosons), device=device,
-                             dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
+                             stabilisation=STABILISATION[stabilisation], dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
                              tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio)
         h = C.c_void_p()
         check(self.lib.dqmc_create(C.byref(p), C.byref(h)))
@@ -255,7 +257,8 @@ class DetSDW:
             updateMethod=UPDATE_METHOD[pars.updateMethod], bc=pars.bc.encode(),
             beta=pars.beta, dtau=pars.dtau, r=pars.r, c=pars.c, u=pars.u, lambda_=pars.lambda_,
             txhor=pars.txhor, txver=pars.txver, tyhor=pars.tyhor, tyver=pars.tyver,
-            mu=pars.mu, mux=pars.mux or 0.0, muy=pars.muy or 0.0, accRatio=pars.accRatio, cdwU=pars.cdwU)
+            mu=pars.mu, mux=pars.mux or 0.0, muy=pars.muy or 0.0, accRatio=pars.accRatio, cdwU=pars.cdwU,
+            stabilisation=STABILISATION[pars.stabilisation])
         h = C.c_void_p()
         check(self.lib.detsdw_create(C.byref(p), C.byref(h)), host=True)
         self.h = h

@@ -49,6 +49,8 @@ typedef struct detsdw_params {
     double mu, mux, muy;
     double accRatio;
     double cdwU;                 /* must be 0 */
+    int32_t stabilisation;       /* 0 = SVD (as the reference), 1 = QR/UDT (same G to rounding, much faster) */
+    int32_t reserved2;
 } detsdw_params;
 
 typedef struct detsdw_info {

@@ -48,6 +48,7 @@ enum {
 enum { DQMC_BC_PBC = 0, DQMC_BC_APBC_X = 1, DQMC_BC_APBC_Y = 2, DQMC_BC_APBC_XY = 3 };
 enum { DQMC_LEFT = 0, DQMC_RIGHT = 1 };
 enum { DQMC_UP = +1, DQMC_DOWN = -1 };
+enum { DQMC_STAB_SVD = 0, DQMC_STAB_QR = 1 };
 
 /* ModelParamsDetSDW fields the kernels depend on (src/detsdwparams.h:24-120) */
 typedef struct dqmc_params {
@@ -60,7 +61,7 @@ typedef struct dqmc_params {
     int32_t weakZflux;    /* only with opdim == 2 */
     int32_t phi2bosons;
     int32_t device;       /* HIP device ordinal */
-    int32_t reserved;
+    int32_t stabilisation; /* DQMC_STAB_SVD (reference-exact UdV = SVD) or DQMC_STAB_QR (pre-pivoted Householder UDT) */
     double dtau, r, c, u, lambda;
     double txhor, txver, tyhor, tyver;
     double mux, muy;
@@ -137,7 +138,9 @@ int dqmc_set_update_state_host(dqmc_ctx* ctx, const dqmc_update_state* in);
 /* ---- state access ------------------------------------------------------------------------------ */
 int dqmc_get_green_host(dqmc_ctx* ctx, dqmc_cplx* out);
 int dqmc_set_green_host(dqmc_ctx* ctx, const dqmc_cplx* in, int currentTimeslice);
-int dqmc_get_sv_host(dqmc_ctx* ctx, double* out);                 /* green_inv_sv (detmodel.h:466) */
+/* green_inv_sv (detmodel.h:466): singular values of G^-1 in SVD mode; in QR mode a positive vector with
+ * the same log-sum (= log|det G^-1|), which is all the global moves use (detsdwopdim.cpp:3613-3620) */
+int dqmc_get_sv_host(dqmc_ctx* ctx, double* out);
 int dqmc_get_udv_host(dqmc_ctx* ctx, int l, dqmc_cplx* U, double* d, dqmc_cplx* V_t);
 int dqmc_current_timeslice(dqmc_ctx* ctx);
 

@@ -7,8 +7,9 @@ from detqmc_amd import DetSDW, SDWParams
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 beta = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 nsw = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+stab = sys.argv[4] if len(sys.argv) > 4 else "svd"
 t0 = time.time()
-rep = DetSDW(SDWParams(opdim=2, L=L, beta=beta, s=10, delaySteps=16))
+rep = DetSDW(SDWParams(opdim=2, L=L, beta=beta, s=10, delaySteps=16, stabilisation=stab))
 print("init %.3f s" % (time.time() - t0), flush=True)
 ctx = rep.kernel_context
 for i in range(2):

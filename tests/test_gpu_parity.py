@@ -363,3 +363,77 @@ def test_headline_size_vs_reference_checksums():
     assert relerr(U.conj().T @ U, I) < 1e-11 and relerr(Vt.conj().T @ Vt, I) < 1e-11
     assert np.all(np.diff(d) <= 0)
     rep.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# QR ("UDT") stabilisation mode: different factorisation, same Green's functions and same Markov chain
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,opdim", [(4, 2), (6, 2), (8, 2), (4, 3)])
+def test_qr_udt_decompose(L, opdim):
+    from detqmc_amd import KernelContext
+    ctx = KernelContext(opdim, L, 20, 10, 0.1, delaySteps=4, stabilisation="qr")
+    n = ctx.ng
+    rng = np.random.default_rng(5)
+    W = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    for M in (W, W * np.logspace(8, -8, n)[None, :]):
+        U, d, Vt, _ = ctx.udvDecompose(M)
+        assert relerr(U.conj().T @ U, np.eye(n)) < 1e-12, "Q must be unitary"
+        assert np.all(d > 0)
+        assert relerr((U * d[None, :]) @ Vt.conj().T, M) < 1e-12
+        # T = V_t^H is a row-scaled, column-permuted triangular factor: well conditioned
+        assert np.linalg.cond(Vt) < 1e6
+        # |det M| is carried by d alone
+        sref = np.linalg.svd(M, compute_uv=False)
+        assert abs(np.sum(np.log(d)) + np.log(abs(np.linalg.det(Vt.conj().T))) - np.sum(np.log(sref))) < 1e-8 * n
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"])
+def test_qr_mode_green_from_scratch_vs_reference(name):
+    g = load_golden(name)
+    ctx, op = _ctx_from_params(g["params"], stabilisation="qr")
+    ctx.set_fields(_golden_phi(g, "init_phi"))
+    ctx.setupUdVStorage_and_calculateGreen()
+    assert relerr(ctx.g, g["init_g"]) < TOL
+    # log|det G^-1| agrees with the sum over the reference's singular values
+    assert abs(np.sum(np.log(ctx.g_inv_sv)) - np.sum(np.log(g["init_g_inv_sv"]))) < 1e-9 * ctx.ng
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5", "o2_L4_gshift"])
+def test_qr_mode_replica_trajectory_vs_reference(name):
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr"))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}: trajectory diverged"
+        assert relerr(rep.g, g[f"sweep{i}_g"]) < TOL, f"sweep {i}"
+        assert abs(np.sum(np.log(rep.g_inv_sv)) - np.sum(np.log(g[f"sweep{i}_g_inv_sv"]))) < 1e-9 * rep.info.n_g
+        inf = rep.info
+        assert inf.phiDelta == g[f"sweep{i}_phiDelta"][0]
+        assert inf.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert inf.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+        i += 1
+    nxt = np.array([rep.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"])
+    rep.close()
+
+
+def test_qr_mode_headline_size_vs_reference_checksums():
+    from detqmc_amd import DetSDW
+    g = load_golden("o2_L16_b10")
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr"))
+    G = rep.g
+    assert relerr(G[::16, ::16], g["init_g_sub16"]) < TOL
+    assert relerr(np.diag(G), g["init_g_diag"]) < TOL
+    assert abs(np.sum(np.log(rep.g_inv_sv)) - np.sum(np.log(g["init_g_inv_sv"]))) < 1e-9 * 512
+    for i in (1, 2):
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}"
+        G = rep.g
+        assert relerr(G[::16, ::16], g[f"sweep{i}_g_sub16"]) < TOL
+        assert relerr(np.diag(G), g[f"sweep{i}_g_diag"]) < TOL
+        assert abs(np.linalg.norm(G) - g[f"sweep{i}_g_fro"][0]) < TOL * g[f"sweep{i}_g_fro"][0]
+    rep.close()
