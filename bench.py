@@ -26,8 +26,11 @@ sys.path.insert(0, ROOT)
 
 WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=16, r=-1.0, c=3.0, u=1.0, lambda_=1.0,
                 mu=-0.5, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, bc="pbc", accRatio=0.5,
-                rngSeed=1020304050)
+                rngSeed=1020304050,
+                # same Green's functions and Markov chain as the reference-exact "svd" mode (tests), ~10x cheaper
+                stabilisation=os.environ.get("DQMC_STABILISATION", "qr"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
 DEFAULT_REPLICAS = 4           # chains per GPU; a Jacobi round occupies 64 of the 256 CUs
 
 
@@ -50,7 +53,7 @@ def cpu_baseline(max_seconds=200):
             sys.stderr.write("reference binary unusable (%r), timing the oracle port instead\n" % (e,))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))   # cpu_baseline leg: the oracle is what is timed here
     from detsdw_oracle import DetSDWOracle, SDWParams as OP
-    kw = {k: v for k, v in WORKLOAD.items() if k in OP.__dataclass_fields__}
+    kw = {k: v for k, v in WORKLOAD.items() if k in OP.__dataclass_fields__ and k != "stabilisation"}
     o = DetSDWOracle(OP(**kw))
     t0 = time.time()
     o.sweepThermalization()
@@ -163,19 +166,50 @@ def main():
         r0 = results[0]
         prof = {k: (tuple(v) if isinstance(v, list) else v) for k, v in r0["prof"].items()}
         n = r0["n_g"]
-        # dominant kernel: one Jacobi round = every column of A and of V read once and written once
-        jac_ms, jac_launches = prof["jacobi"]
-        bytes_per_launch = 4.0 * n * n * 16.0
-        fam = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items() if isinstance(v, tuple)}
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_jacobi.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        avg_us = 1e3 * jac_ms / max(jac_launches, 1)
-        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9 if jac_launches else 0.0
+        N, MSF, D, OPD = n // 2, 2, WORKLOAD["delaySteps"], WORKLOAD["opdim"]
+        fam = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items() if isinstance(v, tuple) and k != "jacobi"}
+
+        def hbm(name, kernel, ms, launches, bytes_per_launch, note):
+            us = 1e3 * ms / max(launches, 1)
+            ach = bytes_per_launch / (us * 1e-6) / 1e9 if launches else 0.0
+            return {"family": name, "kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "avg_launch_us": us, "launches": launches, "device_ms": ms, "note": note}
+
+        roofs = []
+        # decision kernel: per proposal (OPDIM+1) uniforms, 7 field vectors, cosh/sinh, G[c,I], G[I,c], G[c,c]
+        # with |I| = MSF*D/2 on average; N proposals per slice spread over ceil(N/D) launches
+        cand_bytes = (OPD + 1) * 8 + 7 * OPD * 8 + 16 + (2 * MSF * (MSF * D // 2) + MSF * MSF) * 16
+        roofs.append(hbm("decide", "k_update_decide<2>", *prof["decide"], N * cand_bytes / ((N + D - 1) // D),
+                         "sequential Metropolis chain of one slice: ONE wavefront by construction, latency bound"))
+        if WORKLOAD["stabilisation"] == "svd":
+            r = hbm("decomp", "k_jacobi_round<8,2>", prof["decomp_round_ms"], prof["decomp_rounds"], 4.0 * n * n * 16.0,
+                    "one Jacobi round reads and writes every column of A and V once")
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_jacobi.json")
+            if os.path.exists(pmc):
+                try:
+                    r["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+            roofs.append(r)
+        else:
+            # QR + formation of Q: every panel step streams the trailing matrix twice (read, write)
+            np_ = (n + 15) // 16
+            qr_bytes = 2 * sum(2 * 16.0 * (n - 16 * p) * (n - 16 * p) for p in range(np_))
+            calls = max(prof["qr_calls"], 1)
+            roofs.append(hbm("decomp", "k_qr_panel + trailing k_zgemm (one UDT factorisation)", prof["decomp"][0], calls, qr_bytes,
+                             "blocked Householder QR incl. explicit Q; launches = factorisations"))
+        roofs.append(hbm("bmult", "k_bmult_chain", *prof["bmult"], 2 * 16.0 * n * n, "one read + one write of A per chain"))
+        roofs.append(hbm("gather", "k_update_gather", *prof["gather"], 4 * 16.0 * n * MSF * D * 0.72,
+                         "X = G[:,I] W and Gr = G[I,:] - E"))
+        roofs.append(hbm("flush", "k_zgemm (G += X Gr)", *prof["flush"], 2 * 16.0 * n * n, "read-modify-write of G per block"))
+        gms, gl = prof["gemm"]
+        tf = prof["gemm_flops"] / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+        roofs.append({"family": "gemm", "kernel": "k_zgemm<1,1>", "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF,
+                      "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF, "traffic": None,
+                      "algorithmic_flops_per_launch": prof["gemm_flops"] / max(gl, 1), "avg_launch_us": 1e3 * gms / max(gl, 1),
+                      "launches": gl, "device_ms": gms, "note": "n_g^3 complex products on v_mfma_f64_16x16x4_f64"})
+        roofs.sort(key=lambda r: -r["device_ms"])
         res = {
             "metric": "DQMC sweeps/sec (SDW-O2 L=16 beta=10 fp64)",
             "value": world * R * a.steps / dt,
@@ -191,15 +225,14 @@ def main():
             "dtype": "f64",
             "data": "synthetic (random initial field, fixed seed)",
             "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(16) "
-                                   "sweepThermalization, %d independent chains per GPU (one process each)" % R,
+                                   "sweepThermalization, %d independent chains per GPU (one process each), stabilisation=%s"
+                                   % (R, WORKLOAD["stabilisation"]),
                        "n_g": n, "m": r0["m"], "replicas_per_gpu": R},
-            "roofline": {"kernel": "k_jacobi_round<8,2>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us,
-                         "launches": jac_launches},
+            "roofline": roofs[0],
+            "roofline_other_kernels": roofs[1:],
             "device_ms_by_family_chain0": fam,
-            "svd_chain0": {"calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
-                           "max_sweeps": prof["svd_sweeps_max"]},
+            "decompositions_chain0": {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
+                                      "max_sweeps": prof["svd_sweeps_max"], "qr_calls": prof["qr_calls"]},
             "acceptance": r0["acceptance"],
         }
         if world == 1 and not a.no_cpu_baseline:

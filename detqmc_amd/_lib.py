@@ -40,6 +40,13 @@ class dqmc_update_state(C.Structure):
                 ("error", C.c_int32), ("reserved", C.c_int32)]
 
 
+class dqmc_profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8),
+                ("svd_calls", C.c_uint64), ("svd_sweeps_total", C.c_uint64), ("svd_sweeps_max", C.c_uint64),
+                ("qr_calls", C.c_uint64), ("gemm_flops", C.c_double), ("decomp_round_ms", C.c_double),
+                ("decomp_rounds", C.c_uint64)]
+
+
 class detsdw_params(C.Structure):
     _fields_ = [("opdim", C.c_int32), ("L", C.c_int32), ("m", C.c_int32), ("s", C.c_int32),
                 ("delaySteps", C.c_int32), ("globalShift", C.c_int32), ("globalUpdateInterval", C.c_int32),
@@ -102,7 +109,7 @@ SYMBOLS = [
     ("dqmc_exchange_action_host", C.c_int, [_P, _DP]),
     ("dqmc_set_exchange_parameter", C.c_int, [_P, C.c_double]),
     ("dqmc_profile_enable", C.c_int, [_P, C.c_int]),
-    ("dqmc_profile_read", C.c_int, [_P, _DP, C.POINTER(C.c_uint64)]),
+    ("dqmc_profile_read", C.c_int, [_P, C.POINTER(dqmc_profile)]),
     ("detsdw_create", C.c_int, [C.POINTER(detsdw_params), C.POINTER(_P)]),
     ("detsdw_destroy", None, [_P]),
     ("detsdw_last_error", C.c_char_p, []),

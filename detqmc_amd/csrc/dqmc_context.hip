@@ -23,7 +23,8 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct UdVSlot { cplx* U; double* d; cplx* Vt; };
 
-enum { FAM_BMULT = 0, FAM_GEMM = 1, FAM_JACOBI = 2, FAM_UPDATE = 3, FAM_OTHER = 4, FAM_COUNT = 8 };
+enum { FAM_BMULT = DQMC_FAM_BMULT, FAM_GEMM = DQMC_FAM_GEMM, FAM_JACOBI = DQMC_FAM_DECOMP, FAM_UPDATE = DQMC_FAM_DECIDE,
+       FAM_OTHER = DQMC_FAM_OTHER, FAM_GATHER = DQMC_FAM_GATHER, FAM_FLUSH = DQMC_FAM_FLUSH, FAM_ROUNDS = 7, FAM_COUNT = DQMC_FAM_COUNT };
 
 struct dqmc_ctx {
     dqmc_params p;
@@ -68,6 +69,7 @@ struct dqmc_ctx {
     size_t ev_used = 0;
     double fam_ms[FAM_COUNT] = {0};
     uint64_t fam_launches[FAM_COUNT] = {0};
+    double gemm_flops = 0.0;
 };
 
 template<class T>
@@ -405,6 +407,7 @@ static void gemm_dev(dqmc_ctx* c, int opA, int opB, const cplx* A, const cplx* B
     g.A = A; g.lda = c->n_g; g.opA = opA; g.B = B; g.ldb = c->n_g; g.opB = opB; g.C = C; g.ldc = c->n_g;
     g.M = g.N = g.K = c->n_g; g.Kmul = 1;
     g.kscale = kscale; g.kscale_invert = kinv; g.rowscale = rowscale; g.colscale = colscale; g.accumulate = accumulate;
+    c->gemm_flops += 8.0 * (double)g.M * g.N * g.K;
     ProfScope ps(c, FAM_GEMM, 1);
     launch_gemm(c->st, g);
 }
@@ -415,12 +418,13 @@ static void svd_prof_begin(void* u) {
     if (c->ev_used + 2 > c->ev_pool.size())
         for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
     (void)hipEventRecord(c->ev_pool[c->ev_used], c->st);
-    c->ev_open.push_back({FAM_JACOBI, (int)c->ev_used});
+    c->ev_open.push_back({FAM_ROUNDS, (int)c->ev_used});
     c->ev_used += 2;
 }
 static void svd_prof_end(void* u, int launches) {
     dqmc_ctx* c = (dqmc_ctx*)u;
     (void)hipEventRecord(c->ev_pool[c->ev_open.back().second + 1], c->st);
+    c->fam_launches[FAM_ROUNDS] += launches;
     c->fam_launches[FAM_JACOBI] += launches;
 }
 static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, UdVSlot out) {
@@ -665,15 +669,18 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     const int WD = c->MSF * c->D;
     for (int r = 0; r < rounds; ++r) {
         {
-            ProfScope ps(c, FAM_UPDATE, 2);
+            ProfScope ps(c, FAM_UPDATE, 1);
             launch_update_decide(c->st, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, thermalization);
+        }
+        {
+            ProfScope ps(c, FAM_GATHER, 1);
             launch_update_gather(c->st, c->hm, c->us, c->G, c->W, c->X, c->Gr);
         }
         GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.A = c->X; g.lda = c->n_g; g.opA = 0; g.B = c->Gr; g.ldb = WD; g.opB = 0; g.C = c->G; g.ldc = c->n_g;
         g.M = g.N = c->n_g; g.K = WD; g.Kdev = &c->us->block_j; g.Kmul = c->MSF; g.accumulate = 1;
-        ProfScope ps(c, FAM_GEMM, 1);
+        ProfScope ps(c, FAM_FLUSH, 1);
         launch_gemm(c->st, g);
     }
     return DQMC_OK;
@@ -841,14 +848,21 @@ extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
     prof_collect(c);
     c->prof = on != 0;
     for (int i = 0; i < FAM_COUNT; ++i) { c->fam_ms[i] = 0; c->fam_launches[i] = 0; }
-    c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0; c->qr_calls = 0;
+    c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0; c->qr_calls = 0; c->gemm_flops = 0.0;
     return DQMC_OK;
 }
-extern "C" int dqmc_profile_read(dqmc_ctx* c, double ms[8], uint64_t launches[8]) {
-    if (!c) return fail(DQMC_EINVAL, "null ctx");
+extern "C" int dqmc_profile_read(dqmc_ctx* c, dqmc_profile* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     prof_collect(c);
-    for (int i = 0; i < FAM_COUNT; ++i) { if (ms) ms[i] = c->fam_ms[i]; if (launches) launches[i] = c->fam_launches[i]; }
-    if (launches) { launches[5] = c->svd_calls + c->qr_calls; launches[6] = c->svd_sweeps_total; launches[7] = (uint64_t)c->svd_sweeps_max; }
+    memset(out, 0, sizeof(*out));
+    for (int i = 0; i < 7; ++i) { out->ms[i] = c->fam_ms[i]; out->launches[i] = c->fam_launches[i]; }
+    // SVD mode: the decomposition family is dominated by the rounds, which are timed batch-wise
+    if (c->stab == DQMC_STAB_SVD) out->ms[DQMC_FAM_DECOMP] = c->fam_ms[FAM_ROUNDS];
+    out->svd_calls = c->svd_calls; out->svd_sweeps_total = c->svd_sweeps_total; out->svd_sweeps_max = (uint64_t)c->svd_sweeps_max;
+    out->qr_calls = c->qr_calls;
+    out->gemm_flops = c->gemm_flops;
+    out->decomp_round_ms = c->fam_ms[FAM_ROUNDS];
+    out->decomp_rounds = c->fam_launches[FAM_ROUNDS];
     return DQMC_OK;
 }

@@ -136,11 +136,49 @@ __device__ __forceinline__ cplx small_det_inv(const cplx (&Min)[MSF][MSF], cplx 
     return det;
 }
 
+// wavefront sum by DPP row operations (total broadcast through lane 63)
+template<int CTRL, int ROWMASK>
+__device__ __forceinline__ double u_dpp_add(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+    int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double u_wave_total(double v) {
+    v = u_dpp_add<0xB1, 0xf>(v);
+    v = u_dpp_add<0x4E, 0xf>(v);
+    v = u_dpp_add<0x114, 0xf>(v);
+    v = u_dpp_add<0x118, 0xf>(v);
+    v = u_dpp_add<0x142, 0xa>(v);
+    v = u_dpp_add<0x143, 0xc>(v);
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// Everything the decision for ONE candidate site needs from global memory.  It is loaded one candidate
+// ahead (while the previous decision is being computed) so that the L2 round trip of the scattered G
+// entries and of the field values never sits on the critical path of the sequential chain.
+template<int OPDIM, int MSF, int SLOTS>
+struct Candidate {
+    double uni[OPDIM + 2];       // window: the decision before may or may not have consumed one more uniform
+    double oldphi[OPDIM];
+    double tn[OPDIM];            // phi(later slice) + phi(earlier slice)
+    double sn[OPDIM];            // sum over the four space neighbours as they were when loaded
+    double coshO, sinhO;
+    int nb_prev;                 // how many of the four neighbours are the site decided just before
+    cplx Gcc[MSF][MSF];
+    cplx Gnp[MSF][MSF];          // G[c_this rows, c_prev cols]
+    cplx Gpn[MSF][MSF];          // G[c_prev rows, c_this cols]
+    cplx pu[SLOTS], pv[SLOTS];   // this lane's share of u = G[c, I], v = G[I, c] for the I known at issue time
+};
+
 template<int OPDIM>
 __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
                                                        const cplx* __restrict__ G, cplx* __restrict__ Wout,
                                                        int k, int first, int thermal) {
     constexpr int MSF = (OPDIM == 3) ? 4 : 2;
+    constexpr int SLOTS = MSF * DQMC_MAX_WDIM / 64;
     const int N = dm.N, ng = dm.ng, D = dm.D, m = dm.m;
     const int WD = MSF * D;
     extern __shared__ cplx smem[];
@@ -169,38 +207,121 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
     const int kLater = (k < m) ? k + 1 : 1;
     const double* phiE = dm.phi + (size_t)kEarlier * OPDIM * N;
     const double* phiL = dm.phi + (size_t)kLater * OPDIM * N;
+    const double* coshK = dm.coshT + (size_t)k * N;
+    const double* sinhK = dm.sinhT + (size_t)k * N;
+
+    typedef Candidate<OPDIM, MSF, SLOTS> Cand;
+    // issue all loads for candidate `s`; `prev` = the site whose decision is still open (-1: none),
+    // `curGuess` = RNG cursor if that decision consumes no acceptance uniform, nIknown = MSF * (#accepted so far)
+    auto fetch = [&](Cand& c, int s, int prev, unsigned long long curGuess, int nIknown) {
+#pragma unroll
+        for (int d = 0; d < OPDIM + 2; ++d) {
+            unsigned long long idx = curGuess + d;
+            c.uni[d] = (idx < avail) ? uni[idx] : 0.5;
+        }
+        c.nb_prev = 0;
+#pragma unroll
+        for (int d = 0; d < OPDIM; ++d) {
+            c.oldphi[d] = phik[d * N + s];
+            c.tn[d] = phiL[d * N + s] + phiE[d * N + s];
+            double sn = 0.0;
+#pragma unroll
+            for (int dir = 0; dir < 4; ++dir) sn += phik[d * N + dm.neigh[dir * N + s]];
+            c.sn[d] = sn;
+        }
+#pragma unroll
+        for (int dir = 0; dir < 4; ++dir) c.nb_prev += (dm.neigh[dir * N + s] == prev) ? 1 : 0;
+        c.coshO = coshK[s];
+        c.sinhO = sinhK[s];
+#pragma unroll
+        for (int a = 0; a < MSF; ++a)
+#pragma unroll
+            for (int b = 0; b < MSF; ++b) {
+                c.Gcc[a][b] = G[(size_t)(s + b * N) * ng + (s + a * N)];
+                if (prev >= 0) {
+                    c.Gnp[a][b] = G[(size_t)(prev + b * N) * ng + (s + a * N)];
+                    c.Gpn[a][b] = G[(size_t)(s + b * N) * ng + (prev + a * N)];
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            int t = lane + 64 * q;
+            if (t < MSF * nIknown) {
+                int a = t / nIknown, i = t - a * nIknown;
+                int Ii = isite[i / MSF] + (i % MSF) * N;
+                c.pu[q] = G[(size_t)Ii * ng + (s + a * N)];
+                int b = t % MSF, i2 = t / MSF;
+                int Ii2 = isite[i2 / MSF] + (i2 % MSF) * N;
+                c.pv[q] = G[(size_t)(s + b * N) * ng + Ii2];
+            }
+        }
+    };
 
     int j = 0;
     const int dnow = min(D, N - site);            // delayStepsNow (:3052)
+    Cand cnd, nxt;
+    fetch(cnd, site, -1, cur, 0);
+    int cnd_nI = 0;                                // nI the u/v registers of cnd were loaded for
+    int prev_site = -1;                            // site decided in the previous iteration
+    bool prev_acc = false, prev_used_uniform = true;
+    double prev_newphi[OPDIM], prev_oldphi[OPDIM];
+#pragma unroll
+    for (int d = 0; d < OPDIM; ++d) { prev_newphi[d] = 0.0; prev_oldphi[d] = 0.0; }
+
     while (j < dnow && site < N) {
         if (cur + OPDIM + 1 > avail) { err = DQMC_ERNG; break; }
         const int nI = MSF * j;
-        // ---- G entries for this candidate (issued first: longest latency) ----
-        for (int t = lane; t < MSF * nI; t += 64) {
-            int a = t / nI, i = t - a * nI;
-            int Ii = isite[i / MSF] + (i % MSF) * N;
-            su[a * WD + i] = G[(size_t)Ii * ng + (site + a * N)];
-            int b = t % MSF, i2 = t / MSF;
-            int Ii2 = isite[i2 / MSF] + (i2 % MSF) * N;
-            sv[i2 * MSF + b] = G[(size_t)(site + b * N) * ng + Ii2];
+        // ---- land the prefetched u / v in LDS; patch in what the previous decision changed ----
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            int t = lane + 64 * q;
+            if (t < MSF * cnd_nI) {
+                int a = t / cnd_nI, i = t - a * cnd_nI;
+                su[a * WD + i] = cnd.pu[q];
+                int b = t % MSF, i2 = t / MSF;
+                sv[i2 * MSF + b] = cnd.pv[q];
+            }
         }
+        if (prev_acc && lane < MSF * MSF) {           // the site accepted last time joined I after the fetch
+            int a = lane / MSF, b = lane % MSF;
+            cplx gnp = make_double2(0.0, 0.0), gpn = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int aa = 0; aa < MSF; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < MSF; ++bb)
+                    if (aa == a && bb == b) { gnp = cnd.Gnp[aa][bb]; gpn = cnd.Gpn[aa][bb]; }
+            su[a * WD + (nI - MSF + b)] = gnp;          // u[a][i] = G[c_a, I_i], I_i = prev + b N
+            sv[(nI - MSF + a) * MSF + b] = gpn;         // v[i][b] = G[I_i, c_b], I_i = prev + a N
+        }
+        // uniforms: skip the one the previous decision consumed for its acceptance test
+        const int uoff = (prev_site >= 0 && prev_used_uniform) ? 1 : 0;
+        double oldphi[OPDIM], newphi[OPDIM], snb[OPDIM];
+#pragma unroll
+        for (int d = 0; d < OPDIM; ++d) {
+            oldphi[d] = cnd.oldphi[d];
+            double low = -phiDelta, high = phiDelta;
+            newphi[d] = propose_component(oldphi[d], low, high, uoff ? cnd.uni[d + 1] : cnd.uni[d]);
+            // a neighbour that was updated after the prefetch: replace its old value by the accepted one
+            snb[d] = cnd.sn[d];
+            if (prev_acc && cnd.nb_prev) snb[d] += (double)cnd.nb_prev * (prev_newphi[d] - prev_oldphi[d]);
+        }
+        const double uacc = uoff ? cnd.uni[OPDIM + 1] : cnd.uni[OPDIM];
         cplx Gcc[MSF][MSF];
 #pragma unroll
         for (int a = 0; a < MSF; ++a)
 #pragma unroll
-            for (int b = 0; b < MSF; ++b) Gcc[a][b] = G[(size_t)(site + b * N) * ng + (site + a * N)];
-
-        // ---- proposal, bosonic action, delta (uniform across the wave) ----
-        double oldphi[OPDIM], newphi[OPDIM];
+            for (int b = 0; b < MSF; ++b) Gcc[a][b] = cnd.Gcc[a][b];
+        const double coshO = cnd.coshO, sinhO = cnd.sinhO;
+        double tnb[OPDIM];
 #pragma unroll
-        for (int d = 0; d < OPDIM; ++d) {
-            oldphi[d] = phik[d * N + site];
-            double low = -phiDelta, high = phiDelta;
-            // randRange (rngwrapper.h:59-61); separately rounded mul and add like the CPU reference --
-            // a contracted fma would change the proposed field in the last bit
-            newphi[d] = propose_component(oldphi[d], low, high, uni[cur + d]);
-        }
+        for (int d = 0; d < OPDIM; ++d) tnb[d] = cnd.tn[d];
         cur += OPDIM;
+        __syncthreads();
+        // ---- start the loads of the NEXT candidate now; they complete while this decision is computed ----
+        const bool have_next = (site + 1 < N);
+        if (have_next) fetch(nxt, site + 1, site, cur, nI);
+
+        // ---- bosonic action (deltaSPhi, :4186-4239) and delta (get_delta_forsite, :3179-3289) ----
         double dsphi;
         {
             double oldSq = 0.0, newSq = 0.0;
@@ -215,12 +336,8 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
 #pragma unroll
                 for (int d = 0; d < OPDIM; ++d) {
                     double diff = newphi[d] - oldphi[d];
-                    double tn = phiL[d * N + site] + phiE[d * N + site];
-                    double sn = 0.0;
-#pragma unroll
-                    for (int dir = 0; dir < 4; ++dir) sn += phik[d * N + dm.neigh[dir * N + site]];
-                    dotTime += tn * diff;
-                    dotSpace += sn * diff;
+                    dotTime += tnb[d] * diff;
+                    dotSpace += snb[d] * diff;
                 }
                 double delta1 = (1.0 / (dm.c * dm.c * dm.dtau)) * (phiSqDiff - dotTime);
                 double delta2 = 0.5 * dm.dtau * (4.0 * phiSqDiff - 2.0 * dotSpace);
@@ -228,21 +345,30 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
                 dsphi = delta1 + delta2 + delta3;
             }
         }
-        const double probSPhi = exp(-dsphi);
-        double coshN, sinhN;
+        double probSPhi, coshN, sinhN;
         {
             double nn = 0.0;
 #pragma unroll
             for (int d = 0; d < OPDIM; ++d) nn += newphi[d] * newphi[d];
             double nrm = sqrt(nn);
             double arg = dm.lambda * dm.dtau * nrm;
-            coshN = cosh(arg);
-            sinhN = sinh(arg) / nrm;
+            // the wave evaluates ONE exp sequence: lane 0 on -dS, the other lanes on arg
+            double ex = exp(lane == 0 ? -dsphi : arg);
+            int lo = __builtin_amdgcn_readlane(__double2loint(ex), 0), hi = __builtin_amdgcn_readlane(__double2hiint(ex), 0);
+            probSPhi = __hiloint2double(hi, lo);
+            lo = __builtin_amdgcn_readlane(__double2loint(ex), 1); hi = __builtin_amdgcn_readlane(__double2hiint(ex), 1);
+            double ea = __hiloint2double(hi, lo), iea = 1.0 / ea;
+            coshN = 0.5 * (ea + iea);
+            // sinh(a)/|phi|: for small a the difference e^a - e^-a cancels, use the series there
+            double sh = (arg > 0.25) ? 0.5 * (ea - iea)
+                                     : arg * (1.0 + arg * arg * (1.0 / 6.0 + arg * arg * (1.0 / 120.0 + arg * arg *
+                                              (1.0 / 5040.0 + arg * arg * (1.0 / 362880.0 + arg * arg * (1.0 / 39916800.0))))));
+            sinhN = sh / nrm;
         }
         cplx delta[MSF][MSF];
         {
             cplx evOld[MSF][MSF], emvNew[MSF][MSF];
-            ev_matrix<MSF>(evOld, +1.0, oldphi, OPDIM, dm.coshT[(size_t)k * N + site], dm.sinhT[(size_t)k * N + site]);
+            ev_matrix<MSF>(evOld, +1.0, oldphi, OPDIM, coshO, sinhO);
             ev_matrix<MSF>(emvNew, -1.0, newphi, OPDIM, coshN, sinhN);
 #pragma unroll
             for (int a = 0; a < MSF; ++a)
@@ -254,13 +380,17 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
                     delta[a][b] = acc;
                 }
         }
-        __syncthreads();
         // ---- p = W v ----
         for (int t = lane; t < nI * MSF; t += 64) {
             int i = t / MSF, b = t - i * MSF;
-            cplx acc = make_double2(0.0, 0.0);
-            for (int i2 = 0; i2 < nI; ++i2) acc = u_cfma(W[i * WD + i2], sv[i2 * MSF + b], acc);
-            sp[i * MSF + b] = acc;
+            cplx acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+            const cplx* wrow = W + i * WD;
+#pragma unroll 4
+            for (int i2 = 0; i2 < nI; i2 += 2) {             // nI = MSF * j is even
+                acc0 = u_cfma(wrow[i2], sv[i2 * MSF + b], acc0);
+                acc1 = u_cfma(wrow[i2 + 1], sv[(i2 + 1) * MSF + b], acc1);
+            }
+            sp[i * MSF + b] = make_double2(acc0.x + acc1.x, acc0.y + acc1.y);
         }
         __syncthreads();
         // ---- S = Gcc + u p (lane i holds term i, wave reduce) ----
@@ -271,7 +401,7 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
             for (int b = 0; b < MSF; ++b) {
                 cplx part = make_double2(0.0, 0.0);
                 for (int i = lane; i < nI; i += 64) part = u_cfma(su[a * WD + i], sp[i * MSF + b], part);
-                S[a][b] = make_double2(Gcc[a][b].x + u_wave_sum(part.x), Gcc[a][b].y + u_wave_sum(part.y));
+                S[a][b] = make_double2(Gcc[a][b].x + u_wave_total(part.x), Gcc[a][b].y + u_wave_total(part.y));
             }
         // ---- M' = 1 + (1 - S) delta ; det ; acceptance ----
         cplx Mj[MSF][MSF], Minv[MSF][MSF];
@@ -289,7 +419,8 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
         double probSFermion = (OPDIM == 3) ? det.x : (det.x * det.x + det.y * det.y);
         double prob = probSPhi * probSFermion;
         bool accept = prob > 1.0;
-        if (!accept) { accept = uni[cur] < prob; cur += 1; }
+        bool used_uniform = false;
+        if (!accept) { accept = uacc < prob; cur += 1; used_uniform = true; }   // rand01 drawn only if prob <= 1 (:3113)
         if (accept) {
             acc_count += 1;
             if (lane == 0) {
@@ -313,9 +444,13 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
             // q = u W ; pF = p F
             for (int t = lane; t < MSF * nI; t += 64) {
                 int a = t / nI, i = t - a * nI;
-                cplx acc = make_double2(0.0, 0.0);
-                for (int i2 = 0; i2 < nI; ++i2) acc = u_cfma(su[a * WD + i2], W[i2 * WD + i], acc);
-                sq[a * WD + i] = acc;
+                cplx acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+#pragma unroll 4
+                for (int i2 = 0; i2 < nI; i2 += 2) {
+                    acc0 = u_cfma(su[a * WD + i2], W[i2 * WD + i], acc0);
+                    acc1 = u_cfma(su[a * WD + i2 + 1], W[(i2 + 1) * WD + i], acc1);
+                }
+                sq[a * WD + i] = make_double2(acc0.x + acc1.x, acc0.y + acc1.y);
             }
             for (int i = lane; i < nI; i += 64) {
 #pragma unroll
@@ -355,6 +490,14 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
             }
             j += 1;
         }
+        // hand over to the next candidate
+        prev_site = site;
+        prev_acc = accept;
+        prev_used_uniform = used_uniform;
+#pragma unroll
+        for (int d = 0; d < OPDIM; ++d) { prev_newphi[d] = newphi[d]; prev_oldphi[d] = oldphi[d]; }
+        cnd = nxt;
+        cnd_nI = nI;                               // what nxt was fetched for; the accepted site is patched in
         site += 1;
         __syncthreads();
     }

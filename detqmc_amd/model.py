@@ -222,12 +222,14 @@ class KernelContext:
         check(self.lib.dqmc_profile_enable(self.h, int(on)))
 
     def profile_read(self):
-        ms = (C.c_double * 8)()
-        ln = (C.c_uint64 * 8)()
-        check(self.lib.dqmc_profile_read(self.h, ms, ln))
-        names = ["bmult", "gemm", "jacobi", "update", "other"]
-        out = {nm: (ms[i], int(ln[i])) for i, nm in enumerate(names)}
-        out["svd_calls"], out["svd_sweeps_total"], out["svd_sweeps_max"] = int(ln[5]), int(ln[6]), int(ln[7])
+        pr = _lib.dqmc_profile()
+        check(self.lib.dqmc_profile_read(self.h, C.byref(pr)))
+        names = ["bmult", "gemm", "decomp", "decide", "other", "gather", "flush"]
+        out = {nm: (pr.ms[i], int(pr.launches[i])) for i, nm in enumerate(names)}
+        out["jacobi"] = out["decomp"]
+        out.update(svd_calls=int(pr.svd_calls), svd_sweeps_total=int(pr.svd_sweeps_total),
+                   svd_sweeps_max=int(pr.svd_sweeps_max), qr_calls=int(pr.qr_calls), gemm_flops=pr.gemm_flops,
+                   decomp_round_ms=pr.decomp_round_ms, decomp_rounds=int(pr.decomp_rounds))
         return out
 
 

@@ -155,11 +155,21 @@ int dqmc_exchange_action_host(dqmc_ctx* ctx, double* out);
 int dqmc_set_exchange_parameter(dqmc_ctx* ctx, double r);
 
 /* ---- measurement helpers for bench.py -------------------------------------------------------- */
-/* per-kernel-family device time (ms) and launch counts accumulated with HIP events on the context's
- * stream while profiling is switched on; families: 0 bmult 1 gemm 2 jacobi 3 update 4 other;
- * launches[5..7] = UdV decompositions done, Jacobi sweeps in total, most sweeps one of them took */
+/* Device time per kernel family, measured with HIP events on the context's own stream while profiling is
+ * switched on, plus launch counts and decomposition statistics. */
+enum { DQMC_FAM_BMULT = 0, DQMC_FAM_GEMM = 1, DQMC_FAM_DECOMP = 2, DQMC_FAM_DECIDE = 3, DQMC_FAM_OTHER = 4,
+       DQMC_FAM_GATHER = 5, DQMC_FAM_FLUSH = 6, DQMC_FAM_COUNT = 8 };
+typedef struct dqmc_profile {
+    double ms[8];              /* per family: bmult, gemm (fixed-size products), decomp (Jacobi rounds or QR),
+                                  decide, other, gather, flush (G += X Gr), unused */
+    uint64_t launches[8];
+    uint64_t svd_calls, svd_sweeps_total, svd_sweeps_max, qr_calls;
+    double gemm_flops;         /* 8 M N K summed over the launches of family gemm */
+    double decomp_round_ms;    /* SVD mode: time inside batches of back-to-back Jacobi rounds only */
+    uint64_t decomp_rounds;
+} dqmc_profile;
 int dqmc_profile_enable(dqmc_ctx* ctx, int on);
-int dqmc_profile_read(dqmc_ctx* ctx, double ms[8], uint64_t launches[8]);
+int dqmc_profile_read(dqmc_ctx* ctx, dqmc_profile* out);
 
 #ifdef __cplusplus
 }
