@@ -41,6 +41,29 @@ __device__ __forceinline__ double q_wave_total(double v) {
     v = q_dpp_add<0x143, 0xc>(v);
     return q_readlane_d(v, 63);
 }
+
+// Sum 32 doubles per lane across the wavefront with a value-splitting butterfly: at every level a lane keeps
+// one half of its values and trades the other half with its partner, so the traffic is 16+8+4+2+1+1 = 32
+// exchanged doubles instead of 32 x 6.  Afterwards lane l (and l ^ 32) holds the total of the value with index
+// bitreverse5(l & 31) in val[0].
+template<int H, int MASK>
+__device__ __forceinline__ void q_butterfly_level(double (&val)[32], int lane) {
+    const bool hi = (lane & MASK) != 0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        double keep = hi ? val[j + H] : val[j];
+        double send = hi ? val[j] : val[j + H];
+        val[j] = keep + __shfl_xor(send, MASK, 64);
+    }
+}
+__device__ __forceinline__ void q_wave_sum32(double (&val)[32], int lane) {
+    q_butterfly_level<16, 1>(val, lane);
+    q_butterfly_level<8, 2>(val, lane);
+    q_butterfly_level<4, 4>(val, lane);
+    q_butterfly_level<2, 8>(val, lane);
+    q_butterfly_level<1, 16>(val, lane);
+    val[0] += __shfl_xor(val[0], 32, 64);
+}
 __device__ __forceinline__ cplx q_cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // One column step of the panel factorisation (C = column index inside the panel, compile time).
@@ -102,9 +125,9 @@ struct QrPanelState {
         // the thread owning row C keeps R[C][C] = beta aside; its v entry is 1
         cplx vpiv = make_double2(1.0, 0.0);
         // ---- batched dot products: w[c'] = v^H a_c' (c' > C) and z[k] = v_k^H v_C (k < C) ----
-        double pr[QR_NB], pi[QR_NB];
+        double val[32];                     // val[2c] = Re, val[2c+1] = Im of the partial sum for column c
 #pragma unroll
-        for (int c = 0; c < QR_NB; ++c) { pr[c] = 0.0; pi[c] = 0.0; }
+        for (int c = 0; c < 32; ++c) val[c] = 0.0;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             int row = tid + r * 256;
@@ -117,29 +140,17 @@ struct QrPanelState {
                     // rows < c are R entries and do not belong to v_c.  Since row >= C > c here, a[r][c] is v_c.
                     cplx x = a[r][c];
                     if (c > C) {            // conj(v) * a
-                        pr[c] += v.x * x.x + v.y * x.y;
-                        pi[c] += v.x * x.y - v.y * x.x;
+                        val[2 * c] += v.x * x.x + v.y * x.y;
+                        val[2 * c + 1] += v.x * x.y - v.y * x.x;
                     } else {                // conj(v_c) * v
-                        pr[c] += x.x * v.x + x.y * v.y;
-                        pi[c] += x.x * v.y - x.y * v.x;
+                        val[2 * c] += x.x * v.x + x.y * v.y;
+                        val[2 * c + 1] += x.x * v.y - x.y * v.x;
                     }
                 }
             }
         }
-#pragma unroll
-        for (int c = 0; c < QR_NB; ++c) {
-            if (c == C) continue;
-            pr[c] = q_wave_total(pr[c]);
-            pi[c] = q_wave_total(pi[c]);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < QR_NB; ++c) {
-                if (c == C) continue;
-                red[1][wave][2 * c] = pr[c];
-                red[1][wave][2 * c + 1] = pi[c];
-            }
-        }
+        q_wave_sum32(val, lane);
+        if (lane < 32) red[1][wave][__brev((unsigned)lane) >> 27] = val[0];
         __syncthreads();
         cplx w[QR_NB];
 #pragma unroll
@@ -246,6 +257,86 @@ __global__ __launch_bounds__(256) void k_qr_panel(cplx* __restrict__ A, int lda,
     }
 }
 
+
+// Apply a block reflector to 16 columns of C per workgroup:  C <- (I - V op(T) V^H) C,  op(T) = T^H while
+// factoring (Q_p^H on the trailing matrix), T while forming Q.  Tn holds -T.  One launch replaces the three
+// small GEMMs (W = V^H C, W2 = -op(T) W, C += V W2); V and C are streamed through LDS in 64-row chunks.
+template<bool TRANS_T>
+__global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, int ldv, const cplx* __restrict__ Tn,
+                                                   cplx* __restrict__ C, int ldc, int rows, int ncols, int nb) {
+    __shared__ cplx sV[64][QR_NB + 1];
+    __shared__ cplx sC[64][QR_NB + 1];
+    __shared__ cplx sW[QR_NB][QR_NB + 1];      // W, then W2, as [k][j]
+    __shared__ cplx sT[QR_NB][QR_NB + 1];      // -T as [i][k]
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * QR_NB;
+    const int nc = min(QR_NB, ncols - c0);
+    {
+        int i = tid & 15, k = tid >> 4;
+        sT[i][k] = (i < nb && k < nb) ? Tn[k * QR_NB + i] : make_double2(0.0, 0.0);
+    }
+    // ---- pass 1: W[i][j] = sum_row conj(V[row,i]) C[row,j] ----
+    const int wi = tid & 15, wj = tid >> 4;
+    cplx acc = make_double2(0.0, 0.0);
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+        __syncthreads();
+        for (int idx = tid; idx < 64 * QR_NB; idx += 256) {
+            int rr = idx & 63, cc = idx >> 6;
+            int row = r0 + rr;
+            sV[rr][cc] = (row < rows && cc < nb) ? Vp[(size_t)cc * ldv + row] : make_double2(0.0, 0.0);
+            sC[rr][cc] = (row < rows && cc < nc) ? C[(size_t)(c0 + cc) * ldc + row] : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < 64; ++rr) {
+            cplx v = sV[rr][wi], x = sC[rr][wj];
+            acc.x += v.x * x.x + v.y * x.y;
+            acc.y += v.x * x.y - v.y * x.x;
+        }
+    }
+    __syncthreads();
+    sW[wi][wj] = acc;
+    __syncthreads();
+    // ---- W2 = (-T)^(H) W ----
+    {
+        cplx a2 = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < QR_NB; ++k) {
+            cplx t = TRANS_T ? make_double2(sT[k][wi].x, -sT[k][wi].y) : sT[wi][k];
+            cplx w = sW[k][wj];
+            a2.x += t.x * w.x - t.y * w.y;
+            a2.y += t.x * w.y + t.y * w.x;
+        }
+        __syncthreads();
+        sW[wi][wj] = a2;
+    }
+    __syncthreads();
+    // ---- pass 2: C[row, j] += sum_k V[row,k] W2[k][j]; thread = (row in chunk, group of 4 columns) ----
+    const int pr = tid & 63, pg = tid >> 6;
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+        int row = r0 + pr;
+        if (row >= rows) continue;
+        cplx v[QR_NB];
+#pragma unroll
+        for (int k = 0; k < QR_NB; ++k) v[k] = (k < nb) ? Vp[(size_t)k * ldv + row] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            int j = pg * 4 + jj;
+            if (j < nc) {
+                size_t off = (size_t)(c0 + j) * ldc + row;
+                cplx c = C[off];
+#pragma unroll
+                for (int k = 0; k < QR_NB; ++k) {
+                    cplx w = sW[k][j];
+                    c.x += v[k].x * w.x - v[k].y * w.y;
+                    c.y += v[k].x * w.y + v[k].y * w.x;
+                }
+                C[off] = c;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // driver: A (n x n, ld n) -> R in place (strict lower part zeroed), Q explicit; V/T workspace
 // ---------------------------------------------------------------------------------------------
@@ -284,11 +375,9 @@ int run_qr(hipStream_t st, int n, cplx* A, cplx* Q, const QrWork& w) {
         if (ntrail > 0) {
             const cplx* Vp = w.V + (size_t)j0 * n + j0;
             cplx* C = A + (size_t)(j0 + nb) * n + j0;
-            // W = V^H C ; W2 = (-T)^H W ; C += V W2        (apply Q_p^H = I - V T^H V^H)
-            gemm_small(st, 1, 0, Vp, n, C, n, w.W, QR_NB, nb, ntrail, rows, 0);
-            gemm_small(st, 1, 0, Tn, QR_NB, w.W, QR_NB, w.W2, QR_NB, nb, ntrail, nb, 0);
-            gemm_small(st, 0, 0, Vp, n, w.W2, QR_NB, C, n, rows, ntrail, nb, 1);
-            launches += 3;
+            // apply Q_p^H = I - V T^H V^H to the trailing columns
+            hipLaunchKernelGGL((k_qr_apply<true>), dim3((ntrail + QR_NB - 1) / QR_NB), dim3(256), 0, st, Vp, n, Tn, C, n, rows, ntrail, nb);
+            launches += 1;
         }
     }
     // ---- Q = H_0 H_1 ... applied to the identity, block reflectors in reverse order (zungqr) ----
@@ -301,11 +390,9 @@ int run_qr(hipStream_t st, int n, cplx* A, cplx* Q, const QrWork& w) {
         const cplx* Vp = w.V + (size_t)j0 * n + j0;
         const cplx* Tn = w.T + (size_t)p * 2 * QR_NB * QR_NB + QR_NB * QR_NB;
         cplx* C = Q + (size_t)j0 * n + j0;
-        // C <- (I - V T V^H) C :  W = V^H C ; W2 = (-T) W ; C += V W2
-        gemm_small(st, 1, 0, Vp, n, C, n, w.W, QR_NB, nb, ncols, rows, 0);
-        gemm_small(st, 0, 0, Tn, QR_NB, w.W, QR_NB, w.W2, QR_NB, nb, ncols, nb, 0);
-        gemm_small(st, 0, 0, Vp, n, w.W2, QR_NB, C, n, rows, ncols, nb, 1);
-        launches += 3;
+        // C <- (I - V T V^H) C
+        hipLaunchKernelGGL((k_qr_apply<false>), dim3((ncols + QR_NB - 1) / QR_NB), dim3(256), 0, st, Vp, n, Tn, C, n, rows, ncols, nb);
+        launches += 1;
     }
     return launches;
 }

@@ -554,6 +554,13 @@ void launch_update_decide(hipStream_t st, const DevModel* /*dm*/, const DevModel
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal) {
     const int WD = hm.MSF * hm.D;
     size_t lds = ((size_t)WD * WD + 5 * (size_t)hm.MSF * WD) * sizeof(cplx);
+    if (lds > 65536) {     // O(3) with deep delay blocks: raise the dynamic LDS limit once
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void*)k_update_decide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
     if (hm.opdim == 1)
         hipLaunchKernelGGL((k_update_decide<1>), dim3(1), dim3(64), lds, st, hm, us, uniforms, G, W, k, first, thermal);
     else if (hm.opdim == 2)
@@ -563,30 +570,46 @@ void launch_update_decide(hipStream_t st, const DevModel* /*dm*/, const DevModel
 }
 
 // X[:, i'] = sum_i G[:, I_i] W[i, i']   (n_g x nI, ld n_g);   Gr[i, :] = G[I_i, :] - E   (nI x n_g, ld WD)
+// One workgroup per 64 rows (of X) / 64 columns (of Gr).  The 64 x nI slab of G[:, I] is staged in LDS once
+// (coalesced along the rows) and every thread forms its X entries from LDS.
 __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpdateState* __restrict__ us,
                                                         const cplx* __restrict__ G, const cplx* __restrict__ Wg,
                                                         cplx* __restrict__ X, cplx* __restrict__ Gr) {
-    extern __shared__ cplx sW[];      // column-major [WD][nI] as stored by the decision kernel
+    extern __shared__ cplx sdyn[];      // sW: [nI cols][WD] as stored by the decision kernel, then sG: [nI][65]
     const int j = us->block_j;
     if (j <= 0) return;
     const int MSF = dm.MSF, N = dm.N, ng = dm.ng, WD = MSF * dm.D;
     const int nI = MSF * j;
+    cplx* sW = sdyn;
+    cplx* sG = sdyn + (size_t)WD * WD;
     __shared__ int sI[DQMC_MAX_WDIM];
     for (int t = threadIdx.x; t < nI; t += 256) sI[t] = us->block_sites[t / MSF] + (t % MSF) * N;
     for (int t = threadIdx.x; t < nI * WD; t += 256) sW[t] = Wg[t];
     __syncthreads();
-    const int r = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sub = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 64;
+    const int lr = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int r = r0 + lr;
+    for (int i = sub; i < nI; i += 4) {
+        cplx g = make_double2(0.0, 0.0);
+        if (r < ng) {
+            g = G[(size_t)sI[i] * ng + r];                 // G[r, I_i]: coalesced along r
+            cplx h = G[(size_t)r * ng + sI[i]];            // G[I_i, r]
+            if (r == sI[i]) h.x -= 1.0;
+            Gr[(size_t)r * WD + i] = h;
+        }
+        sG[i * 65 + lr] = g;
+    }
+    __syncthreads();
     if (r < ng) {
         for (int i2 = sub; i2 < nI; i2 += 4) {
-            cplx acc = make_double2(0.0, 0.0);
-            for (int i = 0; i < nI; ++i) acc = u_cfma(G[(size_t)sI[i] * ng + r], sW[(size_t)i2 * WD + i], acc);
-            X[(size_t)i2 * ng + r] = acc;
-        }
-        for (int i = sub; i < nI; i += 4) {
-            cplx g = G[(size_t)r * ng + sI[i]];
-            if (r == sI[i]) g.x -= 1.0;
-            Gr[(size_t)r * WD + i] = g;
+            cplx acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+            const cplx* wcol = sW + (size_t)i2 * WD;
+#pragma unroll 4
+            for (int i = 0; i < nI; i += 2) {              // nI is even
+                acc0 = u_cfma(sG[i * 65 + lr], wcol[i], acc0);
+                acc1 = u_cfma(sG[(i + 1) * 65 + lr], wcol[i + 1], acc1);
+            }
+            X[(size_t)i2 * ng + r] = make_double2(acc0.x + acc1.x, acc0.y + acc1.y);
         }
     }
 }
@@ -594,6 +617,13 @@ __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpd
 void launch_update_gather(hipStream_t st, const DevModel& hm, const DevUpdateState* us, const cplx* G,
                           const cplx* W, cplx* X, cplx* Gr) {
     const int WD = hm.MSF * hm.D;
-    size_t lds = (size_t)WD * WD * sizeof(cplx);
+    size_t lds = ((size_t)WD * WD + (size_t)WD * 65) * sizeof(cplx);
+    if (lds > 65536) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void*)k_update_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
     hipLaunchKernelGGL(k_update_gather, dim3((hm.ng + 63) / 64), dim3(256), lds, st, hm, us, G, W, X, Gr);
 }
