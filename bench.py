@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=16, r=-1.0, c=3.0, u=1.0, lambda_=1.0,
+WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=int(os.environ.get("DQMC_DELAY_STEPS", "16")), r=-1.0, c=3.0, u=1.0, lambda_=1.0,
                 mu=-0.5, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, bc="pbc", accRatio=0.5,
                 rngSeed=1020304050,
                 # same Green's functions and Markov chain as the reference-exact "svd" mode (tests), ~10x cheaper
