@@ -31,6 +31,7 @@ WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=int(os.envi
                 stabilisation=os.environ.get("DQMC_STABILISATION", "qr"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
+DEFAULT_THREADS = 1
 DEFAULT_REPLICAS = 4           # chains per GPU; a Jacobi round occupies 64 of the 256 CUs
 
 
@@ -65,30 +66,56 @@ def cpu_baseline(max_seconds=200):
 
 
 def worker(a):
-    """One chain in its own process (own HIP runtime / queues): build, warm up, wait for GO, run, report."""
+    """a.threads chains in one process (own HIP runtime / queues), one host thread and one stream per chain:
+    build, warm up, wait for GO, run, report."""
+    import threading
     from detqmc_amd import DetSDW, SDWParams
-    rep = DetSDW(SDWParams(device=a.device, simindex=a.simindex, **WORKLOAD))
-    ctx = rep.kernel_context
-    for _ in range(a.warmup):
-        rep.sweepThermalization()
+    T = max(1, a.threads)
+    reps = [DetSDW(SDWParams(device=a.device, simindex=a.simindex * T + i, **WORKLOAD)) for i in range(T)]
+    ctxs = [r.kernel_context for r in reps]
+
+    def run_all(nsweeps):
+        if T == 1:
+            for _ in range(nsweeps):
+                reps[0].sweepThermalization()
+            return
+        errs = []
+
+        def work(r):
+            try:
+                for _ in range(nsweeps):
+                    r.sweepThermalization()          # one C call per sweep: the GIL is released inside
+            except Exception as e:
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(r,)) for r in reps]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    run_all(a.warmup)
     if a.profile:
-        ctx.profile_enable(True)
-    ctx.synchronize()
+        ctxs[0].profile_enable(True)
+    for c in ctxs:
+        c.synchronize()
     print("READY", flush=True)
     if sys.stdin.readline().strip() != "GO":
         return
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        rep.sweepThermalization()
-    ctx.synchronize()
+    run_all(a.steps)
+    for c in ctxs:
+        c.synchronize()
     dt = time.perf_counter() - t0
-    info = rep.info
+    info = reps[0].info
     out = {"dt": dt, "n_g": info.n_g, "m": info.m, "acceptance": info.lastAccRatioLocal_phi}
     if a.profile:
-        prof = ctx.profile_read()
+        prof = ctxs[0].profile_read()
         out["prof"] = {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}
     print("RESULT " + json.dumps(out), flush=True)
-    rep.close()
+    for r in reps:
+        r.close()
 
 
 def main():
@@ -99,6 +126,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", type=int, default=int(os.environ.get("DQMC_REPLICAS_PER_GPU", str(DEFAULT_REPLICAS))),
                     help="independent Markov chains per GPU, one worker process each")
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("DQMC_CHAINS_PER_WORKER", str(DEFAULT_THREADS))),
+                    help="chains per worker process (host threads)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--simindex", type=int, default=0, help=argparse.SUPPRESS)
@@ -134,7 +163,7 @@ def main():
     procs = []
     for i in range(R):
         cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--device", str(local), "--simindex",
-               str(rank * R + i), "--steps", str(a.steps), "--warmup", str(a.warmup)] + (["--profile"] if i == 0 else [])
+               str(rank * R + i), "--steps", str(a.steps), "--warmup", str(a.warmup), "--threads", str(a.threads)] + (["--profile"] if i == 0 else [])
         procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env))
 
     def read_tag(p, tag):
@@ -212,7 +241,7 @@ def main():
         roofs.sort(key=lambda r: -r["device_ms"])
         res = {
             "metric": "DQMC sweeps/sec (SDW-O2 L=16 beta=10 fp64)",
-            "value": world * R * a.steps / dt,
+            "value": world * R * a.threads * a.steps / dt,
             "unit": "sweeps/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -225,9 +254,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic (random initial field, fixed seed)",
             "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(16) "
-                                   "sweepThermalization, %d independent chains per GPU (one process each), stabilisation=%s"
-                                   % (R, WORKLOAD["stabilisation"]),
-                       "n_g": n, "m": r0["m"], "replicas_per_gpu": R},
+                                   "sweepThermalization, %d independent chains per GPU (%d worker processes x %d threads), stabilisation=%s"
+                                   % (R * a.threads, R, a.threads, WORKLOAD["stabilisation"]),
+                       "n_g": n, "m": r0["m"], "replicas_per_gpu": R * a.threads, "worker_processes_per_gpu": R,
+                       "chains_per_worker": a.threads},
             "roofline": roofs[0],
             "roofline_other_kernels": roofs[1:],
             "device_ms_by_family_chain0": fam,

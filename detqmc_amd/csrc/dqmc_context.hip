@@ -5,6 +5,7 @@
 #include <complex>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -258,6 +259,7 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     memset(&hm, 0, sizeof(hm));
     hm.opdim = p->opdim; hm.MSF = MSF; hm.L = p->L; hm.N = N; hm.ng = ng; hm.m = p->m; hm.s = p->s; hm.n = c->n;
     hm.D = p->delaySteps; hm.P = N / 4; hm.phi2bosons = p->phi2bosons;
+    hm.dbg = getenv("DQMC_DBG") ? atoi(getenv("DQMC_DBG")) : 0;
     hm.dtau = p->dtau; hm.r = p->r; hm.c = p->c; hm.u = p->u; hm.lambda = p->lambda;
     hm.ov[0] = std::exp(p->dtau * p->mux); hm.ov[1] = std::exp(p->dtau * p->muy);
     hm.ovinv[0] = std::exp(-p->dtau * p->mux); hm.ovinv[1] = std::exp(-p->dtau * p->muy);

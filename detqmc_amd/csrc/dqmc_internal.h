@@ -14,6 +14,7 @@ typedef double2 cplx;   // .x = re, .y = im; same bytes as dqmc_cplx / std::comp
 struct DevModel {
     int opdim, MSF, L, N, ng, m, s, n, D, P;   // P = plaquettes per subgroup = N/4
     int phi2bosons;
+    int dbg;           // developer timing experiments only (DQMC_DBG env var); 0 in production
     double dtau, r, c, u, lambda;
     double ov[2];      // e^{+dtau mu_band}   (detsdwopdim.cpp:2037-2038)
     double ovinv[2];   // e^{-dtau mu_band}   (detsdwopdim.cpp:2137-2138)

@@ -174,7 +174,7 @@ struct Candidate {
 };
 
 template<int OPDIM>
-__global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
+__global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
                                                        const cplx* __restrict__ G, cplx* __restrict__ Wout,
                                                        int k, int first, int thermal) {
     constexpr int MSF = (OPDIM == 3) ? 4 : 2;
@@ -189,13 +189,14 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
     cplx* sq = sp + WD * MSF;             // q = u W                     [MSF][WD]
     cplx* spf = sq + MSF * WD;            // p F                         [WD][MSF]
     __shared__ int isite[DQMC_MAX_WDIM];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;          // 4 waves: scalar Metropolis arithmetic is done redundantly by every
+    const int lane = tid & 63;            // wave, the vector parts (p, q, W update) are split over all 256 threads
 
     int site = first ? 0 : us->site_cursor;
     int acc_count = first ? 0 : us->acc_count;
     int done = first ? 0 : us->slice_done;
     if (done || site >= N) {
-        if (lane == 0) { us->block_j = 0; if (first) { us->site_cursor = site; us->acc_count = 0; us->slice_done = done; } }
+        if (tid == 0) { us->block_j = 0; if (first) { us->site_cursor = site; us->acc_count = 0; us->slice_done = done; } }
         return;
     }
     unsigned long long cur = us->pub.rng_consumed;
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
             }
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
-            int t = lane + 64 * q;
-            if (t < MSF * nIknown) {
+            int t = tid + 64 * q;
+            if (tid < 64 && t < MSF * nIknown) {
                 int a = t / nIknown, i = t - a * nIknown;
                 int Ii = isite[i / MSF] + (i % MSF) * N;
                 c.pu[q] = G[(size_t)Ii * ng + (s + a * N)];
@@ -274,16 +275,16 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
         // ---- land the prefetched u / v in LDS; patch in what the previous decision changed ----
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
-            int t = lane + 64 * q;
-            if (t < MSF * cnd_nI) {
+            int t = tid + 64 * q;
+            if (tid < 64 && t < MSF * cnd_nI) {
                 int a = t / cnd_nI, i = t - a * cnd_nI;
                 su[a * WD + i] = cnd.pu[q];
                 int b = t % MSF, i2 = t / MSF;
                 sv[i2 * MSF + b] = cnd.pv[q];
             }
         }
-        if (prev_acc && lane < MSF * MSF) {           // the site accepted last time joined I after the fetch
-            int a = lane / MSF, b = lane % MSF;
+        if (prev_acc && tid < MSF * MSF) {            // the site accepted last time joined I after the fetch
+            int a = tid / MSF, b = tid % MSF;
             cplx gnp = make_double2(0.0, 0.0), gpn = make_double2(0.0, 0.0);
 #pragma unroll
             for (int aa = 0; aa < MSF; ++aa)
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
         __syncthreads();
         // ---- start the loads of the NEXT candidate now; they complete while this decision is computed ----
         const bool have_next = (site + 1 < N);
-        if (have_next) fetch(nxt, site + 1, site, cur, nI);
+        if (have_next && !(dm.dbg & 1)) fetch(nxt, site + 1, site, cur, nI);
 
         // ---- bosonic action (deltaSPhi, :4186-4239) and delta (get_delta_forsite, :3179-3289) ----
         double dsphi;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
             double nrm = sqrt(nn);
             double arg = dm.lambda * dm.dtau * nrm;
             // the wave evaluates ONE exp sequence: lane 0 on -dS, the other lanes on arg
-            double ex = exp(lane == 0 ? -dsphi : arg);
+            double ex = (dm.dbg & 4) ? 1.0 + (lane == 0 ? -dsphi : arg) : exp(lane == 0 ? -dsphi : arg);
             int lo = __builtin_amdgcn_readlane(__double2loint(ex), 0), hi = __builtin_amdgcn_readlane(__double2hiint(ex), 0);
             probSPhi = __hiloint2double(hi, lo);
             lo = __builtin_amdgcn_readlane(__double2loint(ex), 1); hi = __builtin_amdgcn_readlane(__double2hiint(ex), 1);
@@ -380,17 +381,16 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
                     delta[a][b] = acc;
                 }
         }
-        // ---- p = W v ----
-        for (int t = lane; t < nI * MSF; t += 64) {
-            int i = t / MSF, b = t - i * MSF;
-            cplx acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+        // ---- p = W v: item = (i, b), each dot product split over a quad of lanes ----
+        for (int t = tid; t < ((dm.dbg & 2) ? 0 : 4 * nI * MSF); t += 256) {
+            int item = t >> 2, part = t & 3;
+            int i = item / MSF, b = item - i * MSF;
+            cplx acc = make_double2(0.0, 0.0);
             const cplx* wrow = W + i * WD;
-#pragma unroll 4
-            for (int i2 = 0; i2 < nI; i2 += 2) {             // nI = MSF * j is even
-                acc0 = u_cfma(wrow[i2], sv[i2 * MSF + b], acc0);
-                acc1 = u_cfma(wrow[i2 + 1], sv[(i2 + 1) * MSF + b], acc1);
-            }
-            sp[i * MSF + b] = make_double2(acc0.x + acc1.x, acc0.y + acc1.y);
+            for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(wrow[i2], sv[i2 * MSF + b], acc);
+            acc.x = u_dpp_add<0xB1, 0xf>(acc.x); acc.y = u_dpp_add<0xB1, 0xf>(acc.y);     // quad sum
+            acc.x = u_dpp_add<0x4E, 0xf>(acc.x); acc.y = u_dpp_add<0x4E, 0xf>(acc.y);
+            if (part == 0) sp[i * MSF + b] = acc;
         }
         __syncthreads();
         // ---- S = Gcc + u p (lane i holds term i, wave reduce) ----
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
         if (!accept) { accept = uacc < prob; cur += 1; used_uniform = true; }   // rand01 drawn only if prob <= 1 (:3113)
         if (accept) {
             acc_count += 1;
-            if (lane == 0) {
+            if (tid == 0) {
 #pragma unroll
                 for (int d = 0; d < OPDIM; ++d) phik[d * N + site] = newphi[d];
                 dm.coshT[(size_t)k * N + site] = coshN;
@@ -441,18 +441,17 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
                     for (int q = 0; q < MSF; ++q) acc = u_cfma(delta[a][q], Minv[q][b], acc);
                     F[a][b] = acc;
                 }
-            // q = u W ; pF = p F
-            for (int t = lane; t < MSF * nI; t += 64) {
-                int a = t / nI, i = t - a * nI;
-                cplx acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
-#pragma unroll 4
-                for (int i2 = 0; i2 < nI; i2 += 2) {
-                    acc0 = u_cfma(su[a * WD + i2], W[i2 * WD + i], acc0);
-                    acc1 = u_cfma(su[a * WD + i2 + 1], W[(i2 + 1) * WD + i], acc1);
-                }
-                sq[a * WD + i] = make_double2(acc0.x + acc1.x, acc0.y + acc1.y);
+            // q = u W (quad-split dot products) ; pF = p F
+            for (int t = tid; t < ((dm.dbg & 2) ? 0 : 4 * MSF * nI); t += 256) {
+                int item = t >> 2, part = t & 3;
+                int a = item / nI, i = item - a * nI;
+                cplx acc = make_double2(0.0, 0.0);
+                for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(su[a * WD + i2], W[i2 * WD + i], acc);
+                acc.x = u_dpp_add<0xB1, 0xf>(acc.x); acc.y = u_dpp_add<0xB1, 0xf>(acc.y);
+                acc.x = u_dpp_add<0x4E, 0xf>(acc.x); acc.y = u_dpp_add<0x4E, 0xf>(acc.y);
+                if (part == 0) sq[a * WD + i] = acc;
             }
-            for (int i = lane; i < nI; i += 64) {
+            for (int i = tid; i < nI; i += 256) {
 #pragma unroll
                 for (int b = 0; b < MSF; ++b) {
                     cplx acc2 = make_double2(0.0, 0.0);
@@ -463,7 +462,7 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
             }
             __syncthreads();
             // W11 += pF q
-            for (int t = lane; t < nI * nI; t += 64) {
+            for (int t = tid; t < ((dm.dbg & 2) ? 0 : nI * nI); t += 256) {
                 int i = t / nI, i2 = t - i * nI;
                 cplx acc = W[i * WD + i2];
 #pragma unroll
@@ -471,7 +470,7 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
                 W[i * WD + i2] = acc;
             }
             // W12 = pF ; W21 = F q
-            for (int i = lane; i < nI; i += 64) {
+            for (int i = tid; i < nI; i += 256) {
 #pragma unroll
                 for (int b = 0; b < MSF; ++b) {
                     W[i * WD + (nI + b)] = spf[i * MSF + b];
@@ -482,7 +481,7 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
                 }
             }
             // W22 = F
-            if (lane == 0) {
+            if (tid == 0) {
 #pragma unroll
                 for (int a = 0; a < MSF; ++a)
 #pragma unroll
@@ -504,11 +503,11 @@ __global__ __launch_bounds__(64) void k_update_decide(DevModel dm, DevUpdateStat
 
     // ---- publish block result ----
     const int nI = MSF * j;
-    for (int t = lane; t < nI * nI; t += 64) {
+    for (int t = tid; t < nI * nI; t += 256) {
         int i = t / nI, i2 = t - i * nI;
         Wout[(size_t)i2 * WD + i] = W[i * WD + i2];        // column-major, ld = WD
     }
-    if (lane == 0) {
+    if (tid == 0) {
         us->site_cursor = site;
         us->acc_count = acc_count;
         us->block_j = j;
@@ -562,11 +561,11 @@ void launch_update_decide(hipStream_t st, const DevModel* /*dm*/, const DevModel
         }
     }
     if (hm.opdim == 1)
-        hipLaunchKernelGGL((k_update_decide<1>), dim3(1), dim3(64), lds, st, hm, us, uniforms, G, W, k, first, thermal);
+        hipLaunchKernelGGL((k_update_decide<1>), dim3(1), dim3(256), lds, st, hm, us, uniforms, G, W, k, first, thermal);
     else if (hm.opdim == 2)
-        hipLaunchKernelGGL((k_update_decide<2>), dim3(1), dim3(64), lds, st, hm, us, uniforms, G, W, k, first, thermal);
+        hipLaunchKernelGGL((k_update_decide<2>), dim3(1), dim3(256), lds, st, hm, us, uniforms, G, W, k, first, thermal);
     else
-        hipLaunchKernelGGL((k_update_decide<3>), dim3(1), dim3(64), lds, st, hm, us, uniforms, G, W, k, first, thermal);
+        hipLaunchKernelGGL((k_update_decide<3>), dim3(1), dim3(256), lds, st, hm, us, uniforms, G, W, k, first, thermal);
 }
 
 // X[:, i'] = sum_i G[:, I_i] W[i, i']   (n_g x nI, ld n_g);   Gr[i, :] = G[I_i, :] - E   (nI x n_g, ld WD)
