@@ -38,6 +38,11 @@ CASES = {
     "o2_L8_b5": dict(args=dict(opdim=2, L=8, beta=5, s=10, delaySteps=16, sweeps=2),
                      drop=("bchain_", "bdense", "bmult_leftinv", "bmult_rightinv", "slice_g_wrapped",
                            "init_coshTermPhi", "init_sinhTermPhi")),
+    # BASELINE config 4 temperature (beta = 20) at a size whose matrices still fit a fixture
+    "o2_L8_b20": dict(args=dict(opdim=2, L=8, beta=20, s=10, delaySteps=16, sweeps=2, sliceTrace=0),
+                      drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi"), subsample=4),
+    "o3_L6": dict(args=dict(opdim=3, L=6, beta=3, s=10, delaySteps=12, sweeps=2, sliceTrace=0),
+                  drop=("bchain_", "bdense", "bmult_leftinv", "bmult_rightinv", "init_coshTermPhi", "init_sinhTermPhi"), subsample=4),
     # BASELINE config 3 (headline): checksums / subsamples only
     "o2_L16_b10": dict(args=dict(opdim=2, L=16, beta=10, s=10, delaySteps=16, sweeps=2, sliceTrace=0),
                        drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi"),

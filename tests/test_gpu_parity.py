@@ -437,3 +437,30 @@ def test_qr_mode_headline_size_vs_reference_checksums():
         assert relerr(np.diag(G), g[f"sweep{i}_g_diag"]) < TOL
         assert abs(np.linalg.norm(G) - g[f"sweep{i}_g_fro"][0]) < TOL * g[f"sweep{i}_g_fro"][0]
     rep.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# colder (beta = 20, BASELINE config 4's temperature) and larger O(3) cases, both stabilisation modes
+# ------------------------------------------------------------------------------------------------
+def _check_subsampled(G, g, tag, ss):
+    assert relerr(G[::ss, ::ss], g[f"{tag}_g_sub{ss}"]) < TOL
+    assert relerr(np.diag(G), g[f"{tag}_g_diag"]) < TOL
+    assert abs(np.linalg.norm(G) - g[f"{tag}_g_fro"][0]) < TOL * g[f"{tag}_g_fro"][0]
+
+
+@pytest.mark.parametrize("stab", ["svd", "qr"])
+@pytest.mark.parametrize("name", ["o2_L8_b20", "o3_L6"])
+def test_cold_and_large_o3_trajectories_vs_reference(name, stab):
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    rep = DetSDW(_sdw_params(g["params"], stabilisation=stab))
+    _check_subsampled(rep.g, g, "init", 4)
+    assert abs(np.sum(np.log(rep.g_inv_sv)) - np.sum(np.log(g["init_g_inv_sv"]))) < 1e-9 * rep.info.n_g
+    for i in (1, 2):
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}"
+        _check_subsampled(rep.g, g, f"sweep{i}", 4)
+        assert abs(np.sum(np.log(rep.g_inv_sv)) - np.sum(np.log(g[f"sweep{i}_g_inv_sv"]))) < 1e-9 * rep.info.n_g
+    nxt = np.array([rep.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"])
+    rep.close()

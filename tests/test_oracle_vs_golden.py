@@ -138,3 +138,16 @@ def test_headline_size_checksums():
     assert relerr(np.diag(o.g), g["sweep1_g_diag"]) < TOL
     assert relerr(o.g_inv_sv, g["sweep1_g_inv_sv"]) < TOL
     print("oracle L=16: init + 1 sweep in %.1f s" % (time.time() - t0))
+
+
+@pytest.mark.parametrize("name", ["o2_L8_b20", "o3_L6"])
+def test_cold_and_large_o3_cases(name):
+    g = load_golden(name)
+    o = DetSDWOracle(oracle_params(g["params"]))
+    assert relerr(o.g[::4, ::4], g["init_g_sub4"]) < TOL
+    assert relerr(np.diag(o.g), g["init_g_diag"]) < TOL
+    o.sweepThermalization()
+    phi_ref = np.transpose(g["sweep1_phi"], (2, 0, 1))
+    assert np.array_equal(o.phi[1:], phi_ref[1:])
+    assert relerr(o.g[::4, ::4], g["sweep1_g_sub4"]) < TOL
+    assert relerr(o.g_inv_sv, g["sweep1_g_inv_sv"]) < TOL
