@@ -26,6 +26,7 @@ class dqmc_params(C.Structure):
     _fields_ = [("opdim", C.c_int32), ("L", C.c_int32), ("m", C.c_int32), ("s", C.c_int32),
                 ("delaySteps", C.c_int32), ("bc", C.c_int32), ("weakZflux", C.c_int32),
                 ("phi2bosons", C.c_int32), ("device", C.c_int32), ("stabilisation", C.c_int32),
+                ("cb_none", C.c_int32), ("reserved", C.c_int32),
                 ("dtau", C.c_double), ("r", C.c_double), ("c", C.c_double), ("u", C.c_double),
                 ("lambda_", C.c_double),
                 ("txhor", C.c_double), ("txver", C.c_double), ("tyhor", C.c_double), ("tyver", C.c_double),
@@ -58,7 +59,7 @@ class detsdw_params(C.Structure):
                 ("txhor", C.c_double), ("txver", C.c_double), ("tyhor", C.c_double), ("tyver", C.c_double),
                 ("mu", C.c_double), ("mux", C.c_double), ("muy", C.c_double),
                 ("accRatio", C.c_double), ("cdwU", C.c_double),
-                ("stabilisation", C.c_int32), ("reserved2", C.c_int32)]
+                ("stabilisation", C.c_int32), ("cb_none", C.c_int32)]
 
 
 class detsdw_info(C.Structure):

@@ -42,6 +42,7 @@ struct dqmc_ctx {
     std::vector<UdVSlot> storage, storage_bak;
     UdVSlot spare{}, tmpudv{};
     cplx *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *T4 = nullptr;
+    cplx *propK[2] = {nullptr, nullptr}, *Tdense = nullptr;   // CB_NONE only: blockdiag e^{-+dtau K} (n_g x n_g), GEMM target
     SvdWork sw{};
     int stab = 0;                       // DQMC_STAB_SVD / DQMC_STAB_QR
     QrWork qw{};
@@ -214,6 +215,93 @@ static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::ve
     }
 }
 
+// CB_NONE (checkerboard = false): dense hopping propagators.  setupPropK (detsdwopdim.cpp:1210-1285)
+// builds K_band = -mu_band 1 - sum_<ij> t_ij (APBC signs, Peierls phases of zmag[XUP] = zmag[YDOWN]);
+// computePropagator (detmodel.cpp:31-39) exponentiates it through eig_sym.  Here: cyclic Jacobi on
+// the host (set-up only), out[signIdx] = blockdiag_b(e^{-+dtau K_band(b)}), n_g x n_g column-major.  As in
+// computeBmatSDW (:1324-1474) every block b uses propK[b & 1], also the lower O(3) blocks.
+static void herm_exp_dense(int n, std::vector<hc>& A, double pref_minus, double pref_plus,
+                           std::vector<hc>& Eminus, std::vector<hc>& Eplus) {
+    std::vector<hc> V((size_t)n * n, hc(0.0));            // row-major helpers: A[i*n+j]
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    double total = 0.0;
+    for (auto& a : A) total += std::norm(a);
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += std::norm(A[(size_t)p * n + q]);
+        if (off <= 1e-32 * total) break;
+        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) {
+            double apq = std::abs(A[(size_t)p * n + q]);
+            if (apq < 1e-300) continue;
+            hc ph = A[(size_t)p * n + q] / apq;
+            double app = A[(size_t)p * n + p].real(), aqq = A[(size_t)q * n + q].real();
+            double zeta = (aqq - app) / (2.0 * apq);
+            double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+            double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+            const hc cph = std::conj(ph);
+            for (int k = 0; k < n; ++k) {                 // A <- A J, V <- V J
+                hc akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                A[(size_t)k * n + p] = cs * akp - sn * cph * akq;
+                A[(size_t)k * n + q] = sn * akp + cs * cph * akq;
+                hc vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+                V[(size_t)k * n + p] = cs * vkp - sn * cph * vkq;
+                V[(size_t)k * n + q] = sn * vkp + cs * cph * vkq;
+            }
+            for (int k = 0; k < n; ++k) {                 // A <- J^H A
+                hc apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                A[(size_t)p * n + k] = cs * apk - sn * ph * aqk;
+                A[(size_t)q * n + k] = sn * apk + cs * ph * aqk;
+            }
+        }
+    }
+    Eminus.assign((size_t)n * n, hc(0.0)); Eplus.assign((size_t)n * n, hc(0.0));
+    std::vector<double> em(n), ep(n);
+    for (int k = 0; k < n; ++k) { double ev = A[(size_t)k * n + k].real(); em[k] = std::exp(pref_minus * ev); ep[k] = std::exp(pref_plus * ev); }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+        hc a = 0.0, b = 0.0;
+        for (int k = 0; k < n; ++k) {
+            hc vv = V[(size_t)i * n + k] * std::conj(V[(size_t)j * n + k]);
+            a += vv * em[k]; b += vv * ep[k];
+        }
+        Eminus[(size_t)i * n + j] = a; Eplus[(size_t)i * n + j] = b;
+    }
+}
+
+static void build_dense_propK(const dqmc_params& p, const std::vector<int>& neigh, int MSF,
+                              std::vector<hc>& out_minus, std::vector<hc>& out_plus) {
+    const int L = p.L, N = L * L, ng = MSF * N;
+    const double hopHor[2] = {p.txhor, p.tyhor}, hopVer[2] = {p.txver, p.tyver}, mu[2] = {p.mux, p.muy};
+    const bool apbc_x = (p.bc == DQMC_BC_APBC_X || p.bc == DQMC_BC_APBC_XY);
+    const bool apbc_y = (p.bc == DQMC_BC_APBC_Y || p.bc == DQMC_BC_APBC_XY);
+    const double zmag = p.weakZflux ? 1.0 / N : 0.0, pi = M_PI;
+    out_minus.assign((size_t)ng * ng, hc(0.0)); out_plus.assign((size_t)ng * ng, hc(0.0));
+    for (int band = 0; band < 2; ++band) {
+        std::vector<hc> K((size_t)N * N, hc(0.0));
+        for (int i = 0; i < N; ++i) K[(size_t)i * N + i] = -mu[band];
+        for (int site = 0; site < N; ++site) {
+            const int sx = site % L, sy = site / L;
+            for (int dir = 0; dir < 4; ++dir) {           // XPLUS, XMINUS, YPLUS, YMINUS
+                double hop = dir < 2 ? hopHor[band] : hopVer[band];
+                if (apbc_x && ((sx == 0 && dir == 1) || (sx == L - 1 && dir == 0))) hop *= -1;
+                if (apbc_y && ((sy == 0 && dir == 3) || (sy == L - 1 && dir == 2))) hop *= -1;
+                hc phase = 1.0;
+                if (dir == 0) phase = std::exp(hc(0.0, -2.0 * pi * zmag * sy));
+                if (dir == 1) phase = std::exp(hc(0.0, +2.0 * pi * zmag * sy));
+                if (dir == 2 && sy == L - 1) phase = std::exp(hc(0.0, +2.0 * pi * zmag * L * sx));
+                if (dir == 3 && sy == 0) phase = std::exp(hc(0.0, -2.0 * pi * zmag * L * sx));
+                K[(size_t)site * N + neigh[dir * N + site]] -= hop * phase;
+            }
+        }
+        std::vector<hc> Em, Ep;
+        herm_exp_dense(N, K, -p.dtau, +p.dtau, Em, Ep);
+        for (int b = band; b < MSF; b += 2)
+            for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) {
+                out_minus[(size_t)(b * N + j) * ng + (b * N + i)] = Em[(size_t)i * N + j];
+                out_plus[(size_t)(b * N + j) * ng + (b * N + i)] = Ep[(size_t)i * N + j];
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // lifetime
 // ---------------------------------------------------------------------------------------------
@@ -277,6 +365,16 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     HIPCHK(hipMemcpy(d_neigh, neigh.data(), neigh.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_pmats, pmats.data(), pmats.size() * sizeof(hc), hipMemcpyHostToDevice));
     hm.psites = d_psites; hm.neigh = d_neigh; hm.pmats = d_pmats;
+    if (p->cb_none) {
+        hm.dense = 1;
+        hm.ov[0] = hm.ov[1] = hm.ovinv[0] = hm.ovinv[1] = 1.0;     // mu is part of K in setupPropK
+        std::vector<hc> em, ep;
+        build_dense_propK(*p, neigh, MSF, em, ep);
+        const size_t nn = (size_t)ng * ng;
+        A_(dalloc(c, &c->propK[0], nn)); A_(dalloc(c, &c->propK[1], nn)); A_(dalloc(c, &c->Tdense, nn));
+        HIPCHK(hipMemcpy(c->propK[0], em.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->propK[1], ep.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+    }
 
     const size_t nphi = (size_t)(p->m + 1) * p->opdim * N, ncs = (size_t)(p->m + 1) * N;
     A_(dalloc(c, &c->phi, nphi)); A_(dalloc(c, &c->coshT, ncs)); A_(dalloc(c, &c->sinhT, ncs));
@@ -392,18 +490,44 @@ extern "C" int dqmc_get_fields_host(dqmc_ctx* c, double* phi, double* coshT, dou
 // ---------------------------------------------------------------------------------------------
 // chain order of checkerboard{Left,Right}MultiplyBmat[Inv] (detsdwopdim.cpp:2076-2090, 2172-2186,
 // 2307-2324, 2406-2420)
+static void gemm_dev(dqmc_ctx* c, int opA, int opB, const cplx* A, const cplx* B, cplx* C,
+                     const double* kscale = nullptr, int kinv = 0, const double* rowscale = nullptr,
+                     const double* colscale = nullptr, int accumulate = 0);
+
 static void bmult_dev(dqmc_ctx* c, int side, int inverse, int k2, int k1, cplx* A) {
     const int count = k2 - k1;
     if (count <= 0) return;
     bool ascending = (side == DQMC_LEFT) ? !inverse : (bool)inverse;
     int kfirst = ascending ? k1 + 1 : k2, kstep = ascending ? 1 : -1;
-    ProfScope ps(c, FAM_BMULT, 1);
-    launch_bmult(c->st, nullptr, c->hm, side, inverse, kfirst, kstep, count, A, c->n_g);
+    if (!c->hm.dense) {
+        ProfScope ps(c, FAM_BMULT, 1);
+        launch_bmult(c->st, nullptr, c->hm, side, inverse, kfirst, kstep, count, A, c->n_g);
+        return;
+    }
+    // CB_NONE (sdw*MultiplyBmat[Inv] functors with CBM == CB_NONE, detsdwopdim.h:1305-1375): per slice
+    // B_k = e^{-dtau V_k} propK, B_k^{-1} = propK^{-1} e^{+dtau V_k}; propK^{-+1} is one MFMA GEMM with the
+    // block-diagonal dense matrix, e^{-+dtau V_k} the site-local mix of the chain kernel.  The reference
+    // inverts the chain product numerically (arma::inv); the exact factor-wise inverse used here agrees
+    // with it to rounding.
+    const bool hop_first = ((side == DQMC_RIGHT) == (bool)inverse);   // left B, right B^-1
+    const cplx* PK = c->propK[inverse ? 1 : 0];
+    const size_t n2 = (size_t)c->n_g * c->n_g;
+    for (int i = 0; i < count; ++i) {
+        const int k = kfirst + i * kstep;
+        auto hop = [&]() {
+            if (side == DQMC_LEFT) gemm_dev(c, 0, 0, PK, A, c->Tdense, nullptr, 0, nullptr, nullptr, 0);
+            else                   gemm_dev(c, 0, 0, A, PK, c->Tdense, nullptr, 0, nullptr, nullptr, 0);
+            launch_copy(c->st, c->Tdense, A, n2);
+        };
+        if (hop_first) hop();
+        { ProfScope ps(c, FAM_BMULT, 1); launch_bmult(c->st, nullptr, c->hm, side, inverse, k, kstep, 1, A, c->n_g); }
+        if (!hop_first) hop();
+    }
 }
 
 static void gemm_dev(dqmc_ctx* c, int opA, int opB, const cplx* A, const cplx* B, cplx* C,
-                     const double* kscale = nullptr, int kinv = 0, const double* rowscale = nullptr,
-                     const double* colscale = nullptr, int accumulate = 0) {
+                     const double* kscale, int kinv, const double* rowscale,
+                     const double* colscale, int accumulate) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = c->n_g; g.opA = opA; g.B = B; g.ldb = c->n_g; g.opB = opB; g.C = C; g.ldc = c->n_g;

@@ -15,6 +15,8 @@ struct DevModel {
     int opdim, MSF, L, N, ng, m, s, n, D, P;   // P = plaquettes per subgroup = N/4
     int phi2bosons;
     int dbg;           // developer timing experiments only (DQMC_DBG env var); 0 in production
+    int dense;         // CB_NONE: the hopping part is a dense GEMM done by the host loop, the chain kernel
+                       // only applies e^{+-dtau V}; ov/ovinv are 1 (mu sits inside propK)
     double dtau, r, c, u, lambda;
     double ov[2];      // e^{+dtau mu_band}   (detsdwopdim.cpp:2037-2038)
     double ovinv[2];   // e^{-dtau mu_band}   (detsdwopdim.cpp:2137-2138)

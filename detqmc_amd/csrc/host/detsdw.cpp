@@ -67,6 +67,7 @@ DetSDW::DetSDW(const detsdw_params& in) : pars_(in), rng_(in.rngSeed, (uint32_t)
     kp.mux = p.mux; kp.muy = p.muy; kp.accRatio = p.accRatio;
     if (p.stabilisation != 0 && p.stabilisation != 1) throw ParameterWrong("Parameter stabilisation has incorrect value");
     kp.stabilisation = p.stabilisation;
+    kp.cb_none = p.cb_none ? 1 : 0;          // reference option checkerboard=false (DetSDW<CB_NONE, OPDIM>)
     check(dqmc_create(&kp, &ctx_), "dqmc_create");
 
     phi_.assign((size_t)N_ * opdim_ * (m_ + 1), 0.0);

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
         for (int stage = 0; stage < 2; ++stage) {
             const bool do_passes = (stage == 0) == PASSES_FIRST;
             if (do_passes) {
+                if (dm.dense) continue;      // CB_NONE: dense e^{+-dtau K} applied by a GEMM outside this kernel
                 // e^{+-dtau K1/2} e^{+-dtau K0} e^{+-dtau K1/2}: sub 1 (half), sub 0 (full), sub 1 (half)
                 for (int pass = 0; pass < 3; ++pass) {
                     const int sub = (pass == 1) ? 0 : 1;

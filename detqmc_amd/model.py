@@ -57,6 +57,7 @@ class SDWParams:
     simindex: int = 0
     device: int = 0
     stabilisation: str = "svd"   # "svd": UdV = SVD like the reference; "qr": pre-pivoted Householder UDT
+    checkerboard: bool = True    # False = CB_NONE: dense B_k = e^{-dtau V_k} e^{-dtau K} (reference option checkerboard=false)
 
 
 def _fmat(a):
@@ -69,11 +70,11 @@ class KernelContext:
 
     def __init__(self, opdim, L, m, s, dtau, delaySteps=16, bc="pbc", weakZflux=False, r=-1.0, c=3.0, u=1.0,
                  lambda_=1.0, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, mux=-0.5, muy=-0.5,
-                 accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd"):
+                 accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd", checkerboard=True):
         self.lib = load()
         p = _lib.dqmc_params(opdim=opdim, L=L, m=m, s=s, delaySteps=delaySteps, bc=BC[bc],
                              weakZflux=int(weakZflux), phi2bosons=int(phi2bosons), device=device,
-                             stabilisation=STABILISATION[stabilisation], dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
+                             stabilisation=STABILISATION[stabilisation], cb_none=int(not checkerboard), dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
                              tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio)
         h = C.c_void_p()
         check(self.lib.dqmc_create(C.byref(p), C.byref(h)))
@@ -260,7 +261,7 @@ class DetSDW:
             beta=pars.beta, dtau=pars.dtau, r=pars.r, c=pars.c, u=pars.u, lambda_=pars.lambda_,
             txhor=pars.txhor, txver=pars.txver, tyhor=pars.tyhor, tyver=pars.tyver,
             mu=pars.mu, mux=pars.mux or 0.0, muy=pars.muy or 0.0, accRatio=pars.accRatio, cdwU=pars.cdwU,
-            stabilisation=STABILISATION[pars.stabilisation])
+            stabilisation=STABILISATION[pars.stabilisation], cb_none=int(not pars.checkerboard))
         h = C.c_void_p()
         check(self.lib.detsdw_create(C.byref(p), C.byref(h)), host=True)
         self.h = h

@@ -25,7 +25,7 @@ typedef struct detsdw_replica detsdw_replica;
 
 /* ModelParamsDetSDW (src/detsdwparams.h:24-120) + rngSeed/simindex of DetQMCParams
  * (src/detqmcparams.h) as far as the sweep path uses them.  Unsupported reference options
- * (cdwU != 0, turnoffFermions, rotate/scale proposals, Wolff cluster moves, CB_NONE) are rejected by
+ * (cdwU != 0, turnoffFermions, rotate/scale proposals, Wolff cluster moves) are rejected by
  * detsdw_create with DQMC_EINVAL and a message naming the option. */
 typedef struct detsdw_params {
     int32_t opdim;
@@ -50,7 +50,7 @@ typedef struct detsdw_params {
     double accRatio;
     double cdwU;                 /* must be 0 */
     int32_t stabilisation;       /* 0 = SVD (as the reference), 1 = QR/UDT (same G to rounding, much faster) */
-    int32_t reserved2;
+    int32_t cb_none;             /* 0 = checkerboard (default), 1 = checkerboard=false: dense B matrices (CB_NONE) */
 } detsdw_params;
 
 typedef struct detsdw_info {

@@ -62,6 +62,9 @@ typedef struct dqmc_params {
     int32_t phi2bosons;
     int32_t device;       /* HIP device ordinal */
     int32_t stabilisation; /* DQMC_STAB_SVD (reference-exact UdV = SVD) or DQMC_STAB_QR (pre-pivoted Householder UDT) */
+    int32_t cb_none;      /* 0: checkerboard break-up CB_ASSAAD_BERG (every shipped config); 1: checkerboard=false,
+                             dense B_k = e^{-dtau V_k} e^{-dtau K} (computeBmatSDW, detsdwopdim.cpp:1309-1485) */
+    int32_t reserved;
     double dtau, r, c, u, lambda;
     double txhor, txver, tyhor, tyver;
     double mux, muy;

@@ -52,6 +52,7 @@ class SDWParams:
     globalShift: bool = False
     globalUpdateInterval: int = 100
     phi2bosons: bool = False
+    checkerboard: bool = True     # False = CB_NONE: dense B = e^{-dtau V} e^{-dtau K} (detsdwopdim.h:1305-1375)
     rngSeed: int = 1020304050
     simindex: int = 0
     # derived
@@ -433,24 +434,32 @@ class DetSDWOracle:
 
     # chains (a14), detsdwopdim.cpp:2076-2090, 2172-2186, 2307-2324, 2406-2420
     def leftMultiplyBmat(self, A, k2, k1):
+        if not self.pars.checkerboard:          # CB_NONE functors, detsdwopdim.h:1305-1375
+            return self.computeBmatSDW(k2, k1) @ A
         R = A
         for k in range(k1 + 1, k2 + 1):
             R = self.leftMultiplyBk(R, k)
         return R
 
     def leftMultiplyBmatInv(self, A, k2, k1):
+        if not self.pars.checkerboard:
+            return np.linalg.inv(self.computeBmatSDW(k2, k1)) @ A
         R = A
         for k in range(k2, k1, -1):
             R = self.leftMultiplyBkInv(R, k)
         return R
 
     def rightMultiplyBmat(self, A, k2, k1):
+        if not self.pars.checkerboard:
+            return A @ self.computeBmatSDW(k2, k1)
         R = A
         for k in range(k2, k1, -1):
             R = self.rightMultiplyBk(R, k)
         return R
 
     def rightMultiplyBmatInv(self, A, k2, k1):
+        if not self.pars.checkerboard:
+            return A @ np.linalg.inv(self.computeBmatSDW(k2, k1))
         R = A
         for k in range(k1 + 1, k2 + 1):
             R = self.rightMultiplyBkInv(R, k)
@@ -751,9 +760,12 @@ class DetSDWOracle:
         return 0.5 * self.dtau * float(np.sum(self.phi[1:] ** 2))
 
     # ------------------------------------------------------------------ dense B (a15, checks only)
-    def computeBmatDense(self, k):
-        """detsdwopdim.cpp:1309-1497 single slice, no flux: e^{-dtau V_k} e^{-dtau K}, dense propK via
-        eig_sym (detmodel.cpp:31-39, setupPropK detsdwopdim.cpp:1210-1285)."""
+    def _dense_propK(self):
+        """setupPropK (detsdwopdim.cpp:1210-1285) + computePropagator (detmodel.cpp:31-39):
+        propK[band] = exp(-dtau K_band) through eig_sym, K_band including -mu_band on the diagonal,
+        the APBC signs and the Peierls phases of zmag[XUP] / zmag[YDOWN]."""
+        if getattr(self, "_propK", None) is not None:
+            return self._propK
         p, N, L = self.pars, self.N, self.L
         hop = {XBAND: (p.txhor, p.txver), YBAND: (p.tyhor, p.tyver)}
         props = {}
@@ -781,9 +793,28 @@ class DetSDWOracle:
                     K[site, nb] -= h * ph
             ev, evec = np.linalg.eigh(K)
             props[band] = (evec * np.exp(-self.dtau * ev)) @ evec.conj().T
+        self._propK = props
+        return props
+
+    def computeBmatDense(self, k):
+        """singleTimesliceProp of computeBmatSDW (detsdwopdim.cpp:1324-1474): e^{-dtau V_k} e^{-dtau K};
+        block (r, c) = diag(V_k[r, c]) propK[band(c)].  As in the reference, the O(3) lower blocks use
+        the same propK as the upper ones (its TODO at :1439 notes the flux case is not adapted; flux is
+        only allowed for opdim = 2 anyway)."""
+        props = self._dense_propK()
         V = self._V_slice(-1, k)
         B = np.zeros((self.ng, self.ng), dtype=complex)
         for r in range(self.MSF):
             for c in range(self.MSF):
                 B[self._blk(r), self._blk(c)] = V[r, c][:, None] * props[c % 2]
         return B
+
+    def computeBmatSDW(self, k2, k1):
+        """detsdwopdim.cpp:1309-1485: B(k2, k1) = B_k2 B_{k2-1} ... B_{k1+1}, identity for k2 == k1."""
+        if k2 == k1:
+            return np.eye(self.ng, dtype=complex)
+        assert k1 < k2 <= self.m
+        R = self.computeBmatDense(k2)
+        for k in range(k2 - 1, k1, -1):
+            R = R @ self.computeBmatDense(k)
+        return R

@@ -32,6 +32,10 @@ CASES = {
     "o2_L4_gshift": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=6, globalShift=1,
                                    globalUpdateInterval=2, sliceTrace=0)),
     "o2_L6_seed": dict(args=dict(opdim=2, L=6, beta=3, s=10, delaySteps=8, sweeps=2, rngSeed=5555, simindex=3)),
+    # checkerboard=false (CB_NONE): dense B = e^{-dtau V} e^{-dtau K}, inverse by arma::inv
+    "o2_L4_dense": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, checkerboard=0)),
+    "o2_L4_dense_flux": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=2, checkerboard=0, weakZflux=1,
+                                      bc="apbc-x", mux=-0.3, muy=-0.6)),
     "o1_L4": dict(args=dict(opdim=1, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
     "o3_L4": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
     # BASELINE config 2 (bring-up size): full G only at a few points

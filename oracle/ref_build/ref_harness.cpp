@@ -67,6 +67,7 @@ typedef std::complex<double> cpx_t;
 #endif
 // one binary per order-parameter dimension, like the reference's own detqmcsdwo{1,2,3} targets
 typedef DetSDW<CB_ASSAAD_BERG, HARNESS_OPDIM> SDWN;
+typedef DetSDW<CB_NONE, HARNESS_OPDIM> SDWN_DENSE;     // checkerboard=false: dense B = e^{-dtau V} e^{-dtau K}
 
 static std::string g_outdir;
 static std::ofstream g_manifest;
@@ -146,7 +147,7 @@ static ModelParamsDetSDW make_params(const std::map<std::string, std::string>& k
 #undef SET
     if (kv.count("mux")) { p.mux = get<double>(kv, "mux", 0.0); p.specified.insert("mux"); }
     if (kv.count("muy")) { p.muy = get<double>(kv, "muy", 0.0); p.specified.insert("muy"); }
-    p.checkerboard = true; p.specified.insert("checkerboard");
+    p.checkerboard = get<int>(kv, "checkerboard", 1) != 0; p.specified.insert("checkerboard");
     p.updateMethod_string = gets(kv, "updateMethod", "delayed"); p.specified.insert("updateMethod");
     p.spinProposalMethod_string = "box"; p.specified.insert("spinProposalMethod");
     p.bc_string = gets(kv, "bc", "pbc"); p.specified.insert("bc");
@@ -230,21 +231,25 @@ static int run(const std::map<std::string, std::string>& kv) {
         }
     }
 
-    // --- the four checkerboard multipliers on a fixed test matrix, single slice and chains ---
+    // --- the four B multipliers on a fixed test matrix, single slice and chains ---
     {
         arma::Mat<cpx_t> A = test_matrix(ng);
         uint32_t k = std::min<uint32_t>(3, m);
         dump_scalar("bmult_k", k);
-        dump("bmult_left",     rep->leftMultiplyBk(A, k));
-        dump("bmult_leftinv",  rep->leftMultiplyBkInv(A, k));
-        dump("bmult_right",    rep->rightMultiplyBk(A, k));
-        dump("bmult_rightinv", rep->rightMultiplyBkInv(A, k));
+        typename SDW::sdwLeftMultiplyBmat lB(rep.get());
+        typename SDW::sdwRightMultiplyBmat rB(rep.get());
+        typename SDW::sdwLeftMultiplyBmatInv lBi(rep.get());
+        typename SDW::sdwRightMultiplyBmatInv rBi(rep.get());
+        dump("bmult_left",     lB(0, A, k, k - 1));
+        dump("bmult_leftinv",  lBi(0, A, k, k - 1));
+        dump("bmult_right",    rB(0, A, k, k - 1));
+        dump("bmult_rightinv", rBi(0, A, k, k - 1));
         uint32_t k2 = std::min<uint32_t>(s, m), k1 = 0;
         dump_scalar("bchain_k2", k2);
-        dump("bchain_left",     rep->checkerboardLeftMultiplyBmat(A, k2, k1));
-        dump("bchain_leftinv",  rep->checkerboardLeftMultiplyBmatInv(A, k2, k1));
-        dump("bchain_right",    rep->checkerboardRightMultiplyBmat(A, k2, k1));
-        dump("bchain_rightinv", rep->checkerboardRightMultiplyBmatInv(A, k2, k1));
+        dump("bchain_left",     lB(0, A, k2, k1));
+        dump("bchain_leftinv",  lBi(0, A, k2, k1));
+        dump("bchain_right",    rB(0, A, k2, k1));
+        dump("bchain_rightinv", rBi(0, A, k2, k1));
         // dense B (computeBmatSDW) -- differs from the checkerboard product at O(dtau^2)
         dump("bdense_k", rep->computeBmatSDW(k, k - 1));
     }
@@ -322,7 +327,7 @@ int main(int argc, char** argv) {
 
     uint32_t opdim = get<uint32_t>(kv, "opdim", 2);
     try {
-        if (opdim == HARNESS_OPDIM) return run<SDWN>(kv);
+        if (opdim == HARNESS_OPDIM) return get<int>(kv, "checkerboard", 1) ? run<SDWN>(kv) : run<SDWN_DENSE>(kv);
     } catch (const std::exception& e) {
         std::cerr << "reference threw: " << e.what() << "\n";
         return 3;

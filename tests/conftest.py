@@ -39,6 +39,7 @@ def oracle_params(args):
         kw["bc"] = a["bc"]
     kw["weakZflux"] = bool(int(a.get("weakZflux", 0)))
     kw["globalShift"] = bool(int(a.get("globalShift", 0)))
+    kw["checkerboard"] = bool(int(a.get("checkerboard", 1)))
     kw["rngSeed"] = int(a.get("rngSeed", 1020304050))
     kw["simindex"] = int(a.get("simindex", 0))
     return SDWParams(**kw)

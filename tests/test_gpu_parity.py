@@ -13,7 +13,8 @@ from conftest import load_golden, oracle_params, relerr
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
-SMALL = ["o2_L4", "o2_L4_s7", "o2_L4_flux", "o2_L4_apbc", "o1_L4", "o3_L4", "o2_L6_seed"]
+SMALL = ["o2_L4", "o2_L4_s7", "o2_L4_flux", "o2_L4_apbc", "o1_L4", "o3_L4", "o2_L6_seed",
+         "o2_L4_dense", "o2_L4_dense_flux"]     # *_dense: checkerboard=false (CB_NONE)
 
 
 def _ctx_from_params(a, **over):
@@ -21,7 +22,8 @@ def _ctx_from_params(a, **over):
     op = oracle_params(a).finalize()
     kw = dict(opdim=op.opdim, L=op.L, m=op.m, s=op.s, dtau=op.dtau, delaySteps=op.delaySteps, bc=op.bc,
               weakZflux=op.weakZflux, r=op.r, c=op.c, u=op.u, lambda_=op.lambda_, txhor=op.txhor,
-              txver=op.txver, tyhor=op.tyhor, tyver=op.tyver, mux=op.mux, muy=op.muy, accRatio=op.accRatio)
+              txver=op.txver, tyhor=op.tyhor, tyver=op.tyver, mux=op.mux, muy=op.muy, accRatio=op.accRatio,
+              checkerboard=op.checkerboard)
     kw.update(over)
     return KernelContext(**kw), op
 
@@ -33,7 +35,7 @@ def _sdw_params(a, **over):
               lambda_=op.lambda_, txhor=op.txhor, txver=op.txver, tyhor=op.tyhor, tyver=op.tyver, mu=op.mu,
               mux=op.mux, muy=op.muy, accRatio=op.accRatio, delaySteps=op.delaySteps, bc=op.bc,
               weakZflux=op.weakZflux, globalShift=op.globalShift, globalUpdateInterval=op.globalUpdateInterval,
-              rngSeed=op.rngSeed, simindex=op.simindex)
+              rngSeed=op.rngSeed, simindex=op.simindex, checkerboard=op.checkerboard)
     kw.update(over)
     return SDWParams(**kw)
 
@@ -92,6 +94,9 @@ def test_bmult_vs_reference(name):
         assert relerr(ctx.leftMultiplyBmatInv(A, k2, 0), g["bchain_leftinv"]) < 1e-12
         assert relerr(ctx.rightMultiplyBmat(A, k2, 0), g["bchain_right"]) < 1e-12
         assert relerr(ctx.rightMultiplyBmatInv(A, k2, 0), g["bchain_rightinv"]) < 1e-12
+    if not op.checkerboard:       # CB_NONE: the multiply IS the dense computeBmatSDW (detsdwopdim.cpp:1309-1485)
+        assert relerr(ctx.leftMultiplyBmat(np.eye(ctx.ng), k, k - 1), g["bdense_k"]) < 1e-12
+        assert relerr(ctx.rightMultiplyBmat(np.eye(ctx.ng), k, k - 1), g["bdense_k"]) < 1e-12
     # exact-to-rounding identity of the symmetric break-up: B^-1 B = 1
     # (error grows with the condition number of the chain, so keep it to one stabilisation interval)
     R = ctx.leftMultiplyBmatInv(ctx.leftMultiplyBmat(A, op.s, 0), op.s, 0)

@@ -9,7 +9,8 @@ from dsfmt_oracle import RngWrapper
 
 TOL = 1e-10   # BASELINE.json north_star: 1e-10 relative for fp64
 
-SMALL = ["o2_L4", "o2_L4_s7", "o2_L4_flux", "o2_L4_apbc", "o1_L4", "o3_L4", "o2_L6_seed"]
+SMALL = ["o2_L4", "o2_L4_s7", "o2_L4_flux", "o2_L4_apbc", "o1_L4", "o3_L4", "o2_L6_seed",
+         "o2_L4_dense", "o2_L4_dense_flux"]      # *_dense: checkerboard=false (CB_NONE)
 
 
 def test_rng_bit_exact():
@@ -46,11 +47,11 @@ def test_bmult(case):
     name, g, o = case
     A = make_test_matrix(o.ng)
     k = int(g["bmult_k"][0])
-    assert relerr(o.leftMultiplyBk(A, k), g["bmult_left"]) < 1e-13
-    assert relerr(o.rightMultiplyBk(A, k), g["bmult_right"]) < 1e-13
+    assert relerr(o.leftMultiplyBmat(A, k, k - 1), g["bmult_left"]) < 1e-13
+    assert relerr(o.rightMultiplyBmat(A, k, k - 1), g["bmult_right"]) < 1e-13
     if "bmult_leftinv" in g:
-        assert relerr(o.leftMultiplyBkInv(A, k), g["bmult_leftinv"]) < 1e-13
-        assert relerr(o.rightMultiplyBkInv(A, k), g["bmult_rightinv"]) < 1e-13
+        assert relerr(o.leftMultiplyBmatInv(A, k, k - 1), g["bmult_leftinv"]) < 1e-13
+        assert relerr(o.rightMultiplyBmatInv(A, k, k - 1), g["bmult_rightinv"]) < 1e-13
     if "bchain_left" in g:
         k2 = int(g["bchain_k2"][0])
         assert relerr(o.leftMultiplyBmat(A, k2, 0), g["bchain_left"]) < 1e-12
