@@ -83,6 +83,9 @@ _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
 SYMBOLS = [
     ("dqmc_create", C.c_int, [C.POINTER(dqmc_params), C.POINTER(_P)]),
+    ("dqmc_create_batch", C.c_int, [C.POINTER(dqmc_params), C.c_int, C.POINTER(_P)]),
+    ("dqmc_select_chain", C.c_int, [_P, C.c_int]),
+    ("dqmc_num_chains", C.c_int, [_P]),
     ("dqmc_destroy", None, [_P]),
     ("dqmc_last_error", C.c_char_p, []),
     ("dqmc_synchronize", C.c_int, [_P]),

@@ -31,6 +31,12 @@ struct dqmc_ctx {
     dqmc_params p;
     DevModel hm;
     hipStream_t st = nullptr;
+    // batched chains: nb chains in lockstep; per-chain buffers of chain b = chain 0's + b * cs (one arena)
+    Launch lc{nullptr, 1, 0};
+    int nb = 1, sel = 0;                // sel: chain the host-buffer entry points talk to (dqmc_select_chain)
+    char* arena = nullptr;
+    size_t arena_off = 0;
+    std::vector<void**> fixups;
     int n_g = 0, MSF = 0, N = 0, m = 0, s = 0, n = 0, D = 0;
     std::vector<void*> allocs;
     // fields + backups
@@ -74,14 +80,40 @@ struct dqmc_ctx {
     double gemm_flops = 0.0;
 };
 
+// shared (chain independent) device memory
 template<class T>
-static int dalloc(dqmc_ctx* c, T** p, size_t count) {
+static int salloc(dqmc_ctx* c, T** p, size_t count) {
     void* q = nullptr;
     HIPCHK(hipMalloc(&q, count * sizeof(T)));
     c->allocs.push_back(q);
     *p = (T*)q;
     return 0;
 }
+// per-chain device memory: reserves a range of the arena layout; *p holds the offset (+256) until
+// arena_commit turns it into chain 0's address.  p must stay where it is until then.
+template<class T>
+static int dalloc(dqmc_ctx* c, T** p, size_t count) {
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    *p = (T*)(uintptr_t)(c->arena_off + 256);
+    c->fixups.push_back((void**)p);
+    c->arena_off += bytes;
+    return 0;
+}
+static int arena_commit(dqmc_ctx* c) {
+    const size_t cs = c->arena_off;
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, cs * (size_t)c->nb));
+    c->allocs.push_back(q);
+    HIPCHK(hipMemset(q, 0, cs * (size_t)c->nb));
+    c->arena = (char*)q;
+    for (void** pp : c->fixups) *pp = c->arena + ((uintptr_t)*pp - 256);
+    c->fixups.clear();
+    c->lc = Launch{c->st, c->nb, cs};
+    return 0;
+}
+// the selected chain's copy of a per-chain buffer (host-buffer entry points)
+template<class T> static T* selp(dqmc_ctx* c, T* p) { return (T*)((char*)p + (size_t)c->sel * c->lc.cs); }
+template<class T> static T* chainp(dqmc_ctx* c, T* p, int b) { return (T*)((char*)p + (size_t)b * c->lc.cs); }
 
 struct ProfScope {
     dqmc_ctx* c; int fam; uint64_t launches;
@@ -314,9 +346,12 @@ static int alloc_slot(dqmc_ctx* c, UdVSlot& sl) {
     return 0;
 }
 
-extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
+extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) { return dqmc_create_batch(p, 1, out); }
+
+extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** out) {
     if (!p || !out) return fail(DQMC_EINVAL, "null argument");
     *out = nullptr;
+    if (nchains < 1 || nchains > 1024) return fail(DQMC_EINVAL, "nchains must be in 1..1024");
     // parameter rules of ModelParamsDetSDW::check (detsdwparams.cpp:21-140) that concern the kernels
     if (p->opdim < 1 || p->opdim > 3) return fail(DQMC_EINVAL, "opdim must be 1, 2 or 3");
     if (p->L < 2 || (p->L % 2) != 0)
@@ -339,6 +374,7 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
 
     dqmc_ctx* c = new dqmc_ctx();
     c->p = *p;
+    c->nb = nchains;
     c->N = N; c->MSF = MSF; c->n_g = ng; c->m = p->m; c->s = p->s; c->D = p->delaySteps;
     c->n = (p->m + p->s - 1) / p->s;       // ceil(m/s), detmodel.h:518
     HIPCHK(hipStreamCreate(&c->st));
@@ -358,9 +394,9 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     int *d_psites, *d_neigh; cplx* d_pmats;
     int rc;
 #define A_(x) if ((rc = (x))) { dqmc_destroy(c); return rc; }
-    A_(dalloc(c, &d_psites, psites.size()));
-    A_(dalloc(c, &d_neigh, neigh.size()));
-    A_(dalloc(c, &d_pmats, pmats.size()));
+    A_(salloc(c, &d_psites, psites.size()));
+    A_(salloc(c, &d_neigh, neigh.size()));
+    A_(salloc(c, &d_pmats, pmats.size()));
     HIPCHK(hipMemcpy(d_psites, psites.data(), psites.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_neigh, neigh.data(), neigh.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_pmats, pmats.data(), pmats.size() * sizeof(hc), hipMemcpyHostToDevice));
@@ -371,7 +407,7 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
         std::vector<hc> em, ep;
         build_dense_propK(*p, neigh, MSF, em, ep);
         const size_t nn = (size_t)ng * ng;
-        A_(dalloc(c, &c->propK[0], nn)); A_(dalloc(c, &c->propK[1], nn)); A_(dalloc(c, &c->Tdense, nn));
+        A_(salloc(c, &c->propK[0], nn)); A_(salloc(c, &c->propK[1], nn)); A_(dalloc(c, &c->Tdense, nn));
         HIPCHK(hipMemcpy(c->propK[0], em.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->propK[1], ep.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
     }
@@ -379,10 +415,6 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     const size_t nphi = (size_t)(p->m + 1) * p->opdim * N, ncs = (size_t)(p->m + 1) * N;
     A_(dalloc(c, &c->phi, nphi)); A_(dalloc(c, &c->coshT, ncs)); A_(dalloc(c, &c->sinhT, ncs));
     A_(dalloc(c, &c->phi_bak, nphi)); A_(dalloc(c, &c->cosh_bak, ncs)); A_(dalloc(c, &c->sinh_bak, ncs));
-    HIPCHK(hipMemset(c->phi, 0, nphi * sizeof(double)));
-    HIPCHK(hipMemset(c->coshT, 0, ncs * sizeof(double)));
-    HIPCHK(hipMemset(c->sinhT, 0, ncs * sizeof(double)));
-    hm.phi = c->phi; hm.coshT = c->coshT; hm.sinhT = c->sinhT;
 
     const size_t n2 = (size_t)ng * ng;
     A_(dalloc(c, &c->G, n2)); A_(dalloc(c, &c->G_bak, n2));
@@ -392,11 +424,12 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     A_(alloc_slot(c, c->spare)); A_(alloc_slot(c, c->tmpudv));
     A_(dalloc(c, &c->T1, n2)); A_(dalloc(c, &c->T2, n2)); A_(dalloc(c, &c->T3, n2)); A_(dalloc(c, &c->T4, n2));
     A_(dalloc(c, &c->sw.A, n2)); A_(dalloc(c, &c->sw.V, n2));
-    A_(dalloc(c, &c->sw.norms, (size_t)ng)); A_(dalloc(c, &c->sw.rnorms, (size_t)ng)); A_(dalloc(c, &c->sw.flagT, 1)); A_(dalloc(c, &c->sw.rank, (size_t)ng)); A_(dalloc(c, &c->sw.flag, 1));
+    A_(dalloc(c, &c->sw.norms, (size_t)ng)); A_(dalloc(c, &c->sw.rnorms, (size_t)ng)); A_(dalloc(c, &c->sw.flagT, 1)); A_(dalloc(c, &c->sw.rank, (size_t)ng));
+    A_(salloc(c, &c->sw.flag, 1));        // residual of a Jacobi sweep: max over all chains
     HIPCHK(hipHostMalloc((void**)&c->sw.hflag, 2 * sizeof(unsigned long long), hipHostMallocMapped));
     c->sw.hflag[0] = 0; c->sw.hflag[1] = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&c->sw.hslot_dev, c->sw.hflag, 0));
-    A_(dalloc(c, &c->sw.seqctr, 1));
+    A_(salloc(c, &c->sw.seqctr, 1));
     HIPCHK(hipMemset(c->sw.seqctr, 0, sizeof(unsigned long long)));
     c->sw.host_seq = &c->jacobi_host_seq;
     c->sw.last_residual = &c->last_svd_residual;
@@ -407,7 +440,7 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
         std::vector<int> rounds;
         build_tournament(nblk, rounds);
         int* d_rounds;
-        A_(dalloc(c, &d_rounds, rounds.size()));
+        A_(salloc(c, &d_rounds, rounds.size()));
         HIPCHK(hipMemcpy(d_rounds, rounds.data(), rounds.size() * sizeof(int), hipMemcpyHostToDevice));
         c->sw.rounds = d_rounds; c->sw.nrounds = nblk - 1; c->sw.nblk = nblk;
     }
@@ -420,7 +453,6 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
         A_(dalloc(c, &c->qr_perm, (size_t)ng));
         A_(dalloc(c, &c->rmax_inv, (size_t)ng)); A_(dalloc(c, &c->rmin, (size_t)ng));
         A_(dalloc(c, &c->lmax_inv, (size_t)ng)); A_(dalloc(c, &c->lmin, (size_t)ng));
-        HIPCHK(hipMemset(c->qw.V, 0, n2 * sizeof(cplx)));
     }
     A_(alloc_slot(c, c->eye));
     const int WD = MSF * c->D;
@@ -429,13 +461,16 @@ extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) {
     A_(dalloc(c, &c->uniforms, c->uni_cap));
     A_(dalloc(c, &c->us, 1));
     A_(dalloc(c, &c->scalar_out, 8));
+    A_(arena_commit(c));                    // from here on the per-chain pointers are real (chain 0) addresses, zero filled
 #undef A_
+    hm.phi = c->phi; hm.coshT = c->coshT; hm.sinhT = c->sinhT;
     DevUpdateState hus;
     memset(&hus, 0, sizeof(hus));
     hus.pub.phiDelta = 0.5;                 // AdjustmentData::InitialPhiDelta (detsdwopdim.h:489)
     hus.pub.targetAccRatio = p->accRatio;
     hus.slice_done = 1;
-    HIPCHK(hipMemcpy(c->us, &hus, sizeof(hus), hipMemcpyHostToDevice));
+    hus.r = p->r;
+    for (int b = 0; b < c->nb; ++b) HIPCHK(hipMemcpy(chainp(c, c->us, b), &hus, sizeof(hus), hipMemcpyHostToDevice));
     { int rc2 = set_slot_identity(c, c->eye); if (rc2) { dqmc_destroy(c); return rc2; } }
     HIPCHK(hipDeviceSynchronize());
     *out = c;
@@ -461,6 +496,13 @@ extern "C" int dqmc_synchronize(dqmc_ctx* c) {
     return DQMC_OK;
 }
 extern "C" void* dqmc_stream(dqmc_ctx* c) { return c ? (void*)c->st : nullptr; }
+extern "C" int dqmc_num_chains(dqmc_ctx* c) { return c ? c->nb : 0; }
+extern "C" int dqmc_select_chain(dqmc_ctx* c, int chain) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    if (chain < 0 || chain >= c->nb) return fail(DQMC_EINVAL, "chain index out of range");
+    c->sel = chain;
+    return DQMC_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // fields
@@ -469,8 +511,8 @@ extern "C" int dqmc_set_fields_host(dqmc_ctx* c, const double* phi) {
     if (!c || !phi) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N;
-    HIPCHK(hipMemcpyAsync(c->phi, phi, nphi * sizeof(double), hipMemcpyHostToDevice, c->st));
-    { ProfScope ps(c, FAM_OTHER, 1); launch_cosh_sinh(c->st, c->hm); }
+    HIPCHK(hipMemcpyAsync(selp(c, c->phi), phi, nphi * sizeof(double), hipMemcpyHostToDevice, c->st));
+    { ProfScope ps(c, FAM_OTHER, 1); launch_cosh_sinh(c->lc, c->hm); }
     HIPCHK(hipStreamSynchronize(c->st));
     return DQMC_OK;
 }
@@ -479,9 +521,9 @@ extern "C" int dqmc_get_fields_host(dqmc_ctx* c, double* phi, double* coshT, dou
     (void)hipSetDevice(c->p.device);
     const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
     HIPCHK(hipStreamSynchronize(c->st));
-    if (phi) HIPCHK(hipMemcpy(phi, c->phi, nphi * sizeof(double), hipMemcpyDeviceToHost));
-    if (coshT) HIPCHK(hipMemcpy(coshT, c->coshT, ncs * sizeof(double), hipMemcpyDeviceToHost));
-    if (sinhT) HIPCHK(hipMemcpy(sinhT, c->sinhT, ncs * sizeof(double), hipMemcpyDeviceToHost));
+    if (phi) HIPCHK(hipMemcpy(phi, selp(c, c->phi), nphi * sizeof(double), hipMemcpyDeviceToHost));
+    if (coshT) HIPCHK(hipMemcpy(coshT, selp(c, c->coshT), ncs * sizeof(double), hipMemcpyDeviceToHost));
+    if (sinhT) HIPCHK(hipMemcpy(sinhT, selp(c, c->sinhT), ncs * sizeof(double), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 
@@ -492,7 +534,7 @@ extern "C" int dqmc_get_fields_host(dqmc_ctx* c, double* phi, double* coshT, dou
 // 2307-2324, 2406-2420)
 static void gemm_dev(dqmc_ctx* c, int opA, int opB, const cplx* A, const cplx* B, cplx* C,
                      const double* kscale = nullptr, int kinv = 0, const double* rowscale = nullptr,
-                     const double* colscale = nullptr, int accumulate = 0);
+                     const double* colscale = nullptr, int accumulate = 0, int sharedA = 0, int sharedB = 0);
 
 static void bmult_dev(dqmc_ctx* c, int side, int inverse, int k2, int k1, cplx* A) {
     const int count = k2 - k1;
@@ -501,7 +543,7 @@ static void bmult_dev(dqmc_ctx* c, int side, int inverse, int k2, int k1, cplx* 
     int kfirst = ascending ? k1 + 1 : k2, kstep = ascending ? 1 : -1;
     if (!c->hm.dense) {
         ProfScope ps(c, FAM_BMULT, 1);
-        launch_bmult(c->st, nullptr, c->hm, side, inverse, kfirst, kstep, count, A, c->n_g);
+        launch_bmult(c->lc, nullptr, c->hm, side, inverse, kfirst, kstep, count, A, c->n_g);
         return;
     }
     // CB_NONE (sdw*MultiplyBmat[Inv] functors with CBM == CB_NONE, detsdwopdim.h:1305-1375): per slice
@@ -515,27 +557,28 @@ static void bmult_dev(dqmc_ctx* c, int side, int inverse, int k2, int k1, cplx* 
     for (int i = 0; i < count; ++i) {
         const int k = kfirst + i * kstep;
         auto hop = [&]() {
-            if (side == DQMC_LEFT) gemm_dev(c, 0, 0, PK, A, c->Tdense, nullptr, 0, nullptr, nullptr, 0);
-            else                   gemm_dev(c, 0, 0, A, PK, c->Tdense, nullptr, 0, nullptr, nullptr, 0);
-            launch_copy(c->st, c->Tdense, A, n2);
+            if (side == DQMC_LEFT) gemm_dev(c, 0, 0, PK, A, c->Tdense, nullptr, 0, nullptr, nullptr, 0, /*sharedA=*/1, 0);
+            else                   gemm_dev(c, 0, 0, A, PK, c->Tdense, nullptr, 0, nullptr, nullptr, 0, 0, /*sharedB=*/1);
+            launch_copy(c->lc, c->Tdense, A, n2);
         };
         if (hop_first) hop();
-        { ProfScope ps(c, FAM_BMULT, 1); launch_bmult(c->st, nullptr, c->hm, side, inverse, k, kstep, 1, A, c->n_g); }
+        { ProfScope ps(c, FAM_BMULT, 1); launch_bmult(c->lc, nullptr, c->hm, side, inverse, k, kstep, 1, A, c->n_g); }
         if (!hop_first) hop();
     }
 }
 
 static void gemm_dev(dqmc_ctx* c, int opA, int opB, const cplx* A, const cplx* B, cplx* C,
                      const double* kscale, int kinv, const double* rowscale,
-                     const double* colscale, int accumulate) {
+                     const double* colscale, int accumulate, int sharedA, int sharedB) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = c->n_g; g.opA = opA; g.B = B; g.ldb = c->n_g; g.opB = opB; g.C = C; g.ldc = c->n_g;
     g.M = g.N = g.K = c->n_g; g.Kmul = 1;
     g.kscale = kscale; g.kscale_invert = kinv; g.rowscale = rowscale; g.colscale = colscale; g.accumulate = accumulate;
-    c->gemm_flops += 8.0 * (double)g.M * g.N * g.K;
+    g.sharedA = sharedA; g.sharedB = sharedB;
+    c->gemm_flops += 8.0 * (double)g.M * g.N * g.K * c->nb;
     ProfScope ps(c, FAM_GEMM, 1);
-    launch_gemm(c->st, g);
+    launch_gemm(c->lc, g);
 }
 
 // udvDecompose (udv.h:68-102) of diag(rowscale) M diag(colscale)
@@ -555,7 +598,7 @@ static void svd_prof_end(void* u, int launches) {
 }
 static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, UdVSlot out) {
     SvdProfHooks hooks{svd_prof_begin, svd_prof_end, c};
-    int sweeps = run_svd(c->st, c->n_g, M, c->n_g, colscale, rowscale, out.U, out.d, out.Vt, c->sw, c->max_jacobi_sweeps,
+    int sweeps = run_svd(c->lc, c->n_g, M, c->n_g, colscale, rowscale, out.U, out.d, out.Vt, c->sw, c->max_jacobi_sweeps,
                          c->prof ? &hooks : nullptr);
     if (!c->prof && sweeps > 0) c->fam_launches[FAM_JACOBI] += (uint64_t)sweeps * c->sw.nrounds;
     if (sweeps == DQMC_ENOCONV) return fail(DQMC_ENOCONV, "SVD failed (Jacobi did not converge)");
@@ -580,13 +623,13 @@ static int udt_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
     const int n = c->n_g;
     const int transpose = (kind == KIND_L);
     ProfScope ps(c, FAM_JACOBI, 0);
-    launch_scaled_norms_rank(c->st, M, n, colscale, rowscale, transpose, n, c->sw.norms, c->qr_perm, c->sw.rnorms);
-    launch_udt_init(c->st, M, n, colscale, rowscale, c->qr_perm, transpose, c->sw.A, n);
+    launch_scaled_norms_rank(c->lc, M, n, colscale, rowscale, transpose, n, c->sw.norms, c->qr_perm, c->sw.rnorms);
+    launch_udt_init(c->lc, M, n, colscale, rowscale, c->qr_perm, transpose, c->sw.A, n);
     cplx* Q = transpose ? out.Vt : out.U;
     cplx* Tt = transpose ? out.U : out.Vt;
-    int launches = run_qr(c->st, n, c->sw.A, Q, c->qw);
-    launch_udt_diag(c->st, c->sw.A, n, out.d);
-    launch_udt_tmat(c->st, c->sw.A, out.d, c->qr_perm, n, Tt);
+    int launches = run_qr(c->lc, n, c->sw.A, Q, c->qw);
+    launch_udt_diag(c->lc, c->sw.A, n, out.d);
+    launch_udt_tmat(c->lc, c->sw.A, out.d, c->qr_perm, n, Tt);
     c->fam_launches[FAM_JACOBI] += launches + 5;
     c->qr_calls += 1;
     return DQMC_OK;
@@ -602,19 +645,19 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
     const UdVSlot& R = Rp ? *Rp : c->eye;
     {
         ProfScope ps(c, FAM_OTHER, 2);
-        launch_split_scales(c->st, R.d, n, c->rmax_inv, c->rmin);
-        launch_split_scales(c->st, L.d, n, c->lmax_inv, c->lmin);
+        launch_split_scales(c->lc, R.d, n, c->rmax_inv, c->rmin);
+        launch_split_scales(c->lc, L.d, n, c->lmax_inv, c->lmin);
     }
     gemm_dev(c, 1, 0, R.U, L.Vt, c->T2, nullptr, 0, c->rmax_inv, c->lmax_inv, 0);
     gemm_dev(c, 1, 0, R.Vt, L.U, c->T2, nullptr, 0, c->rmin, c->lmin, 1);
     {
         ProfScope ps(c, FAM_JACOBI, 0);
-        launch_scaled_norms_rank(c->st, c->T2, n, nullptr, nullptr, 0, n, c->sw.norms, c->qr_perm, c->sw.rnorms);
-        launch_udt_init(c->st, c->T2, n, nullptr, nullptr, c->qr_perm, 0, c->sw.A, n);
-        int launches = run_qr(c->st, n, c->sw.A, c->T1, c->qw);          // sw.A = R factor, T1 = Q
-        launch_permute_scale_cols(c->st, L.Vt, c->lmax_inv, c->qr_perm, n, c->T3);
-        launches += run_trsm_right_upper(c->st, n, c->sw.A, c->T3, c->qw);   // T3 = (V_l Dlmax^-1 P) R^-1
-        launch_logdet_vector(c->st, c->sw.A, c->rmax_inv, c->lmax_inv, n, c->sv);
+        launch_scaled_norms_rank(c->lc, c->T2, n, nullptr, nullptr, 0, n, c->sw.norms, c->qr_perm, c->sw.rnorms);
+        launch_udt_init(c->lc, c->T2, n, nullptr, nullptr, c->qr_perm, 0, c->sw.A, n);
+        int launches = run_qr(c->lc, n, c->sw.A, c->T1, c->qw);          // sw.A = R factor, T1 = Q
+        launch_permute_scale_cols(c->lc, L.Vt, c->lmax_inv, c->qr_perm, n, c->T3);
+        launches += run_trsm_right_upper(c->lc, n, c->sw.A, c->T3, c->qw);   // T3 = (V_l Dlmax^-1 P) R^-1
+        launch_logdet_vector(c->lc, c->sw.A, c->rmax_inv, c->lmax_inv, n, c->sv);
         c->fam_launches[FAM_JACOBI] += launches + 5;
         c->qr_calls += 1;
     }
@@ -647,7 +690,7 @@ static int green_from_udv(dqmc_ctx* c, const UdVSlot& L, const UdVSlot& R) {
 static int green_from_eye(dqmc_ctx* c, const UdVSlot& R, int kind) {
     if (c->stab == DQMC_STAB_QR) return (kind == KIND_R) ? green_qr(c, nullptr, &R) : green_qr(c, &R, nullptr);
     gemm_dev(c, 1, 0, R.U, R.Vt, c->T2);
-    { ProfScope ps(c, FAM_OTHER, 1); launch_add_diag(c->st, c->T2, R.d, c->n_g); }
+    { ProfScope ps(c, FAM_OTHER, 1); launch_add_diag(c->lc, c->T2, R.d, c->n_g); }
     UdVSlot t = c->tmpudv; t.d = c->sv;
     int rc = udv_dev(c, c->T2, nullptr, nullptr, t);
     if (rc) return rc;
@@ -659,10 +702,11 @@ static int green_from_eye(dqmc_ctx* c, const UdVSlot& R, int kind) {
 
 static int set_slot_identity(dqmc_ctx* c, UdVSlot& sl) {
     ProfScope ps(c, FAM_OTHER, 2);
-    launch_set_identity(c->st, sl.U, c->n_g);
-    launch_set_identity(c->st, sl.Vt, c->n_g);
+    launch_set_identity(c->lc, sl.U, c->n_g);
+    launch_set_identity(c->lc, sl.Vt, c->n_g);
     std::vector<double> ones(c->n_g, 1.0);
-    HIPCHK(hipMemcpyAsync(sl.d, ones.data(), c->n_g * sizeof(double), hipMemcpyHostToDevice, c->st));
+    for (int b = 0; b < c->nb; ++b)
+        HIPCHK(hipMemcpyAsync(chainp(c, sl.d, b), ones.data(), c->n_g * sizeof(double), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     return DQMC_OK;
 }
@@ -674,12 +718,12 @@ extern "C" int dqmc_udv_setup(dqmc_ctx* c) {
     const int n = c->n, s = c->s, m = c->m, ng = c->n_g;
     int rc;
     if ((rc = set_slot_identity(c, c->storage[0]))) return rc;
-    { ProfScope ps(c, FAM_OTHER, 1); launch_set_identity(c->st, c->T1, ng); }
+    { ProfScope ps(c, FAM_OTHER, 1); launch_set_identity(c->lc, c->T1, ng); }
     bmult_dev(c, DQMC_LEFT, 0, s, 0, c->T1);
     if ((rc = decompose(c, c->T1, nullptr, nullptr, KIND_R, c->storage[1]))) return rc;
     for (int l = 1; l <= n - 1; ++l) {
         const int k_l = s * l, k_lp1 = (l < n - 1) ? s * (l + 1) : m;
-        launch_copy(c->st, c->storage[l].U, c->T1, (size_t)ng * ng);
+        launch_copy(c->lc, c->storage[l].U, c->T1, (size_t)ng * ng);
         bmult_dev(c, DQMC_LEFT, 0, k_lp1, k_l, c->T1);
         UdVSlot t = c->storage[l + 1]; t.Vt = c->tmpudv.Vt;
         if ((rc = decompose(c, c->T1, c->storage[l].d, nullptr, KIND_R, t))) return rc;
@@ -709,13 +753,13 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
         UdVSlot L = c->spare;
         if (l < n) {
             const UdVSlot& st = c->storage[l];
-            { ProfScope ps(c, FAM_OTHER, 1); launch_conj_transpose(c->st, st.Vt, c->T1, ng); }
+            { ProfScope ps(c, FAM_OTHER, 1); launch_conj_transpose(c->lc, st.Vt, c->T1, ng); }
             bmult_dev(c, DQMC_RIGHT, 0, k_l, k_lm1, c->T1);
             UdVSlot t = L; t.U = c->tmpudv.U;
             if ((rc = decompose(c, c->T1, nullptr, st.d, KIND_L, t))) return rc;
             gemm_dev(c, 0, 0, st.U, c->tmpudv.U, L.U);
         } else {
-            { ProfScope ps(c, FAM_OTHER, 1); launch_set_identity(c->st, c->T1, ng); }
+            { ProfScope ps(c, FAM_OTHER, 1); launch_set_identity(c->lc, c->T1, ng); }
             bmult_dev(c, DQMC_RIGHT, 0, k_l, k_lm1, c->T1);
             if ((rc = decompose(c, c->T1, nullptr, nullptr, KIND_L, L))) return rc;
         }
@@ -731,7 +775,7 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
         if (c->currentTimeslice != k_lp1) return fail(DQMC_EINVAL, "advanceUp: currentTimeslice != k_{l+1}");
         const UdVSlot& st = c->storage[l];
         UdVSlot T = c->spare;
-        launch_copy(c->st, st.U, c->T1, (size_t)ng * ng);
+        launch_copy(c->lc, st.U, c->T1, (size_t)ng * ng);
         bmult_dev(c, DQMC_LEFT, 0, k_lp1, k_l, c->T1);
         UdVSlot t = T; t.Vt = c->tmpudv.Vt;
         if ((rc = decompose(c, c->T1, st.d, nullptr, KIND_R, t))) return rc;
@@ -771,17 +815,12 @@ extern "C" int dqmc_wrap(dqmc_ctx* c, int dir, int k) {
 extern "C" int dqmc_push_uniforms_host(dqmc_ctx* c, const double* u, size_t nvals) {
     if (!c || (!u && nvals)) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
-    if (nvals > c->uni_cap) {
-        double* nb;
-        HIPCHK(hipStreamSynchronize(c->st));
-        HIPCHK(hipMalloc((void**)&nb, nvals * sizeof(double)));
-        c->allocs.push_back(nb);
-        c->uniforms = nb; c->uni_cap = nvals;
-    }
+    if (nvals > c->uni_cap)
+        return fail(DQMC_EINVAL, "more uniforms than one sweep can consume ((opdim+1)*N*m + 64)");
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(c->uniforms, u, nvals * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(selp(c, c->uniforms), u, nvals * sizeof(double), hipMemcpyHostToDevice));
     uint64_t vals[2] = {0, (uint64_t)nvals};
-    HIPCHK(hipMemcpy((char*)c->us + offsetof(DevUpdateState, pub) + offsetof(dqmc_update_state, rng_consumed), vals,
+    HIPCHK(hipMemcpy((char*)selp(c, c->us) + offsetof(DevUpdateState, pub) + offsetof(dqmc_update_state, rng_consumed), vals,
                      sizeof(vals), hipMemcpyHostToDevice));
     return DQMC_OK;
 }
@@ -796,18 +835,18 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     for (int r = 0; r < rounds; ++r) {
         {
             ProfScope ps(c, FAM_UPDATE, 1);
-            launch_update_decide(c->st, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, thermalization);
+            launch_update_decide(c->lc, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, thermalization);
         }
         {
             ProfScope ps(c, FAM_GATHER, 1);
-            launch_update_gather(c->st, c->hm, c->us, c->G, c->W, c->X, c->Gr);
+            launch_update_gather(c->lc, c->hm, c->us, c->G, c->W, c->X, c->Gr);
         }
         GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.A = c->X; g.lda = c->n_g; g.opA = 0; g.B = c->Gr; g.ldb = WD; g.opB = 0; g.C = c->G; g.ldc = c->n_g;
         g.M = g.N = c->n_g; g.K = WD; g.Kdev = &c->us->block_j; g.Kmul = c->MSF; g.accumulate = 1;
         ProfScope ps(c, FAM_FLUSH, 1);
-        launch_gemm(c->st, g);
+        launch_gemm(c->lc, g);
     }
     return DQMC_OK;
 }
@@ -816,7 +855,7 @@ extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(out, &c->us->pub, sizeof(*out), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, &selp(c, c->us)->pub, sizeof(*out), hipMemcpyDeviceToHost));
     if (out->error) return fail(out->error, "device ran out of pre-drawn uniforms");
     return DQMC_OK;
 }
@@ -824,7 +863,7 @@ extern "C" int dqmc_set_update_state_host(dqmc_ctx* c, const dqmc_update_state* 
     if (!c || !in) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(&c->us->pub, in, sizeof(*in), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(&selp(c, c->us)->pub, in, sizeof(*in), hipMemcpyHostToDevice));
     return DQMC_OK;
 }
 
@@ -836,9 +875,10 @@ extern "C" int dqmc_bmult_host(dqmc_ctx* c, int side, int inverse, int k2, int k
     (void)hipSetDevice(c->p.device);
     if (!(k2 > k1) || k2 > c->m || k1 < 0) return fail(DQMC_EINVAL, "need 0 <= k1 < k2 <= m");
     const size_t n2 = (size_t)c->n_g * c->n_g;
-    HIPCHK(hipMemcpyAsync(c->T1, A, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
+    for (int b = 0; b < c->nb; ++b)     // every chain gets the input; the selected chain's result is returned
+        HIPCHK(hipMemcpyAsync(chainp(c, c->T1, b), A, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
     bmult_dev(c, side, inverse, k2, k1, c->T1);
-    HIPCHK(hipMemcpyAsync(A, c->T1, n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(A, selp(c, c->T1), n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipGetLastError());
     return DQMC_OK;
@@ -849,13 +889,14 @@ extern "C" int dqmc_udv_decompose_host(dqmc_ctx* c, const dqmc_cplx* M, dqmc_cpl
     if (!c || !M || !U || !d || !V_t) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     const size_t n2 = (size_t)c->n_g * c->n_g;
-    HIPCHK(hipMemcpyAsync(c->T1, M, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
+    for (int b = 0; b < c->nb; ++b)
+        HIPCHK(hipMemcpyAsync(chainp(c, c->T1, b), M, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
     int rc = decompose(c, c->T1, nullptr, nullptr, KIND_R, c->tmpudv);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(U, c->tmpudv.U, n2 * sizeof(cplx), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(d, c->tmpudv.d, c->n_g * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(V_t, c->tmpudv.Vt, n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(U, selp(c, c->tmpudv.U), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(d, selp(c, c->tmpudv.d), c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(V_t, selp(c, c->tmpudv.Vt), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
     if (sweeps_used) *sweeps_used = c->last_svd_sweeps;
     return DQMC_OK;
 }
@@ -864,10 +905,12 @@ extern "C" int dqmc_gemm_host(dqmc_ctx* c, int opA, int opB, const dqmc_cplx* A,
     if (!c || !A || !B || !C) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     const size_t n2 = (size_t)c->n_g * c->n_g;
-    HIPCHK(hipMemcpyAsync(c->T1, A, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->T2, B, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
+    for (int b = 0; b < c->nb; ++b) {
+        HIPCHK(hipMemcpyAsync(chainp(c, c->T1, b), A, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
+        HIPCHK(hipMemcpyAsync(chainp(c, c->T2, b), B, n2 * sizeof(cplx), hipMemcpyHostToDevice, c->st));
+    }
     gemm_dev(c, opA, opB, c->T1, c->T2, c->T3);
-    HIPCHK(hipMemcpyAsync(C, c->T3, n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(C, selp(c, c->T3), n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipGetLastError());
     return DQMC_OK;
@@ -877,14 +920,14 @@ extern "C" int dqmc_get_green_host(dqmc_ctx* c, dqmc_cplx* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(out, c->G, (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, selp(c, c->G), (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 extern "C" int dqmc_set_green_host(dqmc_ctx* c, const dqmc_cplx* in, int currentTimeslice) {
     if (!c || !in) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(c->G, in, (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(selp(c, c->G), in, (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyHostToDevice));
     c->currentTimeslice = currentTimeslice;
     return DQMC_OK;
 }
@@ -892,7 +935,7 @@ extern "C" int dqmc_get_sv_host(dqmc_ctx* c, double* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(out, c->sv, c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, selp(c, c->sv), c->n_g * sizeof(double), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 extern "C" int dqmc_get_udv_host(dqmc_ctx* c, int l, dqmc_cplx* U, double* d, dqmc_cplx* V_t) {
@@ -901,15 +944,17 @@ extern "C" int dqmc_get_udv_host(dqmc_ctx* c, int l, dqmc_cplx* U, double* d, dq
     if (l < 0 || l > c->n) return fail(DQMC_EINVAL, "l out of range");
     const size_t n2 = (size_t)c->n_g * c->n_g;
     HIPCHK(hipStreamSynchronize(c->st));
-    if (U) HIPCHK(hipMemcpy(U, c->storage[l].U, n2 * sizeof(cplx), hipMemcpyDeviceToHost));
-    if (d) HIPCHK(hipMemcpy(d, c->storage[l].d, c->n_g * sizeof(double), hipMemcpyDeviceToHost));
-    if (V_t) HIPCHK(hipMemcpy(V_t, c->storage[l].Vt, n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    if (U) HIPCHK(hipMemcpy(U, selp(c, c->storage[l].U), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    if (d) HIPCHK(hipMemcpy(d, selp(c, c->storage[l].d), c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    if (V_t) HIPCHK(hipMemcpy(V_t, selp(c, c->storage[l].Vt), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 extern "C" int dqmc_current_timeslice(dqmc_ctx* c) { return c ? c->currentTimeslice : -1; }
 
-// globalMoveStoreBackups / RestoreBackups (detsdwopdim.cpp:3886-3917): the matrices that are fully
-// recomputed by the move are swapped, the fields copied
+// globalMoveStoreBackups / RestoreBackups (detsdwopdim.cpp:3886-3917).  Backup (all chains): the fields are
+// copied, the matrices the move recomputes from scratch (G, sv, UdV storage) swap roles with their backup
+// buffers -- the same swap for every chain, so the chains keep one arena layout.  Restore (the selected
+// chain only: each chain accepts or rejects its own move): copies that chain's backup back.
 static void swap_state(dqmc_ctx* c) {
     std::swap(c->G, c->G_bak);
     std::swap(c->sv, c->sv_bak);
@@ -919,9 +964,9 @@ extern "C" int dqmc_backup(dqmc_ctx* c) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
     (void)hipSetDevice(c->p.device);
     const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
-    HIPCHK(hipMemcpyAsync(c->phi_bak, c->phi, nphi * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->cosh_bak, c->coshT, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->sinh_bak, c->sinhT, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    launch_copy_bytes(c->lc, c->phi, c->phi_bak, nphi * sizeof(double));
+    launch_copy_bytes(c->lc, c->coshT, c->cosh_bak, ncs * sizeof(double));
+    launch_copy_bytes(c->lc, c->sinhT, c->sinh_bak, ncs * sizeof(double));
     swap_state(c);
     return DQMC_OK;
 }
@@ -929,10 +974,19 @@ extern "C" int dqmc_restore(dqmc_ctx* c) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
     (void)hipSetDevice(c->p.device);
     const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
-    HIPCHK(hipMemcpyAsync(c->phi, c->phi_bak, nphi * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->coshT, c->cosh_bak, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->sinhT, c->sinh_bak, ncs * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-    swap_state(c);
+    const size_t n2b = (size_t)c->n_g * c->n_g * sizeof(cplx), nb1 = (size_t)c->n_g * sizeof(double);
+#define CP_(dst, src, bytes) HIPCHK(hipMemcpyAsync(selp(c, dst), selp(c, src), bytes, hipMemcpyDeviceToDevice, c->st))
+    CP_(c->phi, c->phi_bak, nphi * sizeof(double));
+    CP_(c->coshT, c->cosh_bak, ncs * sizeof(double));
+    CP_(c->sinhT, c->sinh_bak, ncs * sizeof(double));
+    CP_(c->G, c->G_bak, n2b);
+    CP_(c->sv, c->sv_bak, nb1);
+    for (int l = 0; l <= c->n; ++l) {
+        CP_(c->storage[l].U, c->storage_bak[l].U, n2b);
+        CP_(c->storage[l].d, c->storage_bak[l].d, nb1);
+        CP_(c->storage[l].Vt, c->storage_bak[l].Vt, n2b);
+    }
+#undef CP_
     c->currentTimeslice = c->m;
     return DQMC_OK;
 }
@@ -940,18 +994,20 @@ extern "C" int dqmc_restore(dqmc_ctx* c) {
 extern "C" int dqmc_exchange_action_host(dqmc_ctx* c, double* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
-    { ProfScope ps(c, FAM_OTHER, 1); launch_phi_sq_sum(c->st, c->hm, c->scalar_out); }
+    { ProfScope ps(c, FAM_OTHER, 1); launch_phi_sq_sum(c->lc, c->hm, c->scalar_out); }
     HIPCHK(hipStreamSynchronize(c->st));
     double v;
-    HIPCHK(hipMemcpy(&v, c->scalar_out, sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&v, selp(c, c->scalar_out), sizeof(double), hipMemcpyDeviceToHost));
     *out = 0.5 * c->p.dtau * v;
     return DQMC_OK;
 }
 
 extern "C" int dqmc_set_exchange_parameter(dqmc_ctx* c, double r) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
-    c->p.r = r;
-    c->hm.r = r;     // kernels receive the model by value at every launch
+    (void)hipSetDevice(c->p.device);
+    if (c->sel == 0) { c->p.r = r; c->hm.r = r; }
+    HIPCHK(hipStreamSynchronize(c->st));     // the decision kernel reads DevUpdateState::r of its chain
+    HIPCHK(hipMemcpy((char*)selp(c, c->us) + offsetof(DevUpdateState, r), &r, sizeof(double), hipMemcpyHostToDevice));
     return DQMC_OK;
 }
 

@@ -10,6 +10,17 @@ typedef double2 cplx;   // .x = re, .y = im; same bytes as dqmc_cplx / std::comp
 #define DQMC_MAX_MSF 4
 #define DQMC_MAX_WDIM 64          // MSF * delaySteps <= 64 (W lives in LDS in the decision kernel)
 
+// ---- batched chains ---------------------------------------------------------------------------
+// One context can run nb independent Markov chains (replicas) in lockstep.  Every per-chain device buffer of
+// chain b lives at (address of chain 0's buffer) + b * cs: all chains share one arena layout.  Kernels are
+// launched with gridDim.z = nb and shift their per-chain pointer arguments by blockIdx.z * cs; read-only
+// tables (plaquette tables, neighbours, tournament schedule) are shared and never shifted.
+struct Launch { hipStream_t st; int nb; size_t cs; };
+template<class T> __device__ __forceinline__ T* chain_ptr(T* p, size_t cs) {
+    return p ? (T*)((char*)p + (size_t)blockIdx.z * cs) : p;
+}
+#define CHAIN(p) p = chain_ptr(p, cs)
+
 // Everything a kernel needs to know about the model; lives in device memory, one per context.
 struct DevModel {
     int opdim, MSF, L, N, ng, m, s, n, D, P;   // P = plaquettes per subgroup = N/4
@@ -17,7 +28,7 @@ struct DevModel {
     int dbg;           // developer timing experiments only (DQMC_DBG env var); 0 in production
     int dense;         // CB_NONE: the hopping part is a dense GEMM done by the host loop, the chain kernel
                        // only applies e^{+-dtau V}; ov/ovinv are 1 (mu sits inside propK)
-    double dtau, r, c, u, lambda;
+    double dtau, r, c, u, lambda;   // r: chain 0's value at create time only -- kernels read DevUpdateState::r
     double ov[2];      // e^{+dtau mu_band}   (detsdwopdim.cpp:2037-2038)
     double ovinv[2];   // e^{-dtau mu_band}   (detsdwopdim.cpp:2137-2138)
     // plaquette sites [sub][P][4] (sub 0: even corners, sub 1: odd corners; detsdwopdim.cpp:1776-1785)
@@ -32,6 +43,10 @@ struct DevModel {
     double* sinhT;     // [m+1][N]
     const int* neigh;  // [4][N]  XPLUS, XMINUS, YPLUS, YMINUS (neighbortable.h:34-36)
 };
+__device__ __forceinline__ DevModel chain_model(DevModel dm, size_t cs) {
+    dm.phi = chain_ptr(dm.phi, cs); dm.coshT = chain_ptr(dm.coshT, cs); dm.sinhT = chain_ptr(dm.sinhT, cs);
+    return dm;
+}
 
 struct DevUpdateState {
     dqmc_update_state pub;   // mirrored to the host on request
@@ -39,12 +54,13 @@ struct DevUpdateState {
     int acc_count;           // accepted proposals in the current slice
     int block_j;             // accepted updates in the block the last decision launch produced
     int slice_done;
+    double r;                // this chain's exchange parameter (differs between the chains of a batch)
     int block_sites[DQMC_MAX_WDIM];
 };
 
 // ---- launchers (implemented in the kernels_*.hip files) ---------------------------------------
 // checkerboard chain: A <- prod B_k A etc. for k = kfirst, kfirst+kstep, ... (count slices)
-void launch_bmult(hipStream_t st, const DevModel* dm, const DevModel& hm, int side, int inverse,
+void launch_bmult(const Launch& lc, const DevModel* dm, const DevModel& hm, int side, int inverse,
                   int kfirst, int kstep, int kcount, cplx* A, int lda);
 
 // C = alpha-less complex GEMM on MFMA f64: C[MxN] (+)= op(A)[MxK] . diag(kscale) . op(B)[KxN]
@@ -60,8 +76,9 @@ struct GemmArgs {
     const double* rowscale;     // optional epilogue: acc *= rowscale[i] * colscale[j]
     const double* colscale;
     int accumulate;             // C += instead of C =
+    int sharedA, sharedB;       // operand is one matrix for all chains (not shifted by the chain stride)
 };
-void launch_gemm(hipStream_t st, const GemmArgs& a);
+void launch_gemm(const Launch& lc, const GemmArgs& a);
 
 // one-sided Jacobi SVD, M = U diag(d) V^H, d descending.  work: A (n*n), V (n*n), norms(n), rank(n),
 // flag (int).  Host-driven sweep loop with one flag read-back per sweep.  Returns sweeps used or <0.
@@ -77,35 +94,36 @@ struct SvdWork {
 };
 // optional timing hooks around each batch of back-to-back round launches (one Jacobi sweep)
 struct SvdProfHooks { void (*begin)(void* user); void (*end)(void* user, int launches); void* user; };
-int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscale, const double* rowscale,
+int run_svd(const Launch& lc, int n, const cplx* M, int ldm, const double* colscale, const double* rowscale,
             cplx* U, double* d, cplx* Vt, const SvdWork& w, int max_sweeps, const SvdProfHooks* hooks = nullptr);
 int svd_block_cols(int n);      // columns per block used by the Jacobi kernel for this n
 
 // local updates
-void launch_update_decide(hipStream_t st, const DevModel* dm, const DevModel& hm, DevUpdateState* us,
+void launch_update_decide(const Launch& lc, const DevModel* dm, const DevModel& hm, DevUpdateState* us,
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal);
-void launch_update_gather(hipStream_t st, const DevModel& hm, const DevUpdateState* us, const cplx* G,
+void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,
                           const cplx* W, cplx* X, cplx* Gr);
 
 // misc elementwise
-void launch_cosh_sinh(hipStream_t st, const DevModel& hm);
-void launch_set_identity(hipStream_t st, cplx* A, int n);
-void launch_conj_transpose(hipStream_t st, const cplx* A, cplx* B, int n);
-void launch_add_diag(hipStream_t st, cplx* A, const double* d, int n);
-void launch_copy(hipStream_t st, const cplx* A, cplx* B, size_t count);
-void launch_phi_sq_sum(hipStream_t st, const DevModel& hm, double* out);
+void launch_cosh_sinh(const Launch& lc, const DevModel& hm);
+void launch_set_identity(const Launch& lc, cplx* A, int n);
+void launch_conj_transpose(const Launch& lc, const cplx* A, cplx* B, int n);
+void launch_add_diag(const Launch& lc, cplx* A, const double* d, int n);
+void launch_copy(const Launch& lc, const cplx* A, cplx* B, size_t count);
+void launch_copy_bytes(const Launch& lc, const void* src, void* dst, size_t bytes);   // same buffer of every chain
+void launch_phi_sq_sum(const Launch& lc, const DevModel& hm, double* out);
 
 // ---- QR / UDT building blocks (kernels_qr.hip) ------------------------------------------------
 struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; };
-int run_qr(hipStream_t st, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit
-int run_trsm_right_upper(hipStream_t st, int n, const cplx* R, cplx* C, const QrWork& w);   // C <- C R^-1
-void launch_udt_init(hipStream_t st, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,
+int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit
+int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w);   // C <- C R^-1
+void launch_udt_init(const Launch& lc, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,
                      int transpose, cplx* W, int n);
-void launch_udt_diag(hipStream_t st, const cplx* R, int n, double* d);
-void launch_udt_tmat(hipStream_t st, const cplx* R, const double* d, const int* perm, int n, cplx* Tt);
-void launch_permute_scale_cols(hipStream_t st, const cplx* X, const double* cs, const int* perm, int n, cplx* Y);
-void launch_split_scales(hipStream_t st, const double* d, int n, double* dmax_inv, double* dmin);
-void launch_logdet_vector(hipStream_t st, const cplx* R, const double* a, const double* b, int n, double* sv);
+void launch_udt_diag(const Launch& lc, const cplx* R, int n, double* d);
+void launch_udt_tmat(const Launch& lc, const cplx* R, const double* d, const int* perm, int n, cplx* Tt);
+void launch_permute_scale_cols(const Launch& lc, const cplx* X, const double* cs, const int* perm, int n, cplx* Y);
+void launch_split_scales(const Launch& lc, const double* d, int n, double* dmax_inv, double* dmin);
+void launch_logdet_vector(const Launch& lc, const cplx* R, const double* a, const double* b, int n, double* sv);
 // column norms / ranks shared with the SVD path (kernels_svd.hip)
-void launch_scaled_norms_rank(hipStream_t st, const cplx* M, int ldm, const double* cs, const double* rs, int transpose,
+void launch_scaled_norms_rank(const Launch& lc, const cplx* M, int ldm, const double* cs, const double* rs, int transpose,
                               int n, double* norms, int* rank, double* scratch_d);

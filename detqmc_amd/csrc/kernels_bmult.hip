@@ -14,6 +14,7 @@
 // a UdV chain cost ONE read and ONE write of A instead of s -- and streams them back.  Column
 // vectors are contiguous in the column-major matrix; row vectors are staged as 64-byte pieces.
 #include "dqmc_internal.h"
+#include <algorithm>
 
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
@@ -56,8 +57,9 @@ __device__ __forceinline__ void build_V(cplx (&V)[MSF][MSF], double sign, double
 
 template<int MSF, bool RIGHT, bool INV>
 __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restrict__ A, int lda, int nvec,
-                                                      int kfirst, int kstep, int kcount) {
+                                                      int kfirst, int kstep, int kcount, size_t cs) {
     extern __shared__ cplx sm[];
+    dm = chain_model(dm, cs); CHAIN(A);
     const int N = dm.N, ng = dm.ng, P = dm.P;
     const int v0 = blockIdx.x * nvec;
     const int nv = min(nvec, ng - v0);
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
     }
 }
 
-void launch_bmult(hipStream_t st, const DevModel* /*dm*/, const DevModel& hm, int side, int inverse,
+void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, int side, int inverse,
                   int kfirst, int kstep, int kcount, cplx* A, int lda) {
     const int ng = hm.ng;
     const int max_fit = (int)(65536 / ((size_t)ng * sizeof(cplx)));   // keep <= 64 KiB of LDS
@@ -191,8 +193,8 @@ void launch_bmult(hipStream_t st, const DevModel* /*dm*/, const DevModel& hm, in
     const int grid = (ng + nvec - 1) / nvec;
     const size_t lds = (size_t)nvec * ng * sizeof(cplx);
 #define LAUNCH(MSFV, R, I)                                                                              \
-    hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I>), dim3(grid), dim3(256), lds, st, hm, A, lda, nvec, \
-                       kfirst, kstep, kcount)
+    hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I>), dim3(grid, 1, lc.nb), dim3(256), lds, lc.st, hm, A, lda, nvec, \
+                       kfirst, kstep, kcount, lc.cs)
     if (hm.MSF == 2) {
         if (side == DQMC_LEFT) { if (!inverse) LAUNCH(2, false, false); else LAUNCH(2, false, true); }
         else                   { if (!inverse) LAUNCH(2, true, false);  else LAUNCH(2, true, true); }
@@ -207,7 +209,8 @@ void launch_bmult(hipStream_t st, const DevModel* /*dm*/, const DevModel& hm, in
 // small elementwise helpers
 // ---------------------------------------------------------------------------------------------
 // updateCoshSinhTermsPhi (detsdwopdim.cpp:1132-1136, 1175-1181)
-__global__ void k_cosh_sinh(DevModel dm) {
+__global__ void k_cosh_sinh(DevModel dm, size_t cs) {
+    dm = chain_model(dm, cs);
     const int total = dm.m * dm.N;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         int k = 1 + idx / dm.N, i = idx % dm.N;
@@ -222,25 +225,28 @@ __global__ void k_cosh_sinh(DevModel dm) {
         dm.sinhT[(size_t)k * dm.N + i] = sinh(a) / nrm;
     }
 }
-void launch_cosh_sinh(hipStream_t st, const DevModel& hm) {
+void launch_cosh_sinh(const Launch& lc, const DevModel& hm) {
     int total = hm.m * hm.N;
-    hipLaunchKernelGGL(k_cosh_sinh, dim3((total + 255) / 256), dim3(256), 0, st, hm);
+    hipLaunchKernelGGL(k_cosh_sinh, dim3((total + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, hm, lc.cs);
 }
 
-__global__ void k_set_identity(cplx* A, int n) {
+__global__ void k_set_identity(cplx* A, int n, size_t cs) {
+    CHAIN(A);
     size_t total = (size_t)n * n;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(idx % n), j = (int)(idx / n);
         A[idx] = make_double2(i == j ? 1.0 : 0.0, 0.0);
     }
 }
-void launch_set_identity(hipStream_t st, cplx* A, int n) {
-    hipLaunchKernelGGL(k_set_identity, dim3(1024), dim3(256), 0, st, A, n);
+void launch_set_identity(const Launch& lc, cplx* A, int n) {
+    const int blocks = (int)std::min<size_t>(1024, ((size_t)n * n + 255) / 256);
+    hipLaunchKernelGGL(k_set_identity, dim3(blocks, 1, lc.nb), dim3(256), 0, lc.st, A, n, lc.cs);
 }
 
 // B = A^H through a 32x32 LDS tile (both sides coalesced)
-__global__ void k_conj_transpose(const cplx* __restrict__ A, cplx* __restrict__ B, int n) {
+__global__ void k_conj_transpose(const cplx* __restrict__ A, cplx* __restrict__ B, int n, size_t cs) {
     __shared__ cplx tile[32][33];
+    CHAIN(A); CHAIN(B);
     int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
     for (int r = ty; r < 32; r += 8) {
@@ -256,27 +262,41 @@ __global__ void k_conj_transpose(const cplx* __restrict__ A, cplx* __restrict__ 
         }
     }
 }
-void launch_conj_transpose(hipStream_t st, const cplx* A, cplx* B, int n) {
-    dim3 grid((n + 31) / 32, (n + 31) / 32);
-    hipLaunchKernelGGL(k_conj_transpose, grid, dim3(256), 0, st, A, B, n);
+void launch_conj_transpose(const Launch& lc, const cplx* A, cplx* B, int n) {
+    dim3 grid((n + 31) / 32, (n + 31) / 32, lc.nb);
+    hipLaunchKernelGGL(k_conj_transpose, grid, dim3(256), 0, lc.st, A, B, n, lc.cs);
 }
 
-__global__ void k_add_diag(cplx* A, const double* d, int n) {
+__global__ void k_add_diag(cplx* A, const double* d, int n, size_t cs) {
+    CHAIN(A); CHAIN(d);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) A[(size_t)i * n + i].x += d[i];
 }
-void launch_add_diag(hipStream_t st, cplx* A, const double* d, int n) {
-    hipLaunchKernelGGL(k_add_diag, dim3((n + 255) / 256), dim3(256), 0, st, A, d, n);
+void launch_add_diag(const Launch& lc, cplx* A, const double* d, int n) {
+    hipLaunchKernelGGL(k_add_diag, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, A, d, n, lc.cs);
 }
 
-void launch_copy(hipStream_t st, const cplx* A, cplx* B, size_t count) {
-    (void)hipMemcpyAsync(B, A, count * sizeof(cplx), hipMemcpyDeviceToDevice, st);
+// the same buffer of every chain (bytes must be a multiple of 8: all per-chain buffers are doubles / cplx)
+__global__ void k_copy64(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, size_t words, size_t cs) {
+    CHAIN(src); CHAIN(dst);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_copy_bytes(const Launch& lc, const void* src, void* dst, size_t bytes) {
+    if (lc.nb == 1) { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, lc.st); return; }
+    const size_t words = bytes / 8;
+    const int blocks = (int)std::min<size_t>(2048, (words + 255) / 256);
+    hipLaunchKernelGGL(k_copy64, dim3(blocks, 1, lc.nb), dim3(256), 0, lc.st, (const unsigned long long*)src,
+                       (unsigned long long*)dst, words, lc.cs);
+}
+void launch_copy(const Launch& lc, const cplx* A, cplx* B, size_t count) {
+    launch_copy_bytes(lc, A, B, count * sizeof(cplx));
 }
 
 // sum over slices 1..m, sites and components of phi^2 (get_exchange_action_contribution,
 // detsdwopdim.cpp:5205-5216); single workgroup, fixed summation order => reproducible
-__global__ void k_phi_sq_sum(DevModel dm, double* out) {
+__global__ void k_phi_sq_sum(DevModel dm, double* out, size_t cs) {
     __shared__ double red[256];
+    dm = chain_model(dm, cs); CHAIN(out);
     double acc = 0.0;
     size_t total = (size_t)dm.m * dm.opdim * dm.N;
     const double* p = dm.phi + (size_t)dm.opdim * dm.N;   // skip slice 0
@@ -289,6 +309,6 @@ __global__ void k_phi_sq_sum(DevModel dm, double* out) {
     }
     if (threadIdx.x == 0) out[0] = red[0];
 }
-void launch_phi_sq_sum(hipStream_t st, const DevModel& hm, double* out) {
-    hipLaunchKernelGGL(k_phi_sq_sum, dim3(1), dim3(256), 0, st, hm, out);
+void launch_phi_sq_sum(const Launch& lc, const DevModel& hm, double* out) {
+    hipLaunchKernelGGL(k_phi_sq_sum, dim3(1, 1, lc.nb), dim3(256), 0, lc.st, hm, out, lc.cs);
 }

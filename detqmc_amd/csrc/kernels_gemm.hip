@@ -20,7 +20,11 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 template<int TM, int TN>
-__global__ __launch_bounds__(256) void k_zgemm(GemmArgs g) {
+__global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs) {
+    if (!g.sharedA) g.A = chain_ptr(g.A, cs);
+    if (!g.sharedB) g.B = chain_ptr(g.B, cs);
+    g.C = chain_ptr(g.C, cs); g.Kdev = chain_ptr(g.Kdev, cs); g.kscale = chain_ptr(g.kscale, cs);
+    g.rowscale = chain_ptr(g.rowscale, cs); g.colscale = chain_ptr(g.colscale, cs);
     constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16;
     __shared__ cplx sA[BK][BM + 1];
     __shared__ cplx sB[BK][BN + 1];
@@ -112,14 +116,14 @@ __global__ __launch_bounds__(256) void k_zgemm(GemmArgs g) {
             }
 }
 
-void launch_gemm(hipStream_t st, const GemmArgs& a) {
+void launch_gemm(const Launch& lc, const GemmArgs& a) {
     // fill the chip: 64x64 tiles only when they still give >= 256 workgroups
-    long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * lc.nb;
     if (tiles64 >= 256) {
-        dim3 grid((a.M + 63) / 64, (a.N + 63) / 64);
-        hipLaunchKernelGGL((k_zgemm<2, 2>), grid, dim3(256), 0, st, a);
+        dim3 grid((a.M + 63) / 64, (a.N + 63) / 64, lc.nb);
+        hipLaunchKernelGGL((k_zgemm<2, 2>), grid, dim3(256), 0, lc.st, a, lc.cs);
     } else {
-        dim3 grid((a.M + 31) / 32, (a.N + 31) / 32);
-        hipLaunchKernelGGL((k_zgemm<1, 1>), grid, dim3(256), 0, st, a);
+        dim3 grid((a.M + 31) / 32, (a.N + 31) / 32, lc.nb);
+        hipLaunchKernelGGL((k_zgemm<1, 1>), grid, dim3(256), 0, lc.st, a, lc.cs);
     }
 }

@@ -206,8 +206,9 @@ struct QrPanelState {
 // -T into Tn[NB*NB].
 template<int RPT>
 __global__ __launch_bounds__(256) void k_qr_panel(cplx* __restrict__ A, int lda, int n, int j0,
-                                                   cplx* __restrict__ Vp, cplx* __restrict__ Tp, cplx* __restrict__ Tn) {
+                                                   cplx* __restrict__ Vp, cplx* __restrict__ Tp, cplx* __restrict__ Tn, size_t cs) {
     __shared__ double red[2][4][2 * QR_NB];
+    CHAIN(A); CHAIN(Vp); CHAIN(Tp); CHAIN(Tn);
     __shared__ cplx sT[QR_NB * QR_NB];
     __shared__ cplx sTau[QR_NB];
     __shared__ double sBeta[QR_NB];
@@ -263,8 +264,9 @@ __global__ __launch_bounds__(256) void k_qr_panel(cplx* __restrict__ A, int lda,
 // small GEMMs (W = V^H C, W2 = -op(T) W, C += V W2); V and C are streamed through LDS in 64-row chunks.
 template<bool TRANS_T>
 __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, int ldv, const cplx* __restrict__ Tn,
-                                                   cplx* __restrict__ C, int ldc, int rows, int ncols, int nb) {
+                                                   cplx* __restrict__ C, int ldc, int rows, int ncols, int nb, size_t cs) {
     __shared__ cplx sV[64][QR_NB + 1];
+    CHAIN(Vp); CHAIN(Tn); CHAIN(C);
     __shared__ cplx sC[64][QR_NB + 1];
     __shared__ cplx sW[QR_NB][QR_NB + 1];      // W, then W2, as [k][j]
     __shared__ cplx sT[QR_NB][QR_NB + 1];      // -T as [i][k]
@@ -340,28 +342,28 @@ __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, i
 // ---------------------------------------------------------------------------------------------
 // driver: A (n x n, ld n) -> R in place (strict lower part zeroed), Q explicit; V/T workspace
 // ---------------------------------------------------------------------------------------------
-static void gemm_small(hipStream_t st, int opA, int opB, const cplx* A, int lda, const cplx* B, int ldb, cplx* C, int ldc,
+static void gemm_small(const Launch& lc, int opA, int opB, const cplx* A, int lda, const cplx* B, int ldb, cplx* C, int ldc,
                        int M, int N, int K, int accumulate) {
     GemmArgs g = GemmArgs();
     g.A = A; g.lda = lda; g.opA = opA; g.B = B; g.ldb = ldb; g.opB = opB; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.Kmul = 1; g.accumulate = accumulate;
-    launch_gemm(st, g);
+    launch_gemm(lc, g);
 }
 
-static void launch_panel(hipStream_t st, cplx* A, int n, int j0, cplx* V, cplx* Tp, cplx* Tn) {
+static void launch_panel(const Launch& lc, cplx* A, int n, int j0, cplx* V, cplx* Tp, cplx* Tn) {
     const int rows = n - j0;
     const int rpt = (rows + 255) / 256;
     switch (rpt) {
-        case 1: hipLaunchKernelGGL((k_qr_panel<1>), dim3(1), dim3(256), 0, st, A, n, n, j0, V, Tp, Tn); break;
-        case 2: hipLaunchKernelGGL((k_qr_panel<2>), dim3(1), dim3(256), 0, st, A, n, n, j0, V, Tp, Tn); break;
-        case 3: hipLaunchKernelGGL((k_qr_panel<3>), dim3(1), dim3(256), 0, st, A, n, n, j0, V, Tp, Tn); break;
-        case 4: hipLaunchKernelGGL((k_qr_panel<4>), dim3(1), dim3(256), 0, st, A, n, n, j0, V, Tp, Tn); break;
+        case 1: hipLaunchKernelGGL((k_qr_panel<1>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+        case 2: hipLaunchKernelGGL((k_qr_panel<2>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+        case 3: hipLaunchKernelGGL((k_qr_panel<3>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+        case 4: hipLaunchKernelGGL((k_qr_panel<4>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
         default: break;     // n <= 1024 enforced by the caller
     }
 }
 
 // returns number of kernel launches issued (for the profiling counters)
-int run_qr(hipStream_t st, int n, cplx* A, cplx* Q, const QrWork& w) {
+int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
     int launches = 0;
     const int np = (n + QR_NB - 1) / QR_NB;
     for (int p = 0; p < np; ++p) {
@@ -369,19 +371,19 @@ int run_qr(hipStream_t st, int n, cplx* A, cplx* Q, const QrWork& w) {
         const int nb = (n - j0 < QR_NB) ? (n - j0) : QR_NB;   // n is a multiple of 8: a last half panel is padded by the kernel guards
         cplx* Tp = w.T + (size_t)p * 2 * QR_NB * QR_NB;
         cplx* Tn = Tp + QR_NB * QR_NB;
-        launch_panel(st, A, n, j0, w.V, Tp, Tn);
+        launch_panel(lc, A, n, j0, w.V, Tp, Tn);
         ++launches;
         const int rows = n - j0, ntrail = n - j0 - nb;
         if (ntrail > 0) {
             const cplx* Vp = w.V + (size_t)j0 * n + j0;
             cplx* C = A + (size_t)(j0 + nb) * n + j0;
             // apply Q_p^H = I - V T^H V^H to the trailing columns
-            hipLaunchKernelGGL((k_qr_apply<true>), dim3((ntrail + QR_NB - 1) / QR_NB), dim3(256), 0, st, Vp, n, Tn, C, n, rows, ntrail, nb);
+            hipLaunchKernelGGL((k_qr_apply<true>), dim3((ntrail + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ntrail, nb, lc.cs);
             launches += 1;
         }
     }
     // ---- Q = H_0 H_1 ... applied to the identity, block reflectors in reverse order (zungqr) ----
-    launch_set_identity(st, Q, n);
+    launch_set_identity(lc, Q, n);
     ++launches;
     for (int p = np - 1; p >= 0; --p) {
         const int j0 = p * QR_NB;
@@ -391,7 +393,7 @@ int run_qr(hipStream_t st, int n, cplx* A, cplx* Q, const QrWork& w) {
         const cplx* Tn = w.T + (size_t)p * 2 * QR_NB * QR_NB + QR_NB * QR_NB;
         cplx* C = Q + (size_t)j0 * n + j0;
         // C <- (I - V T V^H) C
-        hipLaunchKernelGGL((k_qr_apply<false>), dim3((ncols + QR_NB - 1) / QR_NB), dim3(256), 0, st, Vp, n, Tn, C, n, rows, ncols, nb);
+        hipLaunchKernelGGL((k_qr_apply<false>), dim3((ncols + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ncols, nb, lc.cs);
         launches += 1;
     }
     return launches;
@@ -402,8 +404,9 @@ int run_qr(hipStream_t st, int n, cplx* A, cplx* Q, const QrWork& w) {
 //   for each column block J:  C_J -= Y_{<J} R_{<J,J}  (GEMM);  C_J <- C_J R_JJ^-1  (one thread per row)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_trsm_block(cplx* __restrict__ C, int ldc, const cplx* __restrict__ R, int ldr,
-                                                     int n, int j0, int nb) {
+                                                     int n, int j0, int nb, size_t cs) {
     __shared__ cplx sR[QR_NB][QR_NB + 1];
+    CHAIN(C); CHAIN(R);
     for (int i = threadIdx.x; i < QR_NB * QR_NB; i += 256) {
         int r = i % QR_NB, c = i / QR_NB;
         sR[r][c] = (r < nb && c < nb && r <= c) ? R[(size_t)(j0 + c) * ldr + (j0 + r)] : make_double2(0.0, 0.0);
@@ -435,7 +438,8 @@ __global__ __launch_bounds__(256) void k_trsm_block(cplx* __restrict__ C, int ld
         if (c < nb) C[(size_t)(j0 + c) * ldc + row] = y[c];
 }
 
-__global__ void k_negate_copy_block(const cplx* __restrict__ R, int ldr, int rows, int cols, cplx* __restrict__ out, int ldo) {
+__global__ void k_negate_copy_block(const cplx* __restrict__ R, int ldr, int rows, int cols, cplx* __restrict__ out, int ldo, size_t cs) {
+    CHAIN(R); CHAIN(out);
     size_t total = (size_t)rows * cols;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(idx % rows), j = (int)(idx / rows);
@@ -444,18 +448,18 @@ __global__ void k_negate_copy_block(const cplx* __restrict__ R, int ldr, int row
     }
 }
 
-int run_trsm_right_upper(hipStream_t st, int n, const cplx* R, cplx* C, const QrWork& w) {
+int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w) {
     int launches = 0;
     for (int j0 = 0; j0 < n; j0 += QR_NB) {
         const int nb = (n - j0 < QR_NB) ? (n - j0) : QR_NB;
         if (j0 > 0) {
             // C_J += Y_{<J} (-R_{<J,J})
-            hipLaunchKernelGGL(k_negate_copy_block, dim3((j0 * nb + 255) / 256), dim3(256), 0, st,
-                               R + (size_t)j0 * n, n, j0, nb, w.Rneg, n);
-            gemm_small(st, 0, 0, C, n, w.Rneg, n, C + (size_t)j0 * n, n, n, nb, j0, 1);
+            hipLaunchKernelGGL(k_negate_copy_block, dim3((j0 * nb + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st,
+                               R + (size_t)j0 * n, n, j0, nb, w.Rneg, n, lc.cs);
+            gemm_small(lc, 0, 0, C, n, w.Rneg, n, C + (size_t)j0 * n, n, n, nb, j0, 1);
             launches += 2;
         }
-        hipLaunchKernelGGL(k_trsm_block, dim3((n + 255) / 256), dim3(256), 0, st, C, n, R, n, n, j0, nb);
+        hipLaunchKernelGGL(k_trsm_block, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, C, n, R, n, n, j0, nb, lc.cs);
         ++launches;
     }
     return launches;
@@ -466,7 +470,8 @@ int run_trsm_right_upper(hipStream_t st, int n, const cplx* R, cplx* C, const Qr
 // ---------------------------------------------------------------------------------------------
 // W[:, perm[j]] = Ms[:, j] (or Ms^H when T != 0), Ms = diag(rowscale) M diag(colscale)
 __global__ void k_udt_init(const cplx* __restrict__ M, int ldm, const double* colscale, const double* rowscale,
-                           const int* __restrict__ perm, int transpose, cplx* __restrict__ W, int n) {
+                           const int* __restrict__ perm, int transpose, cplx* __restrict__ W, int n, size_t cs) {
+    CHAIN(M); CHAIN(colscale); CHAIN(rowscale); CHAIN(perm); CHAIN(W);
     size_t total = (size_t)n * n;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(idx % n), j = (int)(idx / n);
@@ -480,14 +485,16 @@ __global__ void k_udt_init(const cplx* __restrict__ M, int ldm, const double* co
 }
 
 // d[k] = |R[k,k]|
-__global__ void k_udt_diag(const cplx* __restrict__ R, int n, double* d) {
+__global__ void k_udt_diag(const cplx* __restrict__ R, int n, double* d, size_t cs) {
+    CHAIN(R); CHAIN(d);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) { cplx r = R[(size_t)k * n + k]; d[k] = sqrt(r.x * r.x + r.y * r.y); }
 }
 
 // Tt[j, k] = conj(R[k, perm[j]]) / d[k]   (= (D^-1 R P^T)^H); zero where R is zero
 __global__ void k_udt_tmat(const cplx* __restrict__ R, const double* __restrict__ d, const int* __restrict__ perm,
-                           int n, cplx* __restrict__ Tt) {
+                           int n, cplx* __restrict__ Tt, size_t cs) {
+    CHAIN(R); CHAIN(d); CHAIN(perm); CHAIN(Tt);
     size_t total = (size_t)n * n;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(idx % n), k = (int)(idx / n);           // Tt(j, k), column major: contiguous in j
@@ -504,7 +511,8 @@ __global__ void k_udt_tmat(const cplx* __restrict__ R, const double* __restrict_
 
 // Y[:, perm[j]] = X[:, j] * colscale[j]
 __global__ void k_permute_scale_cols(const cplx* __restrict__ X, const double* colscale, const int* __restrict__ perm,
-                                     int n, cplx* __restrict__ Y) {
+                                     int n, cplx* __restrict__ Y, size_t cs) {
+    CHAIN(X); CHAIN(colscale); CHAIN(perm); CHAIN(Y);
     size_t total = (size_t)n * n;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(idx % n), j = (int)(idx / n);
@@ -515,7 +523,8 @@ __global__ void k_permute_scale_cols(const cplx* __restrict__ X, const double* c
 }
 
 // scale splitting of the UdV singular scales: dmax_inv = 1/max(d,1), dmin = min(d,1)
-__global__ void k_split_scales(const double* __restrict__ d, int n, double* dmax_inv, double* dmin) {
+__global__ void k_split_scales(const double* __restrict__ d, int n, double* dmax_inv, double* dmin, size_t cs) {
+    CHAIN(d); CHAIN(dmax_inv); CHAIN(dmin);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) {
         double x = d[k];
@@ -527,7 +536,8 @@ __global__ void k_split_scales(const double* __restrict__ d, int n, double* dmax
 // sv[k] = |R[k,k]| * max(d_r[k],1) * max(d_l[k],1): its log-sum is log|det G^-1| (the only thing the
 // global moves use, detsdwopdim.cpp:3613-3620)
 __global__ void k_logdet_vector(const cplx* __restrict__ R, const double* __restrict__ drmax_inv,
-                                const double* __restrict__ dlmax_inv, int n, double* sv) {
+                                const double* __restrict__ dlmax_inv, int n, double* sv, size_t cs) {
+    CHAIN(R); CHAIN(drmax_inv); CHAIN(dlmax_inv); CHAIN(sv);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) {
         cplx r = R[(size_t)k * n + k];
@@ -535,22 +545,22 @@ __global__ void k_logdet_vector(const cplx* __restrict__ R, const double* __rest
     }
 }
 
-void launch_udt_init(hipStream_t st, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,
+void launch_udt_init(const Launch& lc, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,
                      int transpose, cplx* W, int n) {
-    hipLaunchKernelGGL(k_udt_init, dim3(1024), dim3(256), 0, st, M, ldm, cs, rs, perm, transpose, W, n);
+    hipLaunchKernelGGL(k_udt_init, dim3(1024, 1, lc.nb), dim3(256), 0, lc.st, M, ldm, cs, rs, perm, transpose, W, n, lc.cs);
 }
-void launch_udt_diag(hipStream_t st, const cplx* R, int n, double* d) {
-    hipLaunchKernelGGL(k_udt_diag, dim3((n + 255) / 256), dim3(256), 0, st, R, n, d);
+void launch_udt_diag(const Launch& lc, const cplx* R, int n, double* d) {
+    hipLaunchKernelGGL(k_udt_diag, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, R, n, d, lc.cs);
 }
-void launch_udt_tmat(hipStream_t st, const cplx* R, const double* d, const int* perm, int n, cplx* Tt) {
-    hipLaunchKernelGGL(k_udt_tmat, dim3(1024), dim3(256), 0, st, R, d, perm, n, Tt);
+void launch_udt_tmat(const Launch& lc, const cplx* R, const double* d, const int* perm, int n, cplx* Tt) {
+    hipLaunchKernelGGL(k_udt_tmat, dim3(1024, 1, lc.nb), dim3(256), 0, lc.st, R, d, perm, n, Tt, lc.cs);
 }
-void launch_permute_scale_cols(hipStream_t st, const cplx* X, const double* cs, const int* perm, int n, cplx* Y) {
-    hipLaunchKernelGGL(k_permute_scale_cols, dim3(1024), dim3(256), 0, st, X, cs, perm, n, Y);
+void launch_permute_scale_cols(const Launch& lc, const cplx* X, const double* cs, const int* perm, int n, cplx* Y) {
+    hipLaunchKernelGGL(k_permute_scale_cols, dim3(1024, 1, lc.nb), dim3(256), 0, lc.st, X, cs, perm, n, Y, lc.cs);
 }
-void launch_split_scales(hipStream_t st, const double* d, int n, double* dmax_inv, double* dmin) {
-    hipLaunchKernelGGL(k_split_scales, dim3((n + 255) / 256), dim3(256), 0, st, d, n, dmax_inv, dmin);
+void launch_split_scales(const Launch& lc, const double* d, int n, double* dmax_inv, double* dmin) {
+    hipLaunchKernelGGL(k_split_scales, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, d, n, dmax_inv, dmin, lc.cs);
 }
-void launch_logdet_vector(hipStream_t st, const cplx* R, const double* a, const double* b, int n, double* sv) {
-    hipLaunchKernelGGL(k_logdet_vector, dim3((n + 255) / 256), dim3(256), 0, st, R, a, b, n, sv);
+void launch_logdet_vector(const Launch& lc, const cplx* R, const double* a, const double* b, int n, double* sv) {
+    hipLaunchKernelGGL(k_logdet_vector, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, R, a, b, n, sv, lc.cs);
 }

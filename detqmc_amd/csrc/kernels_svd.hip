@@ -210,8 +210,10 @@ struct JacobiBody {
 
 template<int NCOL, int RPT>
 __global__ __launch_bounds__(256) void k_jacobi_round(cplx* __restrict__ A, cplx* __restrict__ V, int n,
-                                                       const int* __restrict__ pairs, unsigned long long* flag, double tol2, int npass) {
+                                                       const int* __restrict__ pairs, unsigned long long* flag, double tol2, int npass,
+                                                       size_t cs) {
     constexpr int BW = NCOL / 2;
+    CHAIN(A); CHAIN(V);          // pairs and the residual flag (max over all chains) are shared
     __shared__ double red[2][4][NCOL];
     const int tid = threadIdx.x;
     const int bA = pairs[2 * blockIdx.x], bB = pairs[2 * blockIdx.x + 1];
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(256) void k_jacobi_round(cplx* __restrict__ A, cplx
 // columns, where one-sided Jacobi tolerates it (otherwise 50-70 sweeps instead of ~10).
 __global__ void k_svd_init(const cplx* __restrict__ M, int ldm, const double* colscale, const double* rowscale,
                            const int* __restrict__ perm, const int* __restrict__ flagT,
-                           cplx* __restrict__ A, cplx* __restrict__ V, int n) {
+                           cplx* __restrict__ A, cplx* __restrict__ V, int n, size_t cs) {
+    CHAIN(M); CHAIN(colscale); CHAIN(rowscale); CHAIN(perm); CHAIN(flagT); CHAIN(A); CHAIN(V);
     const bool T = flagT && *flagT;
     size_t total = (size_t)n * n;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -283,8 +286,9 @@ __global__ void k_svd_init(const cplx* __restrict__ M, int ldm, const double* co
 
 // norms of the rows of diag(rowscale) M diag(colscale)
 __global__ __launch_bounds__(256) void k_scaled_row_norms(const cplx* __restrict__ M, int ldm, const double* colscale,
-                                                           const double* rowscale, int n, double* norms) {
+                                                           const double* rowscale, int n, double* norms, size_t cs) {
     __shared__ double part[4][64];
+    CHAIN(M); CHAIN(colscale); CHAIN(rowscale); CHAIN(norms);
     int row = blockIdx.x * 64 + (threadIdx.x & 63);
     int q = threadIdx.x >> 6;
     double s = 0.0;
@@ -304,8 +308,9 @@ __global__ __launch_bounds__(256) void k_scaled_row_norms(const cplx* __restrict
 
 // flagT = 1 if the rows span more decades than the columns (mode: -1 auto, 0 never, 1 always)
 __global__ __launch_bounds__(256) void k_choose_orientation(const double* __restrict__ cn, const double* __restrict__ rn,
-                                                             int n, int mode, int* flagT) {
+                                                             int n, int mode, int* flagT, size_t cs) {
     __shared__ double red[4][256];
+    CHAIN(cn); CHAIN(rn); CHAIN(flagT);
     double cmax = 0.0, cmin = 1e300, rmax = 0.0, rmin = 1e300;
     for (int i = threadIdx.x; i < n; i += 256) {
         double c = cn[i], r = rn[i];
@@ -334,7 +339,8 @@ __global__ __launch_bounds__(256) void k_choose_orientation(const double* __rest
 
 // norms of the columns of diag(rowscale) M diag(colscale): one wave per column
 __global__ __launch_bounds__(256) void k_scaled_col_norms(const cplx* __restrict__ M, int ldm, const double* colscale,
-                                                           const double* rowscale, int n, double* norms) {
+                                                           const double* rowscale, int n, double* norms, size_t cs) {
+    CHAIN(M); CHAIN(colscale); CHAIN(rowscale); CHAIN(norms);
     int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (col >= n) return;
@@ -349,7 +355,8 @@ __global__ __launch_bounds__(256) void k_scaled_col_norms(const cplx* __restrict
 }
 
 // column norms: one wave per column
-__global__ __launch_bounds__(256) void k_col_norms(const cplx* __restrict__ A, int n, double* norms) {
+__global__ __launch_bounds__(256) void k_col_norms(const cplx* __restrict__ A, int n, double* norms, size_t cs) {
+    CHAIN(A); CHAIN(norms);
     int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (col >= n) return;
@@ -361,7 +368,8 @@ __global__ __launch_bounds__(256) void k_col_norms(const cplx* __restrict__ A, i
 
 // rank by counting (descending, index as tie-break) and scatter d; norms_T is used when *flagT != 0
 __global__ void k_rank(const double* __restrict__ norms_N, const double* __restrict__ norms_T,
-                       const int* __restrict__ flagT, int n, int* rank, double* d) {
+                       const int* __restrict__ flagT, int n, int* rank, double* d, size_t cs) {
+    CHAIN(norms_N); CHAIN(norms_T); CHAIN(flagT); CHAIN(rank); CHAIN(d);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double* norms = (flagT && *flagT) ? norms_T : norms_N;
@@ -379,7 +387,8 @@ __global__ void k_rank(const double* __restrict__ norms_N, const double* __restr
 __global__ __launch_bounds__(256) void k_svd_scatter(const cplx* __restrict__ A, const cplx* __restrict__ V,
                                                       const double* __restrict__ norms, const int* __restrict__ rank,
                                                       int n, const int* __restrict__ flagT,
-                                                      cplx* __restrict__ U, cplx* __restrict__ Vt) {
+                                                      cplx* __restrict__ U, cplx* __restrict__ Vt, size_t cs) {
+    CHAIN(A); CHAIN(V); CHAIN(norms); CHAIN(rank); CHAIN(flagT); CHAIN(U); CHAIN(Vt);
     if (flagT && *flagT) { cplx* t = U; U = Vt; Vt = t; }     // W = Ms^H: the roles of U and V swap
     int c = blockIdx.x;
     int dst = rank[c];
@@ -392,13 +401,13 @@ __global__ __launch_bounds__(256) void k_svd_scatter(const cplx* __restrict__ A,
 }
 
 // ranks (0 = largest) of the column norms of Ms (transpose == 0) or of its row norms (transpose != 0)
-void launch_scaled_norms_rank(hipStream_t st, const cplx* M, int ldm, const double* cs, const double* rs, int transpose,
+void launch_scaled_norms_rank(const Launch& lc, const cplx* M, int ldm, const double* cs, const double* rs, int transpose,
                               int n, double* norms, int* rank, double* scratch_d) {
     if (!transpose)
-        hipLaunchKernelGGL(k_scaled_col_norms, dim3((n + 3) / 4), dim3(256), 0, st, M, ldm, cs, rs, n, norms);
+        hipLaunchKernelGGL(k_scaled_col_norms, dim3((n + 3) / 4, 1, lc.nb), dim3(256), 0, lc.st, M, ldm, cs, rs, n, norms, lc.cs);
     else
-        hipLaunchKernelGGL(k_scaled_row_norms, dim3((n + 63) / 64), dim3(256), 0, st, M, ldm, cs, rs, n, norms);
-    hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, st, norms, norms, nullptr, n, rank, scratch_d);
+        hipLaunchKernelGGL(k_scaled_row_norms, dim3((n + 63) / 64, 1, lc.nb), dim3(256), 0, lc.st, M, ldm, cs, rs, n, norms, lc.cs);
+    hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, norms, norms, nullptr, n, rank, scratch_d, lc.cs);
 }
 
 int svd_block_cols(int n) {
@@ -419,22 +428,23 @@ __global__ void k_publish_residual(const unsigned long long* __restrict__ flag, 
 }
 
 template<int NCOL, int RPT>
-static void launch_round(hipStream_t st, cplx* A, cplx* V, int n, const int* pairs, int nwg, unsigned long long* flag, double tol2) {
-    hipLaunchKernelGGL((k_jacobi_round<NCOL, RPT>), dim3(nwg), dim3(256), 0, st, A, V, n, pairs, flag, tol2, g_jacobi_npass);
+static void launch_round(const Launch& lc, cplx* A, cplx* V, int n, const int* pairs, int nwg, unsigned long long* flag, double tol2) {
+    hipLaunchKernelGGL((k_jacobi_round<NCOL, RPT>), dim3(nwg, 1, lc.nb), dim3(256), 0, lc.st, A, V, n, pairs, flag, tol2, g_jacobi_npass, lc.cs);
 }
 
-int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscale, const double* rowscale,
+int run_svd(const Launch& lc, int n, const cplx* M, int ldm, const double* colscale, const double* rowscale,
             cplx* U, double* d, cplx* Vt, const SvdWork& w, int max_sweeps, const SvdProfHooks* hooks) {
     // orientation (Ms or Ms^H) and initial column order are chosen on the device: no host round trip
-    hipLaunchKernelGGL(k_scaled_col_norms, dim3((n + 3) / 4), dim3(256), 0, st, M, ldm, colscale, rowscale, n, w.norms);
-    hipLaunchKernelGGL(k_scaled_row_norms, dim3((n + 63) / 64), dim3(256), 0, st, M, ldm, colscale, rowscale, n, w.rnorms);
-    hipLaunchKernelGGL(k_choose_orientation, dim3(1), dim3(256), 0, st, w.norms, w.rnorms, n, g_jacobi_transpose, w.flagT);
+    hipStream_t st = lc.st;
+    hipLaunchKernelGGL(k_scaled_col_norms, dim3((n + 3) / 4, 1, lc.nb), dim3(256), 0, st, M, ldm, colscale, rowscale, n, w.norms, lc.cs);
+    hipLaunchKernelGGL(k_scaled_row_norms, dim3((n + 63) / 64, 1, lc.nb), dim3(256), 0, st, M, ldm, colscale, rowscale, n, w.rnorms, lc.cs);
+    hipLaunchKernelGGL(k_choose_orientation, dim3(1, 1, lc.nb), dim3(256), 0, st, w.norms, w.rnorms, n, g_jacobi_transpose, w.flagT, lc.cs);
     const int* perm = nullptr;
     if (g_jacobi_sort) {
-        hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, st, w.norms, w.rnorms, w.flagT, n, w.rank, d);
+        hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, st, w.norms, w.rnorms, w.flagT, n, w.rank, d, lc.cs);
         perm = w.rank;
     }
-    hipLaunchKernelGGL(k_svd_init, dim3(1024), dim3(256), 0, st, M, ldm, colscale, rowscale, perm, w.flagT, w.A, w.V, n);
+    hipLaunchKernelGGL(k_svd_init, dim3(1024, 1, lc.nb), dim3(256), 0, st, M, ldm, colscale, rowscale, perm, w.flagT, w.A, w.V, n, lc.cs);
     // rotation threshold on |a_p^H a_q| / (|a_p| |a_q|): a few rounding errors of an n-term dot product
     const double tol = 4.0 * sqrt((double)n) * 2.220446049250313e-16;
     const double tol2 = tol * tol;
@@ -449,19 +459,19 @@ int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscal
             const int* pairs = w.rounds + (size_t)r * nwg * 2;
             if (w.nblk * 4 == n) {          // NCOL = 8
                 switch (rpt) {
-                    case 1: launch_round<8, 1>(st, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
-                    case 2: launch_round<8, 2>(st, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
-                    case 3: launch_round<8, 3>(st, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
-                    case 4: launch_round<8, 4>(st, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
+                    case 1: launch_round<8, 1>(lc, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
+                    case 2: launch_round<8, 2>(lc, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
+                    case 3: launch_round<8, 3>(lc, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
+                    case 4: launch_round<8, 4>(lc, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
                     default: return DQMC_EINVAL;
                 }
             } else {                        // NCOL = 4
                 switch (rpt) {
-                    case 5: launch_round<4, 5>(st, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
-                    case 6: launch_round<4, 6>(st, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
-                    case 7: launch_round<4, 7>(st, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
-                    case 8: launch_round<4, 8>(st, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
-                    case 9: launch_round<4, 9>(st, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
+                    case 5: launch_round<4, 5>(lc, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
+                    case 6: launch_round<4, 6>(lc, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
+                    case 7: launch_round<4, 7>(lc, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
+                    case 8: launch_round<4, 8>(lc, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
+                    case 9: launch_round<4, 9>(lc, w.A, w.V, n, pairs, nwg, w.flag, tol2); break;
                     default: return DQMC_EINVAL;
                 }
             }
@@ -521,9 +531,9 @@ int run_svd(hipStream_t st, int n, const cplx* M, int ldm, const double* colscal
     // 1e-10 parity target needs; anything worse is a failure like the reference's "SVD failed"
     if (!converged && !(res <= 1e-12)) return DQMC_ENOCONV;
     if (w.last_residual) *w.last_residual = res;
-    hipLaunchKernelGGL(k_col_norms, dim3((n + 3) / 4), dim3(256), 0, st, w.A, n, w.norms);
-    hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, st, w.norms, w.norms, nullptr, n, w.rank, d);
-    hipLaunchKernelGGL(k_svd_scatter, dim3(n), dim3(256), 0, st, w.A, w.V, w.norms, w.rank, n, w.flagT, U, Vt);
+    hipLaunchKernelGGL(k_col_norms, dim3((n + 3) / 4, 1, lc.nb), dim3(256), 0, st, w.A, n, w.norms, lc.cs);
+    hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, st, w.norms, w.norms, nullptr, n, w.rank, d, lc.cs);
+    hipLaunchKernelGGL(k_svd_scatter, dim3(n, 1, lc.nb), dim3(256), 0, st, w.A, w.V, w.norms, w.rank, n, w.flagT, U, Vt, lc.cs);
     return sweeps;
 }
 

@@ -176,9 +176,11 @@ struct Candidate {
 template<int OPDIM>
 __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
                                                        const cplx* __restrict__ G, cplx* __restrict__ Wout,
-                                                       int k, int first, int thermal) {
+                                                       int k, int first, int thermal, size_t cs) {
     constexpr int MSF = (OPDIM == 3) ? 4 : 2;
     constexpr int SLOTS = MSF * DQMC_MAX_WDIM / 64;
+    dm = chain_model(dm, cs); CHAIN(us); CHAIN(uni); CHAIN(G); CHAIN(Wout);
+    dm.r = us->r;                         // the exchange parameter differs between the chains of a batch
     const int N = dm.N, ng = dm.ng, D = dm.D, m = dm.m;
     const int WD = MSF * D;
     extern __shared__ cplx smem[];
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     }
 }
 
-void launch_update_decide(hipStream_t st, const DevModel* /*dm*/, const DevModel& hm, DevUpdateState* us,
+void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, DevUpdateState* us,
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal) {
     const int WD = hm.MSF * hm.D;
     size_t lds = ((size_t)WD * WD + 5 * (size_t)hm.MSF * WD) * sizeof(cplx);
@@ -561,11 +563,11 @@ void launch_update_decide(hipStream_t st, const DevModel* /*dm*/, const DevModel
         }
     }
     if (hm.opdim == 1)
-        hipLaunchKernelGGL((k_update_decide<1>), dim3(1), dim3(256), lds, st, hm, us, uniforms, G, W, k, first, thermal);
+        hipLaunchKernelGGL((k_update_decide<1>), dim3(1, 1, lc.nb), dim3(256), lds, lc.st, hm, us, uniforms, G, W, k, first, thermal, lc.cs);
     else if (hm.opdim == 2)
-        hipLaunchKernelGGL((k_update_decide<2>), dim3(1), dim3(256), lds, st, hm, us, uniforms, G, W, k, first, thermal);
+        hipLaunchKernelGGL((k_update_decide<2>), dim3(1, 1, lc.nb), dim3(256), lds, lc.st, hm, us, uniforms, G, W, k, first, thermal, lc.cs);
     else
-        hipLaunchKernelGGL((k_update_decide<3>), dim3(1), dim3(256), lds, st, hm, us, uniforms, G, W, k, first, thermal);
+        hipLaunchKernelGGL((k_update_decide<3>), dim3(1, 1, lc.nb), dim3(256), lds, lc.st, hm, us, uniforms, G, W, k, first, thermal, lc.cs);
 }
 
 // X[:, i'] = sum_i G[:, I_i] W[i, i']   (n_g x nI, ld n_g);   Gr[i, :] = G[I_i, :] - E   (nI x n_g, ld WD)
@@ -573,8 +575,9 @@ void launch_update_decide(hipStream_t st, const DevModel* /*dm*/, const DevModel
 // (coalesced along the rows) and every thread forms its X entries from LDS.
 __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpdateState* __restrict__ us,
                                                         const cplx* __restrict__ G, const cplx* __restrict__ Wg,
-                                                        cplx* __restrict__ X, cplx* __restrict__ Gr) {
-    extern __shared__ cplx sdyn[];      // sW: [nI cols][WD] as stored by the decision kernel, then sG: [nI][65]
+                                                        cplx* __restrict__ X, cplx* __restrict__ Gr, size_t cs) {
+    extern __shared__ cplx sdyn[];
+    CHAIN(us); CHAIN(G); CHAIN(Wg); CHAIN(X); CHAIN(Gr);      // sW: [nI cols][WD] as stored by the decision kernel, then sG: [nI][65]
     const int j = us->block_j;
     if (j <= 0) return;
     const int MSF = dm.MSF, N = dm.N, ng = dm.ng, WD = MSF * dm.D;
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpd
     }
 }
 
-void launch_update_gather(hipStream_t st, const DevModel& hm, const DevUpdateState* us, const cplx* G,
+void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,
                           const cplx* W, cplx* X, cplx* Gr) {
     const int WD = hm.MSF * hm.D;
     size_t lds = ((size_t)WD * WD + (size_t)WD * 65) * sizeof(cplx);
@@ -624,5 +627,5 @@ void launch_update_gather(hipStream_t st, const DevModel& hm, const DevUpdateSta
             raised = true;
         }
     }
-    hipLaunchKernelGGL(k_update_gather, dim3((hm.ng + 63) / 64), dim3(256), lds, st, hm, us, G, W, X, Gr);
+    hipLaunchKernelGGL(k_update_gather, dim3((hm.ng + 63) / 64, 1, lc.nb), dim3(256), lds, lc.st, hm, us, G, W, X, Gr, lc.cs);
 }

@@ -91,6 +91,17 @@ typedef struct dqmc_update_state {
 /* replaces DetSDW ctor set-up of hopping constants / 4-site exponentials
  * (detsdwopdim.cpp:217-264, :1598-1684) */
 int dqmc_create(const dqmc_params* p, dqmc_ctx** out);
+/* Batched replicas: ONE context that advances `nchains` independent Markov chains (the replicas of a
+ * parallel-tempering run, src/detqmcpt.h: one replica per MPI rank there) in lockstep -- every kernel launch
+ * carries all chains (grid.z = chain), which is what fills the 256 CUs at the lattice sizes of interest.
+ * All chains share the lattice/temperature parameters of *p; fields, RNG windows, update state and the
+ * exchange parameter r are per chain.  The compute entry points (udv_setup, advance, wrap, update_slice,
+ * backup) act on all chains; the host-buffer entry points (set/get fields, Green's function, singular
+ * values, UdV, uniforms, update state, exchange parameter / action, restore) act on the chain chosen with
+ * dqmc_select_chain (default 0).  dqmc_create == dqmc_create_batch with nchains = 1. */
+int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** out);
+int dqmc_select_chain(dqmc_ctx* ctx, int chain);
+int dqmc_num_chains(dqmc_ctx* ctx);
 void dqmc_destroy(dqmc_ctx* ctx);
 const char* dqmc_last_error(void);
 int dqmc_synchronize(dqmc_ctx* ctx);
