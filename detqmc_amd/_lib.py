@@ -115,6 +115,9 @@ SYMBOLS = [
     ("dqmc_profile_enable", C.c_int, [_P, C.c_int]),
     ("dqmc_profile_read", C.c_int, [_P, C.POINTER(dqmc_profile)]),
     ("detsdw_create", C.c_int, [C.POINTER(detsdw_params), C.POINTER(_P)]),
+    ("detsdw_create_batch", C.c_int, [C.POINTER(detsdw_params), C.c_int, C.POINTER(_P)]),
+    ("detsdw_select_chain", C.c_int, [_P, C.c_int]),
+    ("detsdw_num_chains", C.c_int, [_P]),
     ("detsdw_destroy", None, [_P]),
     ("detsdw_last_error", C.c_char_p, []),
     ("detsdw_sweep", C.c_int, [_P, C.c_int]),

@@ -16,8 +16,13 @@ void DetSDW::check(int rc, const char* what) {
     if (rc != DQMC_OK) throw GeneralError(rc, std::string(what) + ": " + dqmc_last_error());
 }
 
-DetSDW::DetSDW(const detsdw_params& in) : pars_(in), rng_(in.rngSeed, (uint32_t)in.simindex + 1u) {   // detqmc.h:181
-    detsdw_params& p = pars_;
+void DetSDW::select(int b) {
+    if (b < 0 || b >= (int)ch_.size()) throw ParameterWrong("chain index out of range");
+    check(dqmc_select_chain(ctx_, b), "dqmc_select_chain");
+}
+
+// updateTemperatureParameters + ModelParamsDetSDW::check + createReplica on one parameter set
+void DetSDW::normalise(detsdw_params& p, int& bcv) {
     // --- updateTemperatureParameters (detmodelparams.h:68-122) ---
     if (!(p.dtau > 0)) throw ParameterWrong("Parameter dtau has incorrect value");
     if (p.s <= 0) throw ParameterWrong("Parameter s has incorrect value");
@@ -34,7 +39,6 @@ DetSDW::DetSDW(const detsdw_params& in) : pars_(in), rng_(in.rngSeed, (uint32_t)
     // --- ModelParamsDetSDW::check (detsdwparams.cpp:21-140) ---
     if (!(p.opdim == 1 || p.opdim == 2 || p.opdim == 3)) throw ParameterWrong("Parameter opdim has incorrect value");
     const std::string bc(p.bc[0] ? p.bc : "pbc");
-    int bcv;
     if (bc == "pbc") bcv = DQMC_BC_PBC;
     else if (bc == "apbc-x") bcv = DQMC_BC_APBC_X;
     else if (bc == "apbc-y") bcv = DQMC_BC_APBC_Y;
@@ -50,9 +54,29 @@ DetSDW::DetSDW(const detsdw_params& in) : pars_(in), rng_(in.rngSeed, (uint32_t)
     if (p.globalShift && p.globalUpdateInterval == 0) throw ParameterWrong("Parameter globalUpdateInterval has incorrect value");
     if (p.L % 2 != 0) throw ParameterWrong("Checker board decomposition only supported for even linear lattice sizes");
     if (p.cdwU != 0.0) throw ParameterWrong("cdwU != 0 is not supported by this build");
+    if (p.stabilisation != 0 && p.stabilisation != 1) throw ParameterWrong("Parameter stabilisation has incorrect value");
     // createReplica (detsdwopdim.cpp:75-79)
     if (!p.has_mux_muy) { p.mux = p.mu; p.muy = p.mu; }
+}
 
+DetSDW::DetSDW(const detsdw_params* in, int nchains) {
+    if (!in || nchains < 1) throw ParameterWrong("need at least one replica");
+    int bcv = 0;
+    for (int b = 0; b < nchains; ++b) {
+        detsdw_params p = in[b];
+        normalise(p, bcv);
+        if (b > 0) {
+            // the chains of a batch are the replicas of ONE parallel-tempering ensemble: same lattice, same
+            // temperature and couplings; they may differ in r (the exchange parameter) and in the RNG stream
+            detsdw_params a = ch_[0].pars, q = p;
+            a.r = q.r = 0.0; a.rngSeed = q.rngSeed = 0; a.simindex = q.simindex = 0;
+            if (std::memcmp(&a, &q, sizeof(a)) != 0)
+                throw ParameterWrong("replicas of one batch may differ only in r, rngSeed and simindex");
+        }
+        ch_.emplace_back(p);
+    }
+    const detsdw_params& p = ch_[0].pars;
+    const int N = p.L * p.L;
     N_ = N; opdim_ = p.opdim; MSF_ = (p.opdim == 3) ? 4 : 2; ng_ = MSF_ * N_;
     m_ = p.m; s_ = p.s; n_ = (m_ + s_ - 1) / s_;
 
@@ -65,25 +89,29 @@ DetSDW::DetSDW(const detsdw_params& in) : pars_(in), rng_(in.rngSeed, (uint32_t)
     kp.dtau = p.dtau; kp.r = p.r; kp.c = p.c; kp.u = p.u; kp.lambda = p.lambda;
     kp.txhor = p.txhor; kp.txver = p.txver; kp.tyhor = p.tyhor; kp.tyver = p.tyver;
     kp.mux = p.mux; kp.muy = p.muy; kp.accRatio = p.accRatio;
-    if (p.stabilisation != 0 && p.stabilisation != 1) throw ParameterWrong("Parameter stabilisation has incorrect value");
     kp.stabilisation = p.stabilisation;
     kp.cb_none = p.cb_none ? 1 : 0;          // reference option checkerboard=false (DetSDW<CB_NONE, OPDIM>)
-    check(dqmc_create(&kp, &ctx_), "dqmc_create");
+    check(dqmc_create_batch(&kp, nchains, &ctx_), "dqmc_create");
 
-    phi_.assign((size_t)N_ * opdim_ * (m_ + 1), 0.0);
-    setupRandomField();
-    check(dqmc_set_fields_host(ctx_, phi_.data()), "dqmc_set_fields_host");
+    for (int b = 0; b < nchains; ++b) {
+        Chain& c = ch_[b];
+        c.phi.assign((size_t)N_ * opdim_ * (m_ + 1), 0.0);
+        setupRandomField(c);
+        select(b);
+        check(dqmc_set_exchange_parameter(ctx_, c.pars.r), "dqmc_set_exchange_parameter");
+        check(dqmc_set_fields_host(ctx_, c.phi.data()), "dqmc_set_fields_host");
+    }
     setupUdVStorage_and_calculateGreen();
 }
 
 DetSDW::~DetSDW() { dqmc_destroy(ctx_); }
 
 // detsdwopdim.cpp:1099-1113: k outer, site, dim; one more draw per site for the (unused) cdwl field
-void DetSDW::setupRandomField() {
+void DetSDW::setupRandomField(Chain& c) {
     for (int k = 1; k <= m_; ++k)
         for (int site = 0; site < N_; ++site) {
-            for (int dim = 0; dim < opdim_; ++dim) phi(site, dim, k) = rng_.randRange(-1.0, 1.0);
-            (void)rng_.rand01();
+            for (int dim = 0; dim < opdim_; ++dim) c.phi[phiIdx(site, dim, k)] = c.rng.randRange(-1.0, 1.0);
+            (void)c.rng.rand01();
         }
 }
 
@@ -95,15 +123,21 @@ void DetSDW::setupUdVStorage_and_calculateGreen() {
 // Ship the worst-case number of upcoming uniforms of this sweep; the device consumes a prefix.
 void DetSDW::beginLocalUpdates() {
     const size_t need = (size_t)(opdim_ + 1) * N_ * m_;
-    const double* w = rng_.peek(need);
-    check(dqmc_push_uniforms_host(ctx_, w, need), "dqmc_push_uniforms_host");
+    for (int b = 0; b < (int)ch_.size(); ++b) {
+        const double* w = ch_[b].rng.peek(need);
+        select(b);
+        check(dqmc_push_uniforms_host(ctx_, w, need), "dqmc_push_uniforms_host");
+    }
 }
 void DetSDW::endLocalUpdates() {
-    dqmc_update_state st;
-    check(dqmc_get_update_state_host(ctx_, &st), "dqmc_get_update_state_host");
-    rng_.consume((size_t)st.rng_consumed);
-    phiDelta_ = st.phiDelta;
-    lastAccRatio_ = st.lastAccRatio;
+    for (int b = 0; b < (int)ch_.size(); ++b) {
+        dqmc_update_state st;
+        select(b);
+        check(dqmc_get_update_state_host(ctx_, &st), "dqmc_get_update_state_host");
+        ch_[b].rng.consume((size_t)st.rng_consumed);
+        ch_[b].phiDelta = st.phiDelta;
+        ch_[b].lastAccRatio = st.lastAccRatio;
+    }
 }
 
 void DetSDW::updateInSlice(int k, bool thermalization) {
@@ -163,21 +197,24 @@ void DetSDW::sweep_skeleton(bool thermalization) {
 void DetSDW::sweep(bool /*takeMeasurements*/) { sweep_skeleton(false); }
 void DetSDW::sweepThermalization() { sweep_skeleton(true); }
 
-// detsdwopdim.cpp:3461-3486
+// detsdwopdim.cpp:3461-3486 -- all chains of a batch attempt their global move in the same sweep
 void DetSDW::globalMove() {
-    if (pars_.globalShift && pars_.globalUpdateInterval > 0 &&
-        performedSweeps_ % pars_.globalUpdateInterval == 0)
+    const detsdw_params& p = ch_[0].pars;
+    if (p.globalShift && p.globalUpdateInterval > 0 && performedSweeps_ % p.globalUpdateInterval == 0)
         attemptGlobalShiftMove();
 }
 
-void DetSDW::syncPhiFromDevice() {
-    check(dqmc_get_fields_host(ctx_, phi_.data(), nullptr, nullptr), "dqmc_get_fields_host");
+void DetSDW::syncPhiFromDevice(int b) {
+    select(b);
+    check(dqmc_get_fields_host(ctx_, ch_[b].phi.data(), nullptr, nullptr), "dqmc_get_fields_host");
 }
 
 // detsdwopdim.cpp:4242-4300
-double DetSDW::phiAction() const {
-    const double dtau = pars_.dtau, r = pars_.r, u = pars_.u, c = pars_.c;
-    const int L = pars_.L;
+double DetSDW::phiAction(const Chain& ch) const {
+    const detsdw_params& pars = ch.pars;
+    const double dtau = pars.dtau, r = pars.r, u = pars.u, c = pars.c;
+    const int L = pars.L;
+    const std::vector<double>& f = ch.phi;
     double action = 0.0;
     for (int k = 1; k <= m_; ++k) {
         const int kprev = (k > 1) ? k - 1 : m_;
@@ -185,109 +222,132 @@ double DetSDW::phiAction() const {
             const int x = site % L, y = site / L;
             const int xn = y * L + (x + 1) % L, yn = ((y + 1) % L) * L + x;
             double phisq = 0.0;
-            if (!pars_.phi2bosons) {
+            if (!pars.phi2bosons) {
                 double td2 = 0.0, xd2 = 0.0, yd2 = 0.0;
                 for (int d = 0; d < opdim_; ++d) {
-                    const double ph = phi(site, d, k);
-                    const double td = (ph - phi(site, d, kprev)) / dtau;
+                    const double ph = f[phiIdx(site, d, k)];
+                    const double td = (ph - f[phiIdx(site, d, kprev)]) / dtau;
                     td2 += td * td;
-                    const double xd = ph - phi(xn, d, k);
+                    const double xd = ph - f[phiIdx(xn, d, k)];
                     xd2 += xd * xd;
-                    const double yd = ph - phi(yn, d, k);
+                    const double yd = ph - f[phiIdx(yn, d, k)];
                     yd2 += yd * yd;
                 }
                 action += (dtau / (2.0 * c * c)) * td2;
                 action += 0.5 * dtau * xd2;
                 action += 0.5 * dtau * yd2;
             }
-            for (int d = 0; d < opdim_; ++d) phisq += phi(site, d, k) * phi(site, d, k);
+            for (int d = 0; d < opdim_; ++d) phisq += f[phiIdx(site, d, k)] * f[phiIdx(site, d, k)];
             action += 0.5 * dtau * r * phisq;
-            if (!pars_.phi2bosons) action += 0.25 * dtau * u * phisq * phisq;
+            if (!pars.phi2bosons) action += 0.25 * dtau * u * phisq * phisq;
         }
     }
     return action;
 }
 
-// detsdwopdim.cpp:3565-3644
+// detsdwopdim.cpp:3565-3644, for every chain of the batch: the proposal of each chain is drawn from its own
+// RNG stream, the UdV storage / G of all chains are rebuilt by ONE batched setup, then each chain accepts or
+// restores on its own.
 void DetSDW::attemptGlobalShiftMove() {
-    syncPhiFromDevice();
-    dqmc_update_state st;
-    check(dqmc_get_update_state_host(ctx_, &st), "dqmc_get_update_state_host");
-    phiDelta_ = st.phiDelta;
-    const double old_scalar_action = phiAction();
-    std::vector<double> old_sv(ng_), new_sv(ng_);
-    check(dqmc_get_sv_host(ctx_, old_sv.data()), "dqmc_get_sv_host");
-    check(dqmc_backup(ctx_), "globalMoveStoreBackups");
-    std::vector<double> phi_backup = phi_;
-    // addGlobalRandomDisplacement (:3755-3763): all slices (incl. the unused slice 0) shifted
-    for (int dim = 0; dim < opdim_; ++dim) {
-        const double rr = rng_.randRange(-phiDelta_, +phiDelta_);
-        for (int k = 0; k <= m_; ++k)
-            for (int site = 0; site < N_; ++site) phi(site, dim, k) += rr;
+    const int nb = (int)ch_.size();
+    std::vector<double> old_action(nb), old_sv((size_t)nb * ng_), new_sv(ng_);
+    std::vector<std::vector<double>> phi_backup(nb);
+    for (int b = 0; b < nb; ++b) {
+        Chain& c = ch_[b];
+        syncPhiFromDevice(b);
+        dqmc_update_state st;
+        check(dqmc_get_update_state_host(ctx_, &st), "dqmc_get_update_state_host");
+        c.phiDelta = st.phiDelta;
+        old_action[b] = phiAction(c);
+        check(dqmc_get_sv_host(ctx_, &old_sv[(size_t)b * ng_]), "dqmc_get_sv_host");
     }
-    check(dqmc_set_fields_host(ctx_, phi_.data()), "updateCoshSinhTermsPhi");
+    check(dqmc_backup(ctx_), "globalMoveStoreBackups");
+    for (int b = 0; b < nb; ++b) {
+        Chain& c = ch_[b];
+        phi_backup[b] = c.phi;
+        // addGlobalRandomDisplacement (:3755-3763): all slices (incl. the unused slice 0) shifted
+        for (int dim = 0; dim < opdim_; ++dim) {
+            const double rr = c.rng.randRange(-c.phiDelta, +c.phiDelta);
+            for (int k = 0; k <= m_; ++k)
+                for (int site = 0; site < N_; ++site) c.phi[phiIdx(site, dim, k)] += rr;
+        }
+        select(b);
+        check(dqmc_set_fields_host(ctx_, c.phi.data()), "updateCoshSinhTermsPhi");
+    }
     setupUdVStorage_and_calculateGreen();
-    const double new_scalar_action = phiAction();
-    const double prob_scalar = std::exp(-(new_scalar_action - old_scalar_action));
-    check(dqmc_get_sv_host(ctx_, new_sv.data()), "dqmc_get_sv_host");
-    double log_prob = 0.0;
-    for (int j = 0; j < ng_; ++j) log_prob += std::log(new_sv[j]) - std::log(old_sv[j]);
-    double prob_fermion = std::exp(log_prob);
-    if (opdim_ < 3) prob_fermion = prob_fermion * prob_fermion;
-    const double prob = prob_scalar * prob_fermion;
-    attemptedGlobalShifts_ += 1;
-    if (prob >= 1.0 || rng_.rand01() < prob) {
-        acceptedGlobalShifts_ += 1;
-    } else {
-        check(dqmc_restore(ctx_), "globalMoveRestoreBackups");
-        phi_ = phi_backup;
+    for (int b = 0; b < nb; ++b) {
+        Chain& c = ch_[b];
+        const double new_scalar_action = phiAction(c);
+        const double prob_scalar = std::exp(-(new_scalar_action - old_action[b]));
+        select(b);
+        check(dqmc_get_sv_host(ctx_, new_sv.data()), "dqmc_get_sv_host");
+        double log_prob = 0.0;
+        for (int j = 0; j < ng_; ++j) log_prob += std::log(new_sv[j]) - std::log(old_sv[(size_t)b * ng_ + j]);
+        double prob_fermion = std::exp(log_prob);
+        if (opdim_ < 3) prob_fermion = prob_fermion * prob_fermion;
+        const double prob = prob_scalar * prob_fermion;
+        c.attemptedGlobalShifts += 1;
+        if (prob >= 1.0 || c.rng.rand01() < prob) {
+            c.acceptedGlobalShifts += 1;
+        } else {
+            check(dqmc_restore(ctx_), "globalMoveRestoreBackups");
+            c.phi = phi_backup[b];
+        }
     }
 }
 
-void DetSDW::set_exchange_parameter_value(double r) {
-    pars_.r = r;
+void DetSDW::set_exchange_parameter_value(double r, int b) {
+    select(b);
+    ch_[b].pars.r = r;
     check(dqmc_set_exchange_parameter(ctx_, r), "set_exchange_parameter_value");
 }
-double DetSDW::get_exchange_action_contribution() {
+double DetSDW::get_exchange_action_contribution(int b) {
     double v = 0.0;
+    select(b);
     check(dqmc_exchange_action_host(ctx_, &v), "get_exchange_action_contribution");
     return v;
 }
-void DetSDW::get_control_data(detsdw_control_data& out) {
-    out.acceptedGlobalShifts = acceptedGlobalShifts_;
-    out.attemptedGlobalShifts = attemptedGlobalShifts_;
+void DetSDW::get_control_data(detsdw_control_data& out, int b) {
+    select(b);
+    out.acceptedGlobalShifts = ch_[b].acceptedGlobalShifts;
+    out.attemptedGlobalShifts = ch_[b].attemptedGlobalShifts;
     check(dqmc_get_update_state_host(ctx_, &out.adjust), "get_control_data");
 }
-void DetSDW::set_control_data(const detsdw_control_data& in) {
-    acceptedGlobalShifts_ = in.acceptedGlobalShifts;
-    attemptedGlobalShifts_ = in.attemptedGlobalShifts;
+void DetSDW::set_control_data(const detsdw_control_data& in, int b) {
+    select(b);
+    ch_[b].acceptedGlobalShifts = in.acceptedGlobalShifts;
+    ch_[b].attemptedGlobalShifts = in.attemptedGlobalShifts;
     dqmc_update_state st = in.adjust;
     st.rng_consumed = 0; st.rng_avail = 0; st.error = 0;      // the RNG window is per replica, never exchanged
     check(dqmc_set_update_state_host(ctx_, &st), "set_control_data");
-    phiDelta_ = st.phiDelta;
-    lastAccRatio_ = st.lastAccRatio;
+    ch_[b].phiDelta = st.phiDelta;
+    ch_[b].lastAccRatio = st.lastAccRatio;
 }
 
-void DetSDW::getInfo(detsdw_info& o) {
+void DetSDW::getInfo(detsdw_info& o, int b) {
+    select(b);
+    const Chain& c = ch_[b];
     std::memset(&o, 0, sizeof(o));
-    o.opdim = opdim_; o.L = pars_.L; o.N = N_; o.MSF = MSF_; o.n_g = ng_; o.m = m_; o.s = s_; o.n = n_;
+    o.opdim = opdim_; o.L = c.pars.L; o.N = N_; o.MSF = MSF_; o.n_g = ng_; o.m = m_; o.s = s_; o.n = n_;
     o.performedSweeps = performedSweeps_; o.lastSweepDir = (int)lastSweepDir_;
-    o.acceptedGlobalShifts = acceptedGlobalShifts_; o.attemptedGlobalShifts = attemptedGlobalShifts_;
+    o.acceptedGlobalShifts = c.acceptedGlobalShifts; o.attemptedGlobalShifts = c.attemptedGlobalShifts;
     o.currentTimeslice = dqmc_current_timeslice(ctx_);
-    o.beta = pars_.beta; o.dtau = pars_.dtau; o.phiDelta = phiDelta_; o.lastAccRatioLocal_phi = lastAccRatio_;
-    o.r = pars_.r; o.rngDrawn = rng_.drawn();
+    o.beta = c.pars.beta; o.dtau = c.pars.dtau; o.phiDelta = c.phiDelta; o.lastAccRatioLocal_phi = c.lastAccRatio;
+    o.r = c.pars.r; o.rngDrawn = c.rng.drawn();
 }
-void DetSDW::getPhi(double* out) {
-    syncPhiFromDevice();
-    std::memcpy(out, phi_.data(), phi_.size() * sizeof(double));
+void DetSDW::getPhi(double* out, int b) {
+    syncPhiFromDevice(b);
+    std::memcpy(out, ch_[b].phi.data(), ch_[b].phi.size() * sizeof(double));
 }
-void DetSDW::setPhi(const double* in) {
-    std::memcpy(phi_.data(), in, phi_.size() * sizeof(double));
-    check(dqmc_set_fields_host(ctx_, phi_.data()), "dqmc_set_fields_host");
+// also rebuilds UdV storage and G -- of every chain of the batch (one batched setup)
+void DetSDW::setPhi(const double* in, int b) {
+    select(b);
+    std::memcpy(ch_[b].phi.data(), in, ch_[b].phi.size() * sizeof(double));
+    check(dqmc_set_fields_host(ctx_, ch_[b].phi.data()), "dqmc_set_fields_host");
     setupUdVStorage_and_calculateGreen();
 }
-void DetSDW::getGreen(dqmc_cplx* g) { check(dqmc_get_green_host(ctx_, g), "dqmc_get_green_host"); }
-void DetSDW::getGreenInvSv(double* sv) { check(dqmc_get_sv_host(ctx_, sv), "dqmc_get_sv_host"); }
+void DetSDW::getGreen(dqmc_cplx* g, int b) { select(b); check(dqmc_get_green_host(ctx_, g), "dqmc_get_green_host"); }
+void DetSDW::getGreenInvSv(double* sv, int b) { select(b); check(dqmc_get_sv_host(ctx_, sv), "dqmc_get_sv_host"); }
 
 }  // namespace detqmc
 
@@ -295,11 +355,11 @@ void DetSDW::getGreenInvSv(double* sv) { check(dqmc_get_sv_host(ctx_, sv), "dqmc
 // C API (include/detsdw_host.h)
 // ---------------------------------------------------------------------------------------------
 using detqmc::DetSDW;
-struct detsdw_replica { DetSDW* impl; };
+struct detsdw_replica { DetSDW* impl; int sel; };   // sel: chain the per-replica calls refer to
 static thread_local std::string g_host_err;
 
-#define GUARD(body)                                                          \
-    try { body; return DQMC_OK; }                                            \
+#define GUARD(...)                                                          \
+    try { __VA_ARGS__; return DQMC_OK; }                                            \
     catch (const detqmc::GeneralError& e) { g_host_err = e.what(); return e.code; } \
     catch (const std::exception& e) { g_host_err = e.what(); return DQMC_EINVAL; }
 
@@ -308,26 +368,37 @@ extern "C" const char* detsdw_last_error(void) { return g_host_err.c_str(); }
 extern "C" int detsdw_create(const detsdw_params* p, detsdw_replica** out) {
     if (!p || !out) { g_host_err = "null argument"; return DQMC_EINVAL; }
     *out = nullptr;
-    GUARD({ DetSDW* d = new DetSDW(*p); *out = new detsdw_replica{d}; })
+    GUARD({ DetSDW* d = new DetSDW(*p); *out = new detsdw_replica{d, 0}; })
+}
+extern "C" int detsdw_create_batch(const detsdw_params* p, int nchains, detsdw_replica** out) {
+    if (!p || !out) { g_host_err = "null argument"; return DQMC_EINVAL; }
+    *out = nullptr;
+    GUARD({ DetSDW* d = new DetSDW(p, nchains); *out = new detsdw_replica{d, 0}; })
+}
+extern "C" int detsdw_num_chains(detsdw_replica* r) { return r ? r->impl->numChains() : 0; }
+extern "C" int detsdw_select_chain(detsdw_replica* r, int chain) {
+    if (!r || chain < 0 || chain >= r->impl->numChains()) { g_host_err = "chain index out of range"; return DQMC_EINVAL; }
+    r->sel = chain;
+    return DQMC_OK;
 }
 extern "C" void detsdw_destroy(detsdw_replica* r) { if (r) { delete r->impl; delete r; } }
 extern "C" int detsdw_sweep(detsdw_replica* r, int tm) { GUARD(r->impl->sweep(tm != 0)) }
 extern "C" int detsdw_sweep_thermalization(detsdw_replica* r) { GUARD(r->impl->sweepThermalization()) }
-extern "C" int detsdw_get_info(detsdw_replica* r, detsdw_info* out) { GUARD(r->impl->getInfo(*out)) }
-extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { GUARD(r->impl->getPhi(phi)) }
-extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { GUARD(r->impl->setPhi(phi)) }
-extern "C" int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g) { GUARD(r->impl->getGreen(g)) }
-extern "C" int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv) { GUARD(r->impl->getGreenInvSv(sv)) }
-extern "C" double detsdw_rng_rand01(detsdw_replica* r) { return r->impl->rand01(); }
+extern "C" int detsdw_get_info(detsdw_replica* r, detsdw_info* out) { GUARD(r->impl->getInfo(*out, r->sel)) }
+extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { GUARD(r->impl->getPhi(phi, r->sel)) }
+extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { GUARD(r->impl->setPhi(phi, r->sel)) }
+extern "C" int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g) { GUARD(r->impl->getGreen(g, r->sel)) }
+extern "C" int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv) { GUARD(r->impl->getGreenInvSv(sv, r->sel)) }
+extern "C" double detsdw_rng_rand01(detsdw_replica* r) { return r->impl->rand01(r->sel); }
 extern "C" dqmc_ctx* detsdw_ctx(detsdw_replica* r) { return r ? r->impl->ctx() : nullptr; }
-extern "C" double detsdw_get_exchange_parameter_value(detsdw_replica* r) { return r->impl->get_exchange_parameter_value(); }
-extern "C" int detsdw_set_exchange_parameter_value(detsdw_replica* r, double v) { GUARD(r->impl->set_exchange_parameter_value(v)) }
+extern "C" double detsdw_get_exchange_parameter_value(detsdw_replica* r) { return r->impl->get_exchange_parameter_value(r->sel); }
+extern "C" int detsdw_set_exchange_parameter_value(detsdw_replica* r, double v) { GUARD(r->impl->set_exchange_parameter_value(v, r->sel)) }
 extern "C" const char* detsdw_get_exchange_parameter_name(detsdw_replica* r) { return r->impl->get_exchange_parameter_name(); }
 extern "C" int detsdw_get_exchange_action_contribution(detsdw_replica* r, double* out) {
-    GUARD(*out = r->impl->get_exchange_action_contribution())
+    GUARD(*out = r->impl->get_exchange_action_contribution(r->sel))
 }
-extern "C" int detsdw_get_control_data(detsdw_replica* r, detsdw_control_data* out) { GUARD(r->impl->get_control_data(*out)) }
-extern "C" int detsdw_set_control_data(detsdw_replica* r, const detsdw_control_data* in) { GUARD(r->impl->set_control_data(*in)) }
+extern "C" int detsdw_get_control_data(detsdw_replica* r, detsdw_control_data* out) { GUARD(r->impl->get_control_data(*out, r->sel)) }
+extern "C" int detsdw_set_control_data(detsdw_replica* r, const detsdw_control_data* in) { GUARD(r->impl->set_control_data(*in, r->sel)) }
 // detsdwopdim.cpp:5251-5264 (Hukushima & Nemoto 1996)
 extern "C" double detsdw_replica_exchange_probability(double par1, double action1, double par2, double action2) {
     const double delta = (par1 - par2) * (action2 - action1);

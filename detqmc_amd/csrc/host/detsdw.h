@@ -20,46 +20,59 @@ struct ParameterWrong : GeneralError {
     explicit ParameterWrong(const std::string& msg) : GeneralError(DQMC_EINVAL, msg) {}
 };
 
+// One object drives nb >= 1 replicas ("chains") that share lattice, temperature and couplings and differ in
+// RNG stream (rngSeed / simindex), field configuration and the exchange parameter r -- exactly the set of
+// replicas of a DetQMCPT run (src/detqmcpt.h).  All chains advance in lockstep through ONE kernel context
+// (dqmc_create_batch), i.e. every launch carries all chains; nb = 1 is the reference's single replica.
+// Per-replica methods take the chain index b.
 class DetSDW {
 public:
-    explicit DetSDW(const detsdw_params& pars);     // createReplica + ctor
+    explicit DetSDW(const detsdw_params& pars) : DetSDW(&pars, 1) {}     // createReplica + ctor
+    DetSDW(const detsdw_params* pars, int nchains);
     ~DetSDW();
     DetSDW(const DetSDW&) = delete;
     DetSDW& operator=(const DetSDW&) = delete;
 
+    int numChains() const { return (int)ch_.size(); }
     void sweep(bool takeMeasurements);
     void sweepThermalization();
 
     // replica exchange surface
-    double get_exchange_parameter_value() const { return pars_.r; }
-    void set_exchange_parameter_value(double r);
+    double get_exchange_parameter_value(int b = 0) const { return ch_[b].pars.r; }
+    void set_exchange_parameter_value(double r, int b = 0);
     const char* get_exchange_parameter_name() const { return "r"; }
-    double get_exchange_action_contribution();
-    void get_control_data(detsdw_control_data& out);
-    void set_control_data(const detsdw_control_data& in);
+    double get_exchange_action_contribution(int b = 0);
+    void get_control_data(detsdw_control_data& out, int b = 0);
+    void set_control_data(const detsdw_control_data& in, int b = 0);
 
-    void getInfo(detsdw_info& out);
-    void getPhi(double* phi);
-    void setPhi(const double* phi);
-    void getGreen(dqmc_cplx* g);
-    void getGreenInvSv(double* sv);
-    double rand01() { return rng_.rand01(); }
+    void getInfo(detsdw_info& out, int b = 0);
+    void getPhi(double* phi, int b = 0);
+    void setPhi(const double* phi, int b = 0);
+    void getGreen(dqmc_cplx* g, int b = 0);
+    void getGreenInvSv(double* sv, int b = 0);
+    double rand01(int b = 0) { return ch_[b].rng.rand01(); }
     dqmc_ctx* ctx() { return ctx_; }
 
 private:
     enum SweepDirection { Up = +1, Down = -1 };
-    detsdw_params pars_;
+    struct Chain {
+        detsdw_params pars;
+        RngStream rng;
+        std::vector<double> phi;               // host mirror, valid after syncPhiFromDevice(b)
+        int acceptedGlobalShifts = 0, attemptedGlobalShifts = 0;
+        double phiDelta = 0.5, lastAccRatio = 0.0;
+        Chain(const detsdw_params& p) : pars(p), rng(p.rngSeed, (uint32_t)p.simindex + 1u) {}   // detqmc.h:181
+    };
+    std::vector<Chain> ch_;
     int N_, MSF_, ng_, m_, s_, n_, opdim_;
-    RngStream rng_;
     dqmc_ctx* ctx_ = nullptr;
     SweepDirection lastSweepDir_ = Up;
     int performedSweeps_ = 0;
-    int acceptedGlobalShifts_ = 0, attemptedGlobalShifts_ = 0;
-    std::vector<double> phi_;                  // host mirror, valid after syncPhiFromDevice()
-    double phiDelta_ = 0.5, lastAccRatio_ = 0.0;
 
     void check(int rc, const char* what);
-    void setupRandomField();
+    void select(int b);
+    static void normalise(detsdw_params& p, int& bcv);
+    void setupRandomField(Chain& c);
     void setupUdVStorage_and_calculateGreen();
     void sweep_skeleton(bool thermalization);
     void sweepDown(bool thermalization);
@@ -69,10 +82,9 @@ private:
     void endLocalUpdates();
     void globalMove();
     void attemptGlobalShiftMove();
-    double phiAction() const;
-    void syncPhiFromDevice();
-    double& phi(int site, int dim, int k) { return phi_[(size_t)site + (size_t)N_ * (dim + (size_t)opdim_ * k)]; }
-    double phi(int site, int dim, int k) const { return phi_[(size_t)site + (size_t)N_ * (dim + (size_t)opdim_ * k)]; }
+    double phiAction(const Chain& c) const;
+    void syncPhiFromDevice(int b);
+    size_t phiIdx(int site, int dim, int k) const { return (size_t)site + (size_t)N_ * (dim + (size_t)opdim_ * k); }
 };
 
 }  // namespace detqmc

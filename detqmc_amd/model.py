@@ -70,15 +70,16 @@ class KernelContext:
 
     def __init__(self, opdim, L, m, s, dtau, delaySteps=16, bc="pbc", weakZflux=False, r=-1.0, c=3.0, u=1.0,
                  lambda_=1.0, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, mux=-0.5, muy=-0.5,
-                 accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd", checkerboard=True):
+                 accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd", checkerboard=True, nchains=1):
         self.lib = load()
         p = _lib.dqmc_params(opdim=opdim, L=L, m=m, s=s, delaySteps=delaySteps, bc=BC[bc],
                              weakZflux=int(weakZflux), phi2bosons=int(phi2bosons), device=device,
                              stabilisation=STABILISATION[stabilisation], cb_none=int(not checkerboard), dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
                              tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio)
         h = C.c_void_p()
-        check(self.lib.dqmc_create(C.byref(p), C.byref(h)))
+        check(self.lib.dqmc_create_batch(C.byref(p), nchains, C.byref(h)))
         self.h = h
+        self.nchains = nchains
         self.opdim, self.L, self.m, self.s = opdim, L, m, s
         self.N = L * L
         self.MSF = 4 if opdim == 3 else 2
@@ -95,6 +96,10 @@ class KernelContext:
             self.close()
         except Exception:
             pass
+
+    def select_chain(self, b):
+        """host-buffer calls (fields, G, sv, UdV, uniforms, update state, ...) refer to chain b from now on"""
+        check(self.lib.dqmc_select_chain(self.h, b))
 
     # fields: phi given/returned as (m+1, N, OPDIM) [oracle layout]; the ABI uses (N, OPDIM, m+1) col-major
     def set_fields(self, phi_kNd):
@@ -246,28 +251,49 @@ class _CtxView(KernelContext):
         self.h = None
 
 
-class DetSDW:
-    """The replica (C++ host layer): same method names as the reference's DetSDW / DetModel."""
+def _host_params(pars: SDWParams):
+    return _lib.detsdw_params(
+        opdim=pars.opdim, L=pars.L, m=pars.m, s=pars.s, delaySteps=pars.delaySteps,
+        globalShift=int(pars.globalShift), globalUpdateInterval=pars.globalUpdateInterval,
+        weakZflux=int(pars.weakZflux), phi2bosons=int(pars.phi2bosons), device=pars.device,
+        simindex=pars.simindex, rngSeed=pars.rngSeed,
+        has_mux_muy=int(pars.mux is not None and pars.muy is not None),
+        updateMethod=UPDATE_METHOD[pars.updateMethod], bc=pars.bc.encode(),
+        beta=pars.beta, dtau=pars.dtau, r=pars.r, c=pars.c, u=pars.u, lambda_=pars.lambda_,
+        txhor=pars.txhor, txver=pars.txver, tyhor=pars.tyhor, tyver=pars.tyver,
+        mu=pars.mu, mux=pars.mux or 0.0, muy=pars.muy or 0.0, accRatio=pars.accRatio, cdwU=pars.cdwU,
+        stabilisation=STABILISATION[pars.stabilisation], cb_none=int(not pars.checkerboard))
 
-    def __init__(self, pars: SDWParams):
+
+class DetSDW:
+    """The replica (C++ host layer): same method names as the reference's DetSDW / DetModel.
+
+    Also serves as the view of ONE chain of a DetSDWBatch (`batch.chain(b)`): then it does not own the
+    handle, `sweep*` are not available on it (the batch sweeps all chains in lockstep) and every call first
+    selects its chain."""
+
+    def __init__(self, pars: SDWParams = None, _batch=None, _chain=0):
         self.lib = load()
-        p = _lib.detsdw_params(
-            opdim=pars.opdim, L=pars.L, m=pars.m, s=pars.s, delaySteps=pars.delaySteps,
-            globalShift=int(pars.globalShift), globalUpdateInterval=pars.globalUpdateInterval,
-            weakZflux=int(pars.weakZflux), phi2bosons=int(pars.phi2bosons), device=pars.device,
-            simindex=pars.simindex, rngSeed=pars.rngSeed,
-            has_mux_muy=int(pars.mux is not None and pars.muy is not None),
-            updateMethod=UPDATE_METHOD[pars.updateMethod], bc=pars.bc.encode(),
-            beta=pars.beta, dtau=pars.dtau, r=pars.r, c=pars.c, u=pars.u, lambda_=pars.lambda_,
-            txhor=pars.txhor, txver=pars.txver, tyhor=pars.tyhor, tyver=pars.tyver,
-            mu=pars.mu, mux=pars.mux or 0.0, muy=pars.muy or 0.0, accRatio=pars.accRatio, cdwU=pars.cdwU,
-            stabilisation=STABILISATION[pars.stabilisation], cb_none=int(not pars.checkerboard))
+        self._chain = _chain
+        self._batch = _batch
+        if _batch is not None:
+            self.h = _batch.h
+            self.pars = _batch.pars_list[_chain]
+            return
+        p = _host_params(pars)
         h = C.c_void_p()
         check(self.lib.detsdw_create(C.byref(p), C.byref(h)), host=True)
         self.h = h
         self.pars = pars
 
+    def _sel(self):
+        if self._batch is not None:
+            check(self.lib.detsdw_select_chain(self.h, self._chain), host=True)
+
     def close(self):
+        if self._batch is not None:
+            self.h = None
+            return
         if self.h:
             self.lib.detsdw_destroy(self.h)
             self.h = None
@@ -279,13 +305,18 @@ class DetSDW:
             pass
 
     def sweep(self, takeMeasurements=False):
+        if self._batch is not None:
+            raise RuntimeError("a chain of a batch cannot sweep on its own: call DetSDWBatch.sweep()")
         check(self.lib.detsdw_sweep(self.h, int(takeMeasurements)), host=True)
 
     def sweepThermalization(self):
+        if self._batch is not None:
+            raise RuntimeError("a chain of a batch cannot sweep on its own: call DetSDWBatch.sweepThermalization()")
         check(self.lib.detsdw_sweep_thermalization(self.h), host=True)
 
     @property
     def info(self):
+        self._sel()
         i = _lib.detsdw_info()
         check(self.lib.detsdw_get_info(self.h, C.byref(i)), host=True)
         return i
@@ -293,17 +324,20 @@ class DetSDW:
     @property
     def phi(self):
         """(m+1, N, OPDIM) like the oracle; the ABI hands out the reference layout."""
+        self._sel()
         i = self.info
         a = np.zeros((i.N, i.opdim, i.m + 1), order="F")
         check(self.lib.detsdw_get_phi(self.h, a.ctypes.data_as(_lib._DP)), host=True)
         return np.transpose(a, (2, 0, 1)).copy()
 
     def set_phi(self, phi_kNd):
+        self._sel()
         ref = np.asfortranarray(np.transpose(np.asarray(phi_kNd, dtype=np.float64), (1, 2, 0)))
         check(self.lib.detsdw_set_phi(self.h, ref.ctypes.data_as(_lib._DP)), host=True)
 
     @property
     def g(self):
+        self._sel()
         n = self.info.n_g
         g = np.zeros((n, n), dtype=np.complex128, order="F")
         check(self.lib.detsdw_get_green(self.h, g.ctypes.data), host=True)
@@ -311,36 +345,89 @@ class DetSDW:
 
     @property
     def g_inv_sv(self):
+        self._sel()
         sv = np.zeros(self.info.n_g)
         check(self.lib.detsdw_get_green_inv_sv(self.h, sv.ctypes.data_as(_lib._DP)), host=True)
         return sv
 
     def rand01(self):
+        self._sel()
         return self.lib.detsdw_rng_rand01(self.h)
 
     @property
     def kernel_context(self):
-        return _CtxView(self.lib, self.lib.detsdw_ctx(self.h), self.info)
+        kc = _CtxView(self.lib, self.lib.detsdw_ctx(self.h), self.info)
+        check(self.lib.dqmc_select_chain(kc.h, self._chain))
+        return kc
 
     # replica exchange surface (reference src/detsdwopdim.h:116-153)
     def get_exchange_parameter_value(self):
+        self._sel()
         return self.lib.detsdw_get_exchange_parameter_value(self.h)
 
     def set_exchange_parameter_value(self, v):
+        self._sel()
         check(self.lib.detsdw_set_exchange_parameter_value(self.h, v), host=True)
 
     def get_exchange_parameter_name(self):
         return self.lib.detsdw_get_exchange_parameter_name(self.h).decode()
 
     def get_exchange_action_contribution(self):
+        self._sel()
         v = C.c_double(0)
         check(self.lib.detsdw_get_exchange_action_contribution(self.h, C.byref(v)), host=True)
         return v.value
 
     def get_control_data(self):
+        self._sel()
         cd = _lib.detsdw_control_data()
         check(self.lib.detsdw_get_control_data(self.h, C.byref(cd)), host=True)
         return cd
 
     def set_control_data(self, cd):
+        self._sel()
         check(self.lib.detsdw_set_control_data(self.h, C.byref(cd)), host=True)
+
+
+class DetSDWBatch:
+    """The replicas of one parallel-tempering ensemble on ONE GPU, swept in lockstep by one kernel context
+    (detsdw_create_batch): every launch carries all chains, which is what fills the chip.  The parameter sets
+    may differ only in r, rngSeed and simindex; chain b follows exactly the Markov chain of DetSDW(pars[b])."""
+
+    def __init__(self, pars_list):
+        self.lib = load()
+        self.pars_list = list(pars_list)
+        arr = (_lib.detsdw_params * len(self.pars_list))(*[_host_params(p) for p in self.pars_list])
+        h = C.c_void_p()
+        check(self.lib.detsdw_create_batch(arr, len(self.pars_list), C.byref(h)), host=True)
+        self.h = h
+        self.chains = [DetSDW(_batch=self, _chain=b) for b in range(len(self.pars_list))]
+
+    def __len__(self):
+        return len(self.chains)
+
+    def chain(self, b):
+        return self.chains[b]
+
+    def sweep(self, takeMeasurements=False):
+        check(self.lib.detsdw_sweep(self.h, int(takeMeasurements)), host=True)
+
+    def sweepThermalization(self):
+        check(self.lib.detsdw_sweep_thermalization(self.h), host=True)
+
+    @property
+    def kernel_context(self):
+        return _CtxView(self.lib, self.lib.detsdw_ctx(self.h), self.chains[0].info)
+
+    def close(self):
+        if self.h:
+            for c in self.chains:
+                c.h = None
+            self.lib.detsdw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -77,6 +77,14 @@ typedef struct detsdw_control_data {
  * RNG with (rngSeed, simindex + 1) (src/detqmc.h:181), draws the random field, builds UdV storage and
  * G(beta) */
 int detsdw_create(const detsdw_params* p, detsdw_replica** out);
+/* The replicas of one parallel-tempering ensemble held by ONE process / GPU (the reference holds one replica per
+ * MPI rank, src/detqmcpt.h:300-420): p[0..nchains) may differ only in r, rngSeed and simindex.  All chains
+ * sweep in lockstep (every kernel launch carries all of them); each follows exactly the Markov chain a
+ * single replica created from p[b] would.  detsdw_sweep* act on all chains, every other call below on the
+ * chain chosen with detsdw_select_chain (default 0). */
+int detsdw_create_batch(const detsdw_params* p, int nchains, detsdw_replica** out);
+int detsdw_select_chain(detsdw_replica* r, int chain);
+int detsdw_num_chains(detsdw_replica* r);
 void detsdw_destroy(detsdw_replica* r);
 const char* detsdw_last_error(void);
 

@@ -469,3 +469,84 @@ def test_cold_and_large_o3_trajectories_vs_reference(name, stab):
     nxt = np.array([rep.rand01() for _ in range(4)])
     assert np.array_equal(nxt, g["rng_next"])
     rep.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# batched chains: nb replicas in lockstep through one context (grid.z = chain)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stab", ["svd", "qr"])
+@pytest.mark.parametrize("name", ["o2_L4_gshift", "o3_L4", "o2_L6_seed"])
+def test_batched_chains_follow_the_single_replica_chains(name, stab):
+    """Chain 0 of the batch has the fixture's parameters -> must reproduce the REFERENCE trajectory; the other
+    chains (other seeds, other r) must be identical to single-replica runs with the same parameters."""
+    import dataclasses
+    from detqmc_amd import DetSDW, DetSDWBatch
+    g = load_golden(name)
+    p0 = _sdw_params(g["params"], stabilisation=stab)
+    plist = [p0,
+             dataclasses.replace(p0, r=p0.r + 0.4, rngSeed=777, simindex=1),
+             dataclasses.replace(p0, r=p0.r - 0.3, rngSeed=p0.rngSeed, simindex=5)]
+    batch = DetSDWBatch(plist)
+    singles = [DetSDW(p) for p in plist[1:]]
+    nsweeps = 0
+    while f"sweep{nsweeps + 1}_phi" in g:
+        nsweeps += 1
+    for i in range(1, nsweeps + 1):
+        batch.sweepThermalization()
+        for sgl in singles:
+            sgl.sweepThermalization()
+        c0 = batch.chain(0)
+        assert np.array_equal(c0.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}: chain 0 left the reference chain"
+        assert relerr(c0.g, g[f"sweep{i}_g"]) < TOL
+        inf = c0.info
+        assert inf.phiDelta == g[f"sweep{i}_phiDelta"][0]
+        assert inf.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert inf.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+        for b, sgl in enumerate(singles, start=1):
+            cb = batch.chain(b)
+            assert np.array_equal(cb.phi, sgl.phi), f"sweep {i}: chain {b} differs from its single-replica run"
+            assert relerr(cb.g, sgl.g) < 1e-12
+            ib, isg = cb.info, sgl.info
+            assert ib.phiDelta == isg.phiDelta and ib.rngDrawn == isg.rngDrawn
+            assert ib.acceptedGlobalShifts == isg.acceptedGlobalShifts
+            assert abs(cb.get_exchange_action_contribution() - sgl.get_exchange_action_contribution()) < 1e-12
+    nxt = np.array([batch.chain(0).rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"])
+    for sgl in singles:
+        sgl.close()
+    batch.close()
+
+
+def test_batch_rejects_replicas_that_differ_in_more_than_r_and_seed():
+    import dataclasses
+    from detqmc_amd import DetSDWBatch, DqmcError
+    g = load_golden("o2_L4")
+    p0 = _sdw_params(g["params"])
+    with pytest.raises(DqmcError):
+        DetSDWBatch([p0, dataclasses.replace(p0, u=p0.u + 0.1)])
+
+
+def test_batched_kernel_context_entry_points():
+    """gemm / bmult / decompose through a 3-chain context: results of the selected chain; per-chain fields."""
+    from detqmc_amd import KernelContext
+    from detsdw_oracle import DetSDWOracle, make_test_matrix
+    g = load_golden("o2_L4")
+    ctx, op = _ctx_from_params(g["params"], nchains=3)
+    o = DetSDWOracle(op)
+    phi = _golden_phi(g, "init_phi")
+    A = make_test_matrix(ctx.ng)
+    k = 3
+    rng = np.random.default_rng(3)
+    fields = [phi, phi * 0.5, phi + 0.1 * rng.standard_normal(phi.shape)]
+    for b in range(3):
+        ctx.select_chain(b)
+        ctx.set_fields(fields[b])
+    for b in range(3):
+        ctx.select_chain(b)
+        o.phi = fields[b].copy()
+        o.updateCoshSinhTermsPhi()
+        assert relerr(ctx.leftMultiplyBmat(A, k, 0), o.leftMultiplyBmat(A, k, 0)) < 1e-12, b
+        assert relerr(ctx.rightMultiplyBmatInv(A, k, 0), o.rightMultiplyBmatInv(A, k, 0)) < 1e-12, b
+        B = rng.standard_normal(A.shape) + 1j * rng.standard_normal(A.shape)
+        assert relerr(ctx.gemm(0, 1, A, B), A @ B.conj().T) < 1e-13
+    ctx.close()
