@@ -4,11 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One process per GPU (for N > 1 launched by torch.distributed.run).  A "step" is one
-sweepThermalization() of every replica the rank drives (--replicas R independent chains per GPU, each
-in its own worker process = own HIP runtime and hardware queues; value = all sweeps of all chains / time;
-`sweeps_per_s_per_chain` is the single-chain rate): SDW O(2), L=16, beta=10, dtau=0.1 (m=100), s=10, checkerboard,
-delayed updates (delaySteps=16), no fermion measurements.  Each rank runs an
-independent Markov chain (simindex = rank, as the reference's DetQMC does per process); there is no
+sweepThermalization() of every replica the rank drives: --workers W worker processes per GPU (own HIP
+runtime and hardware queues each), each holding --batch B independent chains that advance in lockstep
+through ONE kernel context (every launch carries all B chains, grid.z = chain).  value = all sweeps of all
+chains / time; `sweeps_per_s_per_chain` is the single-chain rate.  Workload: SDW O(2), L=16, beta=10,
+dtau=0.1 (m=100), s=10, checkerboard, delayed updates (delaySteps=16), no fermion measurements (SURVEY.md
+section 8d).  Every chain is an independent Markov chain with its own RNG stream (simindex), like the
+replicas the reference's DetQMC / DetQMCPT run one per MPI process; there is no
 data-path collective, so the value is the sum over ranks and scaling is weak.  Rank 0 prints ONE
 JSON line with `roofline` (dominant kernel, timed live with HIP events on the kernel's own stream)
 and, at N=1, `cpu_baseline` (the real reference binary from oracle/_ref when it runs on this host,
@@ -31,8 +33,8 @@ WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=int(os.envi
                 stabilisation=os.environ.get("DQMC_STABILISATION", "qr"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
-DEFAULT_THREADS = 1
-DEFAULT_REPLICAS = 4           # chains per GPU; a Jacobi round occupies 64 of the 256 CUs
+DEFAULT_BATCH = 32             # chains per kernel context (lockstep batch): fills the 256 CUs
+DEFAULT_WORKERS = 2            # contexts per GPU: one's latency-bound decision kernel overlaps the other's GEMMs
 
 
 def cpu_baseline(max_seconds=200):
@@ -66,56 +68,34 @@ def cpu_baseline(max_seconds=200):
 
 
 def worker(a):
-    """a.threads chains in one process (own HIP runtime / queues), one host thread and one stream per chain:
-    build, warm up, wait for GO, run, report."""
-    import threading
-    from detqmc_amd import DetSDW, SDWParams
-    T = max(1, a.threads)
-    reps = [DetSDW(SDWParams(device=a.device, simindex=a.simindex * T + i, **WORKLOAD)) for i in range(T)]
-    ctxs = [r.kernel_context for r in reps]
-
-    def run_all(nsweeps):
-        if T == 1:
-            for _ in range(nsweeps):
-                reps[0].sweepThermalization()
-            return
-        errs = []
-
-        def work(r):
-            try:
-                for _ in range(nsweeps):
-                    r.sweepThermalization()          # one C call per sweep: the GIL is released inside
-            except Exception as e:
-                errs.append(e)
-        th = [threading.Thread(target=work, args=(r,)) for r in reps]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
-
-    run_all(a.warmup)
+    """One kernel context with a.batch chains in lockstep: build, warm up, wait for GO, run, report."""
+    import dataclasses
+    from detqmc_amd import DetSDWBatch, SDWParams
+    B = max(1, a.batch)
+    p0 = SDWParams(device=a.device, **WORKLOAD)
+    batch = DetSDWBatch([dataclasses.replace(p0, simindex=a.simindex * B + i) for i in range(B)])
+    ctx = batch.kernel_context
+    for _ in range(a.warmup):
+        batch.sweepThermalization()
     if a.profile:
-        ctxs[0].profile_enable(True)
-    for c in ctxs:
-        c.synchronize()
+        ctx.profile_enable(True)
+    ctx.synchronize()
     print("READY", flush=True)
     if sys.stdin.readline().strip() != "GO":
         return
     t0 = time.perf_counter()
-    run_all(a.steps)
-    for c in ctxs:
-        c.synchronize()
+    for _ in range(a.steps):
+        batch.sweepThermalization()          # one C call per lockstep sweep of all B chains
+    ctx.synchronize()
     dt = time.perf_counter() - t0
-    info = reps[0].info
-    out = {"dt": dt, "n_g": info.n_g, "m": info.m, "acceptance": info.lastAccRatioLocal_phi}
+    info = batch.chain(0).info
+    out = {"dt": dt, "n_g": info.n_g, "m": info.m,
+           "acceptance": [batch.chain(i).info.lastAccRatioLocal_phi for i in range(min(B, 4))]}
     if a.profile:
-        prof = ctxs[0].profile_read()
+        prof = ctx.profile_read()
         out["prof"] = {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}
     print("RESULT " + json.dumps(out), flush=True)
-    for r in reps:
-        r.close()
+    batch.close()
 
 
 def main():
@@ -124,10 +104,10 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--replicas", type=int, default=int(os.environ.get("DQMC_REPLICAS_PER_GPU", str(DEFAULT_REPLICAS))),
-                    help="independent Markov chains per GPU, one worker process each")
-    ap.add_argument("--threads", type=int, default=int(os.environ.get("DQMC_CHAINS_PER_WORKER", str(DEFAULT_THREADS))),
-                    help="chains per worker process (host threads)")
+    ap.add_argument("--workers", type=int, default=int(os.environ.get("DQMC_WORKERS_PER_GPU", str(DEFAULT_WORKERS))),
+                    help="worker processes (kernel contexts) per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DQMC_CHAINS_PER_CONTEXT", str(DEFAULT_BATCH))),
+                    help="independent Markov chains per context, advanced in lockstep (grid.z = chain)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--simindex", type=int, default=0, help=argparse.SUPPRESS)
@@ -155,7 +135,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    R = max(1, a.replicas)
+    R = max(1, a.workers)
+    B = max(1, a.batch)
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
               "TORCHELASTIC_RUN_ID"):
@@ -163,7 +144,7 @@ def main():
     procs = []
     for i in range(R):
         cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--device", str(local), "--simindex",
-               str(rank * R + i), "--steps", str(a.steps), "--warmup", str(a.warmup), "--threads", str(a.threads)] + (["--profile"] if i == 0 else [])
+               str(rank * R + i), "--steps", str(a.steps), "--warmup", str(a.warmup), "--batch", str(B)] + (["--profile"] if i == 0 else [])
         procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env))
 
     def read_tag(p, tag):
@@ -198,19 +179,20 @@ def main():
         N, MSF, D, OPD = n // 2, 2, WORKLOAD["delaySteps"], WORKLOAD["opdim"]
         fam = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items() if isinstance(v, tuple) and k != "jacobi"}
 
-        def hbm(name, kernel, ms, launches, bytes_per_launch, note):
+        def hbm(name, kernel, ms, launches, bytes_per_chain, note):
+            bytes_per_launch = bytes_per_chain * B          # every launch carries all B chains of the context
             us = 1e3 * ms / max(launches, 1)
             ach = bytes_per_launch / (us * 1e-6) / 1e9 if launches else 0.0
             return {"family": name, "kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "avg_launch_us": us, "launches": launches, "device_ms": ms, "note": note}
+                    "avg_launch_us": us, "launches": launches, "device_ms": ms, "chains_per_launch": B, "note": note}
 
         roofs = []
         # decision kernel: per proposal (OPDIM+1) uniforms, 7 field vectors, cosh/sinh, G[c,I], G[I,c], G[c,c]
         # with |I| = MSF*D/2 on average; N proposals per slice spread over ceil(N/D) launches
         cand_bytes = (OPD + 1) * 8 + 7 * OPD * 8 + 16 + (2 * MSF * (MSF * D // 2) + MSF * MSF) * 16
         roofs.append(hbm("decide", "k_update_decide<2>", *prof["decide"], N * cand_bytes / ((N + D - 1) // D),
-                         "sequential Metropolis chain of one slice: ONE wavefront by construction, latency bound"))
+                         "sequential Metropolis chain of one slice: one workgroup per chain by construction, latency bound"))
         if WORKLOAD["stabilisation"] == "svd":
             r = hbm("decomp", "k_jacobi_round<8,2>", prof["decomp_round_ms"], prof["decomp_rounds"], 4.0 * n * n * 16.0,
                     "one Jacobi round reads and writes every column of A and V once")
@@ -241,7 +223,7 @@ def main():
         roofs.sort(key=lambda r: -r["device_ms"])
         res = {
             "metric": "DQMC sweeps/sec (SDW-O2 L=16 beta=10 fp64)",
-            "value": world * R * a.threads * a.steps / dt,
+            "value": world * R * B * a.steps / dt,
             "unit": "sweeps/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -254,14 +236,14 @@ def main():
             "dtype": "f64",
             "data": "synthetic (random initial field, fixed seed)",
             "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(16) "
-                                   "sweepThermalization, %d independent chains per GPU (%d worker processes x %d threads), stabilisation=%s"
-                                   % (R * a.threads, R, a.threads, WORKLOAD["stabilisation"]),
-                       "n_g": n, "m": r0["m"], "replicas_per_gpu": R * a.threads, "worker_processes_per_gpu": R,
-                       "chains_per_worker": a.threads},
+                                   "sweepThermalization, %d independent chains per GPU (%d kernel contexts x %d lockstep chains), stabilisation=%s"
+                                   % (R * B, R, B, WORKLOAD["stabilisation"]),
+                       "n_g": n, "m": r0["m"], "replicas_per_gpu": R * B, "contexts_per_gpu": R,
+                       "chains_per_context": B},
             "roofline": roofs[0],
             "roofline_other_kernels": roofs[1:],
-            "device_ms_by_family_chain0": fam,
-            "decompositions_chain0": {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
+            "device_ms_by_family_context0": fam,
+            "decompositions_context0": {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
                                       "max_sweeps": prof["svd_sweeps_max"], "qr_calls": prof["qr_calls"]},
             "acceptance": r0["acceptance"],
         }

@@ -841,12 +841,8 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
             ProfScope ps(c, FAM_GATHER, 1);
             launch_update_gather(c->lc, c->hm, c->us, c->G, c->W, c->X, c->Gr);
         }
-        GemmArgs g;
-        memset(&g, 0, sizeof(g));
-        g.A = c->X; g.lda = c->n_g; g.opA = 0; g.B = c->Gr; g.ldb = WD; g.opB = 0; g.C = c->G; g.ldc = c->n_g;
-        g.M = g.N = c->n_g; g.K = WD; g.Kdev = &c->us->block_j; g.Kmul = c->MSF; g.accumulate = 1;
         ProfScope ps(c, FAM_FLUSH, 1);
-        launch_gemm(c->lc, g);
+        launch_flush(c->lc, c->X, c->n_g, c->Gr, WD, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
     }
     return DQMC_OK;
 }
@@ -855,6 +851,13 @@ extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
+    if (c->hm.dbg & 8) {     // developer phase timers of the decision kernel
+        DevUpdateState h;
+        HIPCHK(hipMemcpy(&h, selp(c, c->us), sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[decide cycles, chain %d, %llu launches]", c->sel, h.dbg_cycles[12]);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " t%d=%llu", i, h.dbg_cycles[i]);
+        fprintf(stderr, "\n");
+    }
     HIPCHK(hipMemcpy(out, &selp(c, c->us)->pub, sizeof(*out), hipMemcpyDeviceToHost));
     if (out->error) return fail(out->error, "device ran out of pre-drawn uniforms");
     return DQMC_OK;

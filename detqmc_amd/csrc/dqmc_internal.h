@@ -56,6 +56,7 @@ struct DevUpdateState {
     int slice_done;
     double r;                // this chain's exchange parameter (differs between the chains of a batch)
     int block_sites[DQMC_MAX_WDIM];
+    unsigned long long dbg_cycles[16];   // developer phase timers of the decision kernel (DQMC_DBG & 8)
 };
 
 // ---- launchers (implemented in the kernels_*.hip files) ---------------------------------------
@@ -79,6 +80,9 @@ struct GemmArgs {
     int sharedA, sharedB;       // operand is one matrix for all chains (not shifted by the chain stride)
 };
 void launch_gemm(const Launch& lc, const GemmArgs& a);
+// G += X Gr, K = min(Kmax, *Kdev * Kmul): the delayed-update flush as a register-only read-modify-write stream
+void launch_flush(const Launch& lc, const cplx* X, int ldx, const cplx* Gr, int ldg, cplx* G, int ldc, int n, int Kmax,
+                  const int* Kdev, int Kmul);
 
 // one-sided Jacobi SVD, M = U diag(d) V^H, d descending.  work: A (n*n), V (n*n), norms(n), rank(n),
 // flag (int).  Host-driven sweep loop with one flag read-back per sweep.  Returns sweeps used or <0.

@@ -156,23 +156,12 @@ __device__ __forceinline__ double u_wave_total(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// Everything the decision for ONE candidate site needs from global memory.  It is loaded one candidate
-// ahead (while the previous decision is being computed) so that the L2 round trip of the scattered G
-// entries and of the field values never sits on the critical path of the sequential chain.
-template<int OPDIM, int MSF, int SLOTS>
-struct Candidate {
-    double uni[OPDIM + 2];       // window: the decision before may or may not have consumed one more uniform
-    double oldphi[OPDIM];
-    double tn[OPDIM];            // phi(later slice) + phi(earlier slice)
-    double sn[OPDIM];            // sum over the four space neighbours as they were when loaded
-    double coshO, sinhO;
-    int nb_prev;                 // how many of the four neighbours are the site decided just before
-    cplx Gcc[MSF][MSF];
-    cplx Gnp[MSF][MSF];          // G[c_this rows, c_prev cols]
-    cplx Gpn[MSF][MSF];          // G[c_prev rows, c_this cols]
-    cplx pu[SLOTS], pv[SLOTS];   // this lane's share of u = G[c, I], v = G[I, c] for the I known at issue time
-};
-
+// Everything the decision for ONE candidate site needs from global memory is loaded one candidate ahead
+// (while the previous decision is being computed), so the L2 round trip of the scattered G entries and of
+// the field values never sits on the critical path of the sequential chain.  The ~44 scalars (uniforms, field
+// values, cosh/sinh, G[c,c], G[c,prev], G[prev,c]) are gathered by ONE wavefront with ONE load instruction --
+// lane l loads item l -- and handed to the other waves through LDS: the same scalars loaded by every lane of
+// every wave (wave-uniform vector loads) cost ~40 x 4 trips through the address coalescer per proposal.
 template<int OPDIM>
 __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
                                                        const cplx* __restrict__ G, cplx* __restrict__ Wout,
@@ -185,14 +174,16 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     const int WD = MSF * D;
     extern __shared__ cplx smem[];
     cplx* W = smem;                       // [WD][WD] row-major: W[i*WD + i']
-    cplx* su = W + WD * WD;               // u[a][i]  = G[c_a, I_i]      [MSF][WD]
-    cplx* sv = su + MSF * WD;             // v[i][b]  = G[I_i, c_b]      [WD][MSF]
-    cplx* sp = sv + WD * MSF;             // p = W v                     [WD][MSF]
+    cplx* su2 = W + WD * WD;              // u[a][i]  = G[c_a, I_i]      2 x [MSF][WD]  (ping-pong per proposal)
+    cplx* sv2 = su2 + 2 * MSF * WD;       // v[i][b]  = G[I_i, c_b]      2 x [WD][MSF]
+    cplx* sp = sv2 + 2 * WD * MSF;        // p = W v                     [WD][MSF]
     cplx* sq = sp + WD * MSF;             // q = u W                     [MSF][WD]
-    cplx* spf = sq + MSF * WD;            // p F                         [WD][MSF]
-    __shared__ int isite[DQMC_MAX_WDIM];
+    double* sphi = (double*)(sq + MSF * WD);   // phi of slice k, [OPDIM][N]: all field reads and writes of the loop
+    __shared__ int isite[DQMC_MAX_WDIM];       //   go here, the accepted values reach global memory after the loop
+    __shared__ double sacc[DQMC_MAX_WDIM][OPDIM + 2];   // accepted: new phi, cosh, sinh
     const int tid = threadIdx.x;          // 4 waves: scalar Metropolis arithmetic is done redundantly by every
     const int lane = tid & 63;            // wave, the vector parts (p, q, W update) are split over all 256 threads
+    const int L = dm.L;
 
     int site = first ? 0 : us->site_cursor;
     int acc_count = first ? 0 : us->acc_count;
@@ -213,118 +204,192 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     const double* coshK = dm.coshT + (size_t)k * N;
     const double* sinhK = dm.sinhT + (size_t)k * N;
 
-    typedef Candidate<OPDIM, MSF, SLOTS> Cand;
-    // issue all loads for candidate `s`; `prev` = the site whose decision is still open (-1: none),
+    // ---- scalar items of one candidate, as doubles (lane l of wave 0 loads item l, l + 64, ...) ----
+    constexpr int O_UNI = 0;                       // OPDIM + 2 uniforms: the decision before may or may not have
+    constexpr int O_TL = O_UNI + OPDIM + 2;        //   consumed one more than the guess the loads were issued with
+    constexpr int O_TE = O_TL + OPDIM;             // phi(later slice), phi(earlier slice)
+    constexpr int O_CH = O_TE + OPDIM;
+    constexpr int O_SH = O_CH + 1;
+    constexpr int GBLK = 2 * MSF * MSF;            // one MSF x MSF complex block; blocks are aligned to their size so
+    constexpr int O_GCC = (O_SH + GBLK) / GBLK * GBLK;   // none straddles a group of 64 lanes:  G[c rows, c cols]
+    constexpr int O_GNP = O_GCC + 2 * MSF * MSF;   // G[c_this rows, c_prev cols]
+    constexpr int O_GPN = O_GNP + 2 * MSF * MSF;   // G[c_prev rows, c_this cols]
+    constexpr int NITEMS = O_GPN + 2 * MSF * MSF;
+    constexpr int NIT = (NITEMS + 63) / 64;
+    static_assert(O_GCC % 2 == 0, "complex items must be 16-byte aligned in LDS");
+    __shared__ __attribute__((aligned(16))) double scand[NIT * 64];
+
+    auto neighbours = [&](int s, int (&nbr)[4]) {
+        // neighbortable.h:34-36 (XPLUS, XMINUS, YPLUS, YMINUS), computed: a table look-up would put a dependent
+        // memory round trip in front of the field loads
+        const int sx = s % L, sy = s / L;
+        nbr[0] = sy * L + (sx + 1 == L ? 0 : sx + 1);
+        nbr[1] = sy * L + (sx == 0 ? L - 1 : sx - 1);
+        nbr[2] = (sy + 1 == L ? 0 : sy + 1) * L + sx;
+        nbr[3] = (sy == 0 ? L - 1 : sy - 1) * L + sx;
+    };
+    // issue all loads for candidate `s` (wave 0 only); `prev` = the site whose decision is still open (-1: none),
     // `curGuess` = RNG cursor if that decision consumes no acceptance uniform, nIknown = MSF * (#accepted so far)
-    auto fetch = [&](Cand& c, int s, int prev, unsigned long long curGuess, int nIknown) {
+    auto fetch = [&](double (&pre)[NIT], cplx (&pu)[SLOTS], cplx (&pv)[SLOTS], int s, int prev,
+                     unsigned long long curGuess, int nIknown) {
+        if (tid >= 64) return;
 #pragma unroll
-        for (int d = 0; d < OPDIM + 2; ++d) {
-            unsigned long long idx = curGuess + d;
-            c.uni[d] = (idx < avail) ? uni[idx] : 0.5;
-        }
-        c.nb_prev = 0;
-#pragma unroll
-        for (int d = 0; d < OPDIM; ++d) {
-            c.oldphi[d] = phik[d * N + s];
-            c.tn[d] = phiL[d * N + s] + phiE[d * N + s];
-            double sn = 0.0;
-#pragma unroll
-            for (int dir = 0; dir < 4; ++dir) sn += phik[d * N + dm.neigh[dir * N + s]];
-            c.sn[d] = sn;
-        }
-#pragma unroll
-        for (int dir = 0; dir < 4; ++dir) c.nb_prev += (dm.neigh[dir * N + s] == prev) ? 1 : 0;
-        c.coshO = coshK[s];
-        c.sinhO = sinhK[s];
-#pragma unroll
-        for (int a = 0; a < MSF; ++a)
-#pragma unroll
-            for (int b = 0; b < MSF; ++b) {
-                c.Gcc[a][b] = G[(size_t)(s + b * N) * ng + (s + a * N)];
-                if (prev >= 0) {
-                    c.Gnp[a][b] = G[(size_t)(prev + b * N) * ng + (s + a * N)];
-                    c.Gpn[a][b] = G[(size_t)(s + b * N) * ng + (prev + a * N)];
-                }
+        for (int q = 0; q < NIT; ++q) {
+            const int item = tid + 64 * q;
+            const double* addr = nullptr;
+            double dflt = 0.0;
+            if (item < O_TL) {
+                unsigned long long idx = curGuess + item;
+                if (idx < avail) addr = uni + idx;
+                dflt = 0.5;
+            } else if (item < O_TE) {
+                addr = phiL + (item - O_TL) * N + s;
+            } else if (item < O_CH) {
+                addr = phiE + (item - O_TE) * N + s;
+            } else if (item == O_CH) {
+                addr = coshK + s;
+            } else if (item == O_SH) {
+                addr = sinhK + s;
+            } else if (item >= O_GCC && item < NITEMS) {
+                const int t = item - O_GCC;
+                const int blk = t / (2 * MSF * MSF), e = t % (2 * MSF * MSF);
+                const int part = e & 1, ab = e >> 1, a = ab / MSF, b = ab % MSF;
+                const int row = (blk == 2 ? prev : s) + a * N, col = (blk == 1 ? prev : s) + b * N;
+                if (blk == 0 || prev >= 0) addr = (const double*)G + 2 * ((size_t)col * ng + row) + part;
             }
+            pre[q] = addr ? *addr : dflt;
+        }
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
-            int t = tid + 64 * q;
-            if (tid < 64 && t < MSF * nIknown) {
-                int a = t / nIknown, i = t - a * nIknown;
-                int Ii = isite[i / MSF] + (i % MSF) * N;
-                c.pu[q] = G[(size_t)Ii * ng + (s + a * N)];
-                int b = t % MSF, i2 = t / MSF;
-                int Ii2 = isite[i2 / MSF] + (i2 % MSF) * N;
-                c.pv[q] = G[(size_t)(s + b * N) * ng + Ii2];
+            const int t = tid + 64 * q;                   // (i, a): entry u[a][i] = G[c_a, I_i] and v[i][a] = G[I_i, c_a]
+            if (t < MSF * nIknown) {
+                const int a = t % MSF, i = t / MSF;
+                const int Ii = isite[i / MSF] + (i % MSF) * N;
+                pu[q] = G[(size_t)Ii * ng + (s + a * N)];
+                pv[q] = G[(size_t)(s + a * N) * ng + Ii];
             }
         }
     };
 
+    // developer phase timers (build with -DDQMC_DECIDE_TIMING, run with DQMC_DBG=8): cycles between TICK marks,
+    // accumulated over the launch.  Compiled out by default -- the counters cost ~26 SGPRs in a kernel that is
+    // already short of them.
+#ifdef DQMC_DECIDE_TIMING
+    unsigned long long tk[12], tlast = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) tk[i] = 0;
+    const bool timing = (dm.dbg & 8) != 0;
+#define TICK(n) do { if (timing) { unsigned long long t_ = __builtin_readcyclecounter(); tk[n] += t_ - tlast; tlast = t_; } } while (0)
+    if (timing) tlast = __builtin_readcyclecounter();
+#else
+#define TICK(n) do { } while (0)
+#endif
     int j = 0;
     const int dnow = min(D, N - site);            // delayStepsNow (:3052)
-    Cand cnd, nxt;
-    fetch(cnd, site, -1, cur, 0);
-    int cnd_nI = 0;                                // nI the u/v registers of cnd were loaded for
+    double pre[NIT];                               // wave 0: the prefetched scalar items, one per lane
+    cplx pu[SLOTS], pv[SLOTS];                     // wave 0: u = G[c, I], v = G[I, c] for the I known at issue time
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) pre[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) { pu[q] = make_double2(0.0, 0.0); pv[q] = make_double2(0.0, 0.0); }
+    fetch(pre, pu, pv, site, -1, cur, 0);
+    // No global store happens inside the loop: a store followed by a load that may alias makes the compiler wait
+    // for the store's round trip (s_waitcnt vmcnt(0)) before every prefetch.  The slice's field lives in LDS.
+    for (int t = tid; t < OPDIM * N; t += 256) sphi[t] = phik[t];
+    int cnd_nI = 0;                                // nI the u/v registers were loaded for
     int prev_site = -1;                            // site decided in the previous iteration
     bool prev_acc = false, prev_used_uniform = true;
-    double prev_newphi[OPDIM], prev_oldphi[OPDIM];
-#pragma unroll
-    for (int d = 0; d < OPDIM; ++d) { prev_newphi[d] = 0.0; prev_oldphi[d] = 0.0; }
 
+    int it = 0;                                    // proposal counter of this launch: selects the u/v buffer
     while (j < dnow && site < N) {
         if (cur + OPDIM + 1 > avail) { err = DQMC_ERNG; break; }
         const int nI = MSF * j;
-        // ---- land the prefetched u / v in LDS; patch in what the previous decision changed ----
+        cplx* su = su2 + (it & 1) * MSF * WD;
+        cplx* sv = sv2 + (it & 1) * WD * MSF;
+        // ---- A (wave 0): land the prefetched scalars and u / v in LDS; patch in what the previous decision
+        //      changed.  The u/v buffers alternate, so threads still reading the previous proposal's u are not
+        //      overtaken; scand is read right after barrier 1 and rewritten only after barrier 2. ----
+        if (tid < 64) {
 #pragma unroll
-        for (int q = 0; q < SLOTS; ++q) {
-            int t = tid + 64 * q;
-            if (tid < 64 && t < MSF * cnd_nI) {
-                int a = t / cnd_nI, i = t - a * cnd_nI;
-                su[a * WD + i] = cnd.pu[q];
-                int b = t % MSF, i2 = t / MSF;
-                sv[i2 * MSF + b] = cnd.pv[q];
+            for (int q = 0; q < NIT; ++q) scand[tid + 64 * q] = pre[q];
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                const int t = tid + 64 * q;
+                if (t < MSF * cnd_nI) {
+                    const int a = t % MSF, i = t / MSF;
+                    su[a * WD + i] = pu[q];
+                    sv[i * MSF + a] = pv[q];
+                }
+            }
+            // the site accepted last time joined I after the fetch: its u / v entries are G[c, prev], G[prev, c],
+            // which sit in the lanes O_GNP.. / O_GPN.. of `pre`
+            const int e = (tid < MSF * MSF) ? tid : 0;
+            constexpr int QN = O_GNP / 64, QP = O_GPN / 64;
+            static_assert((O_GNP + 2 * MSF * MSF - 1) / 64 == QN && (O_GPN + 2 * MSF * MSF - 1) / 64 == QP, "item block straddles a lane group");
+            cplx gnp = make_double2(__shfl(pre[QN], (O_GNP + 2 * e) & 63, 64), __shfl(pre[QN], (O_GNP + 2 * e + 1) & 63, 64));
+            cplx gpn = make_double2(__shfl(pre[QP], (O_GPN + 2 * e) & 63, 64), __shfl(pre[QP], (O_GPN + 2 * e + 1) & 63, 64));
+            if (prev_acc && tid < MSF * MSF) {
+                const int a = tid / MSF, b = tid % MSF;
+                su[a * WD + (nI - MSF + b)] = gnp;          // u[a][i] = G[c_a, I_i], I_i = prev + b N
+                sv[(nI - MSF + a) * MSF + b] = gpn;         // v[i][b] = G[I_i, c_b], I_i = prev + a N
             }
         }
-        if (prev_acc && tid < MSF * MSF) {            // the site accepted last time joined I after the fetch
-            int a = tid / MSF, b = tid % MSF;
-            cplx gnp = make_double2(0.0, 0.0), gpn = make_double2(0.0, 0.0);
-#pragma unroll
-            for (int aa = 0; aa < MSF; ++aa)
-#pragma unroll
-                for (int bb = 0; bb < MSF; ++bb)
-                    if (aa == a && bb == b) { gnp = cnd.Gnp[aa][bb]; gpn = cnd.Gpn[aa][bb]; }
-            su[a * WD + (nI - MSF + b)] = gnp;          // u[a][i] = G[c_a, I_i], I_i = prev + b N
-            sv[(nI - MSF + a) * MSF + b] = gpn;         // v[i][b] = G[I_i, c_b], I_i = prev + a N
-        }
+        TICK(0);
+        __syncthreads();                              // barrier 1 of 2: scalars, u, v (and last proposal's W update) visible
+        TICK(1);
+        // ---- C: start the loads of the NEXT candidate now; they complete while this decision is computed ----
+        const bool have_next = (site + 1 < N);
+        if (have_next && !(dm.dbg & 1)) fetch(pre, pu, pv, site + 1, site, cur + OPDIM, nI);
+        // ---- every thread picks up the candidate's scalars (broadcast LDS reads) ----
         // uniforms: skip the one the previous decision consumed for its acceptance test
         const int uoff = (prev_site >= 0 && prev_used_uniform) ? 1 : 0;
-        double oldphi[OPDIM], newphi[OPDIM], snb[OPDIM];
+        int nbr[4];
+        neighbours(site, nbr);
+        double oldphi[OPDIM], newphi[OPDIM], snb[OPDIM], tnb[OPDIM];
 #pragma unroll
         for (int d = 0; d < OPDIM; ++d) {
-            oldphi[d] = cnd.oldphi[d];
+            oldphi[d] = sphi[d * N + site];
             double low = -phiDelta, high = phiDelta;
-            newphi[d] = propose_component(oldphi[d], low, high, uoff ? cnd.uni[d + 1] : cnd.uni[d]);
-            // a neighbour that was updated after the prefetch: replace its old value by the accepted one
-            snb[d] = cnd.sn[d];
-            if (prev_acc && cnd.nb_prev) snb[d] += (double)cnd.nb_prev * (prev_newphi[d] - prev_oldphi[d]);
+            newphi[d] = propose_component(oldphi[d], low, high, scand[O_UNI + uoff + d]);
+            // XPLUS, XMINUS, YPLUS, YMINUS in the order of the reference's neighbour loop (:4208-4214)
+            snb[d] = ((0.0 + sphi[d * N + nbr[0]]) + sphi[d * N + nbr[1]]) + sphi[d * N + nbr[2]] + sphi[d * N + nbr[3]];
+            tnb[d] = scand[O_TL + d] + scand[O_TE + d];
         }
-        const double uacc = uoff ? cnd.uni[OPDIM + 1] : cnd.uni[OPDIM];
+        const double uacc = scand[O_UNI + uoff + OPDIM];
+        const double coshO = scand[O_CH], sinhO = scand[O_SH];
         cplx Gcc[MSF][MSF];
 #pragma unroll
         for (int a = 0; a < MSF; ++a)
 #pragma unroll
-            for (int b = 0; b < MSF; ++b) Gcc[a][b] = cnd.Gcc[a][b];
-        const double coshO = cnd.coshO, sinhO = cnd.sinhO;
-        double tnb[OPDIM];
-#pragma unroll
-        for (int d = 0; d < OPDIM; ++d) tnb[d] = cnd.tn[d];
+            for (int b = 0; b < MSF; ++b) Gcc[a][b] = *(const cplx*)&scand[O_GCC + 2 * (a * MSF + b)];
         cur += OPDIM;
-        __syncthreads();
-        // ---- start the loads of the NEXT candidate now; they complete while this decision is computed ----
-        const bool have_next = (site + 1 < N);
-        if (have_next && !(dm.dbg & 1)) fetch(nxt, site + 1, site, cur, nI);
-
-        // ---- bosonic action (deltaSPhi, :4186-4239) and delta (get_delta_forsite, :3179-3289) ----
+        TICK(2);
+        // ---- E: p = W v and, speculatively (needed only on acceptance), q = u W.  Work item = one dot product
+        //      split over a quad of lanes; items [0, nI MSF) are p(i, b), items [nI MSF, 2 nI MSF) are q(a, i). ----
+        {
+            const int nitems = (dm.dbg & 2) ? 0 : 2 * nI * MSF;
+            for (int t = tid; t < 4 * nitems; t += 256) {
+                int item = t >> 2, part = t & 3;
+                cplx acc = make_double2(0.0, 0.0);
+                cplx* dst;
+                if (item < nI * MSF) {
+                    int i = item / MSF, b = item - i * MSF;
+                    const cplx* wrow = W + i * WD;
+                    for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(wrow[i2], sv[i2 * MSF + b], acc);
+                    dst = sp + i * MSF + b;
+                } else {
+                    int it2 = item - nI * MSF;
+                    int a = it2 / nI, i = it2 - a * nI;
+                    for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(su[a * WD + i2], W[i2 * WD + i], acc);
+                    dst = sq + a * WD + i;
+                }
+                acc.x = u_dpp_add<0xB1, 0xf>(acc.x); acc.y = u_dpp_add<0xB1, 0xf>(acc.y);     // quad sum
+                acc.x = u_dpp_add<0x4E, 0xf>(acc.x); acc.y = u_dpp_add<0x4E, 0xf>(acc.y);
+                if (part == 0) *dst = acc;
+            }
+        }
+        TICK(3);
+        // ---- D: bosonic action (deltaSPhi, :4186-4239) and delta (get_delta_forsite, :3179-3289) ----
         double dsphi;
         {
             double oldSq = 0.0, newSq = 0.0;
@@ -383,28 +448,42 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                     delta[a][b] = acc;
                 }
         }
-        // ---- p = W v: item = (i, b), each dot product split over a quad of lanes ----
-        for (int t = tid; t < ((dm.dbg & 2) ? 0 : 4 * nI * MSF); t += 256) {
-            int item = t >> 2, part = t & 3;
-            int i = item / MSF, b = item - i * MSF;
-            cplx acc = make_double2(0.0, 0.0);
-            const cplx* wrow = W + i * WD;
-            for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(wrow[i2], sv[i2 * MSF + b], acc);
-            acc.x = u_dpp_add<0xB1, 0xf>(acc.x); acc.y = u_dpp_add<0xB1, 0xf>(acc.y);     // quad sum
-            acc.x = u_dpp_add<0x4E, 0xf>(acc.x); acc.y = u_dpp_add<0x4E, 0xf>(acc.y);
-            if (part == 0) sp[i * MSF + b] = acc;
-        }
-        __syncthreads();
-        // ---- S = Gcc + u p (lane i holds term i, wave reduce) ----
+        TICK(4);
+        __syncthreads();                              // barrier 2 of 2: p, q visible
+        TICK(5);
+        // ---- G: S = Gcc + u p ----
         cplx S[MSF][MSF];
+        if (MSF == 2) {
+            // 16 lanes per entry (a, b) = (lane >> 5, (lane >> 4) & 1); sum within the DPP row, then 8 readlanes
+            const int e_a = lane >> 5, e_b = (lane >> 4) & 1, l16 = lane & 15;
+            cplx part = make_double2(0.0, 0.0);
+            for (int i = l16; i < nI; i += 16) part = u_cfma(su[e_a * WD + i], sp[i * MSF + e_b], part);
+            part.x = u_dpp_add<0x111, 0xf>(part.x); part.y = u_dpp_add<0x111, 0xf>(part.y);   // row_shr:1
+            part.x = u_dpp_add<0x112, 0xf>(part.x); part.y = u_dpp_add<0x112, 0xf>(part.y);   // row_shr:2
+            part.x = u_dpp_add<0x114, 0xf>(part.x); part.y = u_dpp_add<0x114, 0xf>(part.y);   // row_shr:4
+            part.x = u_dpp_add<0x118, 0xf>(part.x); part.y = u_dpp_add<0x118, 0xf>(part.y);   // row_shr:8 -> lane 15 of the row
 #pragma unroll
-        for (int a = 0; a < MSF; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < MSF; ++b) {
-                cplx part = make_double2(0.0, 0.0);
-                for (int i = lane; i < nI; i += 64) part = u_cfma(su[a * WD + i], sp[i * MSF + b], part);
-                S[a][b] = make_double2(Gcc[a][b].x + u_wave_total(part.x), Gcc[a][b].y + u_wave_total(part.y));
-            }
+                for (int b = 0; b < 2; ++b) {
+                    const int src = (a * 2 + b) * 16 + 15;
+                    double re = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(part.x), src),
+                                                 __builtin_amdgcn_readlane(__double2loint(part.x), src));
+                    double im = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(part.y), src),
+                                                 __builtin_amdgcn_readlane(__double2loint(part.y), src));
+                    S[a][b] = make_double2(Gcc[a][b].x + re, Gcc[a][b].y + im);
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MSF; ++a)
+#pragma unroll
+                for (int b = 0; b < MSF; ++b) {
+                    cplx part = make_double2(0.0, 0.0);
+                    for (int i = lane; i < nI; i += 64) part = u_cfma(su[a * WD + i], sp[i * MSF + b], part);
+                    S[a][b] = make_double2(Gcc[a][b].x + u_wave_total(part.x), Gcc[a][b].y + u_wave_total(part.y));
+                }
+        }
+        TICK(6);
         // ---- M' = 1 + (1 - S) delta ; det ; acceptance ----
         cplx Mj[MSF][MSF], Minv[MSF][MSF];
 #pragma unroll
@@ -423,13 +502,14 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         bool accept = prob > 1.0;
         bool used_uniform = false;
         if (!accept) { accept = uacc < prob; cur += 1; used_uniform = true; }   // rand01 drawn only if prob <= 1 (:3113)
+        TICK(7);
         if (accept) {
             acc_count += 1;
             if (tid == 0) {
 #pragma unroll
-                for (int d = 0; d < OPDIM; ++d) phik[d * N + site] = newphi[d];
-                dm.coshT[(size_t)k * N + site] = coshN;
-                dm.sinhT[(size_t)k * N + site] = sinhN;
+                for (int d = 0; d < OPDIM; ++d) { sphi[d * N + site] = newphi[d]; sacc[j][d] = newphi[d]; }
+                sacc[j][OPDIM] = coshN;
+                sacc[j][OPDIM + 1] = sinhN;
                 isite[j] = site;
             }
             // F = delta M'^-1
@@ -443,46 +523,39 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                     for (int q = 0; q < MSF; ++q) acc = u_cfma(delta[a][q], Minv[q][b], acc);
                     F[a][b] = acc;
                 }
-            // q = u W (quad-split dot products) ; pF = p F
-            for (int t = tid; t < ((dm.dbg & 2) ? 0 : 4 * MSF * nI); t += 256) {
-                int item = t >> 2, part = t & 3;
-                int a = item / nI, i = item - a * nI;
-                cplx acc = make_double2(0.0, 0.0);
-                for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(su[a * WD + i2], W[i2 * WD + i], acc);
-                acc.x = u_dpp_add<0xB1, 0xf>(acc.x); acc.y = u_dpp_add<0xB1, 0xf>(acc.y);
-                acc.x = u_dpp_add<0x4E, 0xf>(acc.x); acc.y = u_dpp_add<0x4E, 0xf>(acc.y);
-                if (part == 0) sq[a * WD + i] = acc;
-            }
-            for (int i = tid; i < nI; i += 256) {
-#pragma unroll
-                for (int b = 0; b < MSF; ++b) {
-                    cplx acc2 = make_double2(0.0, 0.0);
-#pragma unroll
-                    for (int q = 0; q < MSF; ++q) acc2 = u_cfma(sp[i * MSF + q], F[q][b], acc2);
-                    spf[i * MSF + b] = acc2;
-                }
-            }
-            __syncthreads();
-            // W11 += pF q
+            // block bordering of W straight from p and q in LDS (pF is formed on the fly: no staging, no barrier):
+            //   W11 += (p F) q ;  W12 = p F ;  W21 = F q ;  W22 = F
             for (int t = tid; t < ((dm.dbg & 2) ? 0 : nI * nI); t += 256) {
                 int i = t / nI, i2 = t - i * nI;
+                cplx pi[MSF];
+#pragma unroll
+                for (int q = 0; q < MSF; ++q) pi[q] = sp[i * MSF + q];
                 cplx acc = W[i * WD + i2];
 #pragma unroll
-                for (int q = 0; q < MSF; ++q) acc = u_cfma(spf[i * MSF + q], sq[q * WD + i2], acc);
+                for (int b = 0; b < MSF; ++b) {
+                    cplx pf = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int q = 0; q < MSF; ++q) pf = u_cfma(pi[q], F[q][b], pf);
+                    acc = u_cfma(pf, sq[b * WD + i2], acc);
+                }
                 W[i * WD + i2] = acc;
             }
-            // W12 = pF ; W21 = F q
             for (int i = tid; i < nI; i += 256) {
+                cplx pi[MSF];
+#pragma unroll
+                for (int q = 0; q < MSF; ++q) pi[q] = sp[i * MSF + q];
 #pragma unroll
                 for (int b = 0; b < MSF; ++b) {
-                    W[i * WD + (nI + b)] = spf[i * MSF + b];
-                    cplx acc = make_double2(0.0, 0.0);
+                    cplx pf = make_double2(0.0, 0.0), fq = make_double2(0.0, 0.0);
 #pragma unroll
-                    for (int q = 0; q < MSF; ++q) acc = u_cfma(F[b][q], sq[q * WD + i], acc);
-                    W[(nI + b) * WD + i] = acc;
+                    for (int q = 0; q < MSF; ++q) {
+                        pf = u_cfma(pi[q], F[q][b], pf);
+                        fq = u_cfma(F[b][q], sq[q * WD + i], fq);
+                    }
+                    W[i * WD + (nI + b)] = pf;
+                    W[(nI + b) * WD + i] = fq;
                 }
             }
-            // W22 = F
             if (tid == 0) {
 #pragma unroll
                 for (int a = 0; a < MSF; ++a)
@@ -491,16 +564,25 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             }
             j += 1;
         }
-        // hand over to the next candidate
+        TICK(8);
+        // hand over to the next candidate (no barrier here: the next proposal writes the OTHER u/v buffer, and
+        // everything else it touches before its first barrier is thread private)
         prev_site = site;
         prev_acc = accept;
         prev_used_uniform = used_uniform;
-#pragma unroll
-        for (int d = 0; d < OPDIM; ++d) { prev_newphi[d] = newphi[d]; prev_oldphi[d] = oldphi[d]; }
-        cnd = nxt;
-        cnd_nI = nI;                               // what nxt was fetched for; the accepted site is patched in
+        cnd_nI = nI;                               // what the u/v registers were fetched for; the accepted site is patched in
         site += 1;
-        __syncthreads();
+        it += 1;
+        TICK(9);
+    }
+    __syncthreads();                               // W complete before it is published
+    // the accepted field values and their cosh / sinh terms (updateCoshSinhTerms, :3128-3140)
+    if (tid < j) {
+        const int st = isite[tid];
+#pragma unroll
+        for (int d = 0; d < OPDIM; ++d) phik[d * N + st] = sacc[tid][d];
+        dm.coshT[(size_t)k * N + st] = sacc[tid][OPDIM];
+        dm.sinhT[(size_t)k * N + st] = sacc[tid][OPDIM + 1];
     }
 
     // ---- publish block result ----
@@ -548,13 +630,20 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             }
         }
         us->slice_done = sdone;
+#ifdef DQMC_DECIDE_TIMING
+        if (timing) {
+            for (int i = 0; i < 12; ++i) us->dbg_cycles[i] += tk[i];
+            us->dbg_cycles[12] += 1;
+        }
+#endif
     }
+#undef TICK
 }
 
 void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, DevUpdateState* us,
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal) {
     const int WD = hm.MSF * hm.D;
-    size_t lds = ((size_t)WD * WD + 5 * (size_t)hm.MSF * WD) * sizeof(cplx);
+    size_t lds = ((size_t)WD * WD + 6 * (size_t)hm.MSF * WD) * sizeof(cplx) + (size_t)hm.opdim * hm.N * sizeof(double);
     if (lds > 65536) {     // O(3) with deep delay blocks: raise the dynamic LDS limit once
         static bool raised = false;
         if (!raised) {
