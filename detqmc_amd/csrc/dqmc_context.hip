@@ -731,6 +731,7 @@ extern "C" int dqmc_udv_setup(dqmc_ctx* c) {
     }
     if ((rc = green_from_eye(c, c->storage[n], KIND_R))) return rc;
     c->currentTimeslice = m;
+    HIPCHK(hipGetLastError());
     return DQMC_OK;
 }
 
@@ -768,6 +769,7 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
         if (rc) return rc;
         std::swap(c->storage[l - 1], c->spare);          // storage[l-1] = UdV_L
         c->currentTimeslice = s * (l - 1);
+        HIPCHK(hipGetLastError());
         return DQMC_OK;
     } else if (dir == DQMC_UP) {
         if (l < 0 || l > n - 1) return fail(DQMC_EINVAL, "advanceUp: l out of range");
@@ -785,6 +787,7 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
         if (rc) return rc;
         std::swap(c->storage[l + 1], c->spare);
         c->currentTimeslice = k_lp1;
+        HIPCHK(hipGetLastError());
         return DQMC_OK;
     }
     return fail(DQMC_EINVAL, "dir must be DQMC_UP or DQMC_DOWN");
@@ -806,6 +809,7 @@ extern "C" int dqmc_wrap(dqmc_ctx* c, int dir, int k) {
         bmult_dev(c, DQMC_LEFT, 1, k, k - 1, c->G);
         c->currentTimeslice = k - 1;
     } else return fail(DQMC_EINVAL, "dir must be DQMC_UP or DQMC_DOWN");
+    HIPCHK(hipGetLastError());
     return DQMC_OK;
 }
 
@@ -844,6 +848,7 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
         ProfScope ps(c, FAM_FLUSH, 1);
         launch_flush(c->lc, c->X, c->n_g, c->Gr, WD, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
     }
+    HIPCHK(hipGetLastError());      // a rejected launch (bad configuration) must not pass silently
     return DQMC_OK;
 }
 

@@ -644,11 +644,13 @@ void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevMod
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal) {
     const int WD = hm.MSF * hm.D;
     size_t lds = ((size_t)WD * WD + 6 * (size_t)hm.MSF * WD) * sizeof(cplx) + (size_t)hm.opdim * hm.N * sizeof(double);
-    if (lds > 65536) {     // O(3) with deep delay blocks: raise the dynamic LDS limit once
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute((const void*)k_update_decide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised = true;
+    if (lds > 48 * 1024) {     // deep delay blocks: raise the dynamic LDS limit of the instantiation to what is needed
+        static size_t raised[4] = {0, 0, 0, 0};
+        if (lds > raised[hm.opdim]) {
+            const void* f = hm.opdim == 1 ? (const void*)k_update_decide<1> : hm.opdim == 2 ? (const void*)k_update_decide<2>
+                                                                                           : (const void*)k_update_decide<3>;
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised[hm.opdim] = lds;
+            else (void)hipGetLastError();      // the launch below then reports the problem
         }
     }
     if (hm.opdim == 1)
@@ -709,11 +711,11 @@ void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateS
                           const cplx* W, cplx* X, cplx* Gr) {
     const int WD = hm.MSF * hm.D;
     size_t lds = ((size_t)WD * WD + (size_t)WD * 65) * sizeof(cplx);
-    if (lds > 65536) {
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute((const void*)k_update_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised = true;
+    if (lds > 48 * 1024) {
+        static size_t raised = 0;
+        if (lds > raised) {
+            if (hipFuncSetAttribute((const void*)k_update_gather, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised = lds;
+            else (void)hipGetLastError();
         }
     }
     hipLaunchKernelGGL(k_update_gather, dim3((hm.ng + 63) / 64, 1, lc.nb), dim3(256), lds, lc.st, hm, us, G, W, X, Gr, lc.cs);
