@@ -34,7 +34,7 @@ WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=int(os.envi
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
 DEFAULT_BATCH = 32             # chains per kernel context (lockstep batch): fills the 256 CUs
-DEFAULT_WORKERS = 2            # contexts per GPU: one's latency-bound decision kernel overlaps the other's GEMMs
+DEFAULT_WORKERS = 4            # contexts per GPU: the latency-bound kernels of one overlap the streaming kernels of the others
 
 
 def cpu_baseline(max_seconds=200):
@@ -77,7 +77,9 @@ def worker(a):
     ctx = batch.kernel_context
     for _ in range(a.warmup):
         batch.sweepThermalization()
+    blocks0 = 0
     if a.profile:
+        blocks0 = ctx.profile_read()["blocks_nonempty"]
         ctx.profile_enable(True)
     ctx.synchronize()
     print("READY", flush=True)
@@ -94,7 +96,20 @@ def worker(a):
     if a.profile:
         prof = ctx.profile_read()
         out["prof"] = {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}
+        out["prof"]["blocks_nonempty"] -= blocks0
     print("RESULT " + json.dumps(out), flush=True)
+    # worker 0 is then asked to repeat the steps ALONE on the GPU: kernel durations free of the other contexts
+    if sys.stdin.readline().strip() == "SOLO":
+        blocks0 = ctx.profile_read()["blocks_nonempty"]
+        ctx.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            batch.sweepThermalization()
+        ctx.synchronize()
+        prof = ctx.profile_read()
+        prof["blocks_nonempty"] -= blocks0
+        print("SOLO " + json.dumps({"dt": time.perf_counter() - t0,
+                                    "prof": {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}}), flush=True)
     batch.close()
 
 
@@ -165,6 +180,12 @@ def main():
     results = [json.loads(read_tag(p, "RESULT")) for p in procs]    # each worker synchronised its stream
     fence()
     dt = time.perf_counter() - t0
+    solo = None
+    for i, p in enumerate(procs):
+        p.stdin.write("SOLO\n" if (i == 0 and rank == 0) else "QUIT\n")
+        p.stdin.flush()
+    if rank == 0:
+        solo = json.loads(read_tag(procs[0], "SOLO"))
     for p in procs:
         p.wait()
     if dist is not None:
@@ -174,53 +195,61 @@ def main():
 
     if rank == 0:
         r0 = results[0]
-        prof = {k: (tuple(v) if isinstance(v, list) else v) for k, v in r0["prof"].items()}
         n = r0["n_g"]
         N, MSF, D, OPD = n // 2, 2, WORKLOAD["delaySteps"], WORKLOAD["opdim"]
+
+        def rooflines(rawprof, sharing):
+            prof = {k: (tuple(v) if isinstance(v, list) else v) for k, v in rawprof.items()}
+
+            def hbm(name, kernel, ms, launches, bytes_per_chain, note):
+                bytes_per_launch = bytes_per_chain * B          # every launch carries all B chains of the context
+                us = 1e3 * ms / max(launches, 1)
+                ach = bytes_per_launch / (us * 1e-6) / 1e9 if launches else 0.0
+                return {"family": name, "kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
+                        "avg_launch_us": us, "launches": launches, "device_ms": ms, "chains_per_launch": B,
+                        "contexts_sharing_the_gpu": sharing, "note": note}
+
+            roofs = []
+            # decision kernel: per proposal (OPDIM+1) uniforms, 2*OPDIM field values of the neighbouring slices, cosh/sinh,
+            # G[c,I], G[I,c], G[c,c], G[c,prev], G[prev,c] with |I| = MSF*D/2 on average; N proposals per slice over
+            # the launches that found work
+            cand_bytes = (OPD + 1) * 8 + 2 * OPD * 8 + 16 + (2 * MSF * (MSF * D // 2) + 3 * MSF * MSF) * 16
+            nblocks = max(prof["blocks_nonempty"], 1)
+            roofs.append(hbm("decide", "k_update_decide<2>", prof["decide"][0], nblocks, N * cand_bytes * (prof["decide"][1] // ((N + D - 1) // D)) / nblocks,
+                             "sequential Metropolis chain of one slice: one workgroup per chain by construction, latency bound; "
+                             "launches = blocks that found work (the rest exit at once)"))
+            if WORKLOAD["stabilisation"] == "svd":
+                r = hbm("decomp", "k_jacobi_round<8,2>", prof["decomp_round_ms"], prof["decomp_rounds"], 4.0 * n * n * 16.0,
+                        "one Jacobi round reads and writes every column of A and V once")
+                roofs.append(r)
+            else:
+                # QR + formation of Q: every panel step streams the trailing matrix twice (read, write)
+                np_ = (n + 15) // 16
+                qr_bytes = 2 * sum(2 * 16.0 * (n - 16 * p) * (n - 16 * p) for p in range(np_))
+                calls = max(prof["qr_calls"], 1)
+                roofs.append(hbm("decomp", "k_qr_panel + k_qr_apply (one UDT factorisation incl. explicit Q)", prof["decomp"][0], calls, qr_bytes,
+                                 "blocked Householder QR; launches = factorisations"))
+            roofs.append(hbm("bmult", "k_bmult_chain", *prof["bmult"], 2 * 16.0 * n * n, "one read + one write of A per chain of slices"))
+            roofs.append(hbm("gather", "k_update_gather", prof["gather"][0], nblocks, 4 * 16.0 * n * MSF * D,
+                             "X = G[:,I] W and Gr = G[I,:] - E; launches = blocks that found work"))
+            roofs.append(hbm("flush", "k_flush (G += X Gr)", prof["flush"][0], nblocks, 2 * 16.0 * n * n,
+                             "read-modify-write of G once per delayed-update block; launches = blocks that accepted an update "
+                             "(launches for empty blocks return at once and are not counted)"))
+            gms, gl = prof["gemm"]
+            tf = prof["gemm_flops"] / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+            roofs.append({"family": "gemm", "kernel": "k_zgemm<2,2>", "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF,
+                          "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF, "traffic": None,
+                          "algorithmic_flops_per_launch": prof["gemm_flops"] / max(gl, 1), "avg_launch_us": 1e3 * gms / max(gl, 1),
+                          "launches": gl, "device_ms": gms, "chains_per_launch": B, "contexts_sharing_the_gpu": sharing,
+                          "note": "n_g^3 complex products on v_mfma_f64_16x16x4_f64"})
+            roofs.sort(key=lambda r: -r["device_ms"])
+            return prof, roofs
+
+        prof, roofs = rooflines(r0["prof"], R)
         fam = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items() if isinstance(v, tuple) and k != "jacobi"}
-
-        def hbm(name, kernel, ms, launches, bytes_per_chain, note):
-            bytes_per_launch = bytes_per_chain * B          # every launch carries all B chains of the context
-            us = 1e3 * ms / max(launches, 1)
-            ach = bytes_per_launch / (us * 1e-6) / 1e9 if launches else 0.0
-            return {"family": name, "kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "avg_launch_us": us, "launches": launches, "device_ms": ms, "chains_per_launch": B, "note": note}
-
-        roofs = []
-        # decision kernel: per proposal (OPDIM+1) uniforms, 7 field vectors, cosh/sinh, G[c,I], G[I,c], G[c,c]
-        # with |I| = MSF*D/2 on average; N proposals per slice spread over ceil(N/D) launches
-        cand_bytes = (OPD + 1) * 8 + 7 * OPD * 8 + 16 + (2 * MSF * (MSF * D // 2) + MSF * MSF) * 16
-        roofs.append(hbm("decide", "k_update_decide<2>", *prof["decide"], N * cand_bytes / ((N + D - 1) // D),
-                         "sequential Metropolis chain of one slice: one workgroup per chain by construction, latency bound"))
-        if WORKLOAD["stabilisation"] == "svd":
-            r = hbm("decomp", "k_jacobi_round<8,2>", prof["decomp_round_ms"], prof["decomp_rounds"], 4.0 * n * n * 16.0,
-                    "one Jacobi round reads and writes every column of A and V once")
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_jacobi.json")
-            if os.path.exists(pmc):
-                try:
-                    r["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    pass
-            roofs.append(r)
-        else:
-            # QR + formation of Q: every panel step streams the trailing matrix twice (read, write)
-            np_ = (n + 15) // 16
-            qr_bytes = 2 * sum(2 * 16.0 * (n - 16 * p) * (n - 16 * p) for p in range(np_))
-            calls = max(prof["qr_calls"], 1)
-            roofs.append(hbm("decomp", "k_qr_panel + trailing k_zgemm (one UDT factorisation)", prof["decomp"][0], calls, qr_bytes,
-                             "blocked Householder QR incl. explicit Q; launches = factorisations"))
-        roofs.append(hbm("bmult", "k_bmult_chain", *prof["bmult"], 2 * 16.0 * n * n, "one read + one write of A per chain"))
-        roofs.append(hbm("gather", "k_update_gather", *prof["gather"], 4 * 16.0 * n * MSF * D * 0.72,
-                         "X = G[:,I] W and Gr = G[I,:] - E"))
-        roofs.append(hbm("flush", "k_zgemm (G += X Gr)", *prof["flush"], 2 * 16.0 * n * n, "read-modify-write of G per block"))
-        gms, gl = prof["gemm"]
-        tf = prof["gemm_flops"] / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
-        roofs.append({"family": "gemm", "kernel": "k_zgemm<1,1>", "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF,
-                      "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF, "traffic": None,
-                      "algorithmic_flops_per_launch": prof["gemm_flops"] / max(gl, 1), "avg_launch_us": 1e3 * gms / max(gl, 1),
-                      "launches": gl, "device_ms": gms, "note": "n_g^3 complex products on v_mfma_f64_16x16x4_f64"})
-        roofs.sort(key=lambda r: -r["device_ms"])
+        _, roofs_solo = rooflines(solo["prof"], 1)
+        solo_by_family = {r["family"]: r for r in roofs_solo}
         res = {
             "metric": "DQMC sweeps/sec (SDW-O2 L=16 beta=10 fp64)",
             "value": world * R * B * a.steps / dt,
@@ -240,8 +269,14 @@ def main():
                                    % (R * B, R, B, WORKLOAD["stabilisation"]),
                        "n_g": n, "m": r0["m"], "replicas_per_gpu": R * B, "contexts_per_gpu": R,
                        "chains_per_context": B},
+            # timed region, context 0 while all contexts share the GPU: durations include waiting for the others
             "roofline": roofs[0],
             "roofline_other_kernels": roofs[1:],
+            # the same kernels right after the timed region with ONE context alone on the GPU (clean durations;
+            # this is what the rocprofv3 summary under profiles/ shows)
+            "roofline_solo_context": solo_by_family[roofs[0]["family"]],
+            "roofline_solo_context_other_kernels": [r for r in roofs_solo if r["family"] != roofs[0]["family"]],
+            "solo_context_sweeps_per_s": B * a.steps / solo["dt"],
             "device_ms_by_family_context0": fam,
             "decompositions_context0": {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
                                       "max_sweeps": prof["svd_sweeps_max"], "qr_calls": prof["qr_calls"]},

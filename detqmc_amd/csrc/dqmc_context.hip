@@ -1054,5 +1054,11 @@ extern "C" int dqmc_profile_read(dqmc_ctx* c, dqmc_profile* out) {
     out->gemm_flops = c->gemm_flops;
     out->decomp_round_ms = c->fam_ms[FAM_ROUNDS];
     out->decomp_rounds = c->fam_launches[FAM_ROUNDS];
+    {
+        DevUpdateState h;
+        HIPCHK(hipMemcpy(&h, selp(c, c->us), sizeof(h), hipMemcpyDeviceToHost));
+        out->blocks_nonempty = h.blocks_nonempty;
+    }
+    out->chains = (uint64_t)c->nb;
     return DQMC_OK;
 }

@@ -56,6 +56,7 @@ struct DevUpdateState {
     int slice_done;
     double r;                // this chain's exchange parameter (differs between the chains of a batch)
     int block_sites[DQMC_MAX_WDIM];
+    unsigned long long blocks_nonempty;  // delayed-update blocks that accepted at least one update (-> real flushes)
     unsigned long long dbg_cycles[16];   // developer phase timers of the decision kernel (DQMC_DBG & 8)
 };
 
