@@ -181,7 +181,7 @@ static void herm4_exp(const hc H[4][4], double pref, hc out[4][4]) {
 }
 
 static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::vector<hc>& pmats,
-                         std::vector<int>& neigh) {
+                         std::vector<double>& pabcd, std::vector<int>& neigh) {
     const int L = p.L, N = L * L, P = N / 4;
     neigh.assign(4 * N, 0);
     for (int site = 0; site < N; ++site) {
@@ -193,6 +193,7 @@ static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::ve
     }
     psites.assign(2 * P * 4, 0);
     pmats.assign((size_t)2 * 2 * 2 * P * 16, hc(0.0));
+    pabcd.assign((size_t)2 * 2 * 2 * P * 4, 0.0);
     const double hopHor[2] = {p.txhor, p.tyhor}, hopVer[2] = {p.txver, p.tyver};
     const bool apbc_x = (p.bc == DQMC_BC_APBC_X || p.bc == DQMC_BC_APBC_XY);
     const bool apbc_y = (p.bc == DQMC_BC_APBC_Y || p.bc == DQMC_BC_APBC_XY);
@@ -203,13 +204,15 @@ static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::ve
         for (int i1 = sub; i1 < L; i1 += 2)
             for (int i2 = sub; i2 < L; i2 += 2, ++pidx) {
                 int i = i2 * L + i1, j = neigh[0 * N + i], k = neigh[2 * N + i], l = neigh[0 * N + k];
-                int* ps = &psites[(sub * P + pidx) * 4];
-                ps[0] = i; ps[1] = j; ps[2] = k; ps[3] = l;
+                const int corner[4] = {i, j, k, l};
+                for (int q = 0; q < 4; ++q) psites[(sub * 4 + q) * P + pidx] = corner[q];
                 const bool half = (sub == 1);
                 for (int band = 0; band < 2; ++band)
                     for (int signIdx = 0; signIdx < 2; ++signIdx) {
                         const double sign = signIdx == 0 ? -1.0 : +1.0;
-                        hc* M = &pmats[((size_t)((band * 2 + signIdx) * 2 + sub) * P + pidx) * 16];
+                        hc Mloc[16];
+                        hc* M = Mloc;
+                        const size_t tbl = (size_t)((band * 2 + signIdx) * 2 + sub);
                         if (!p.weakZflux) {
                             const double f = half ? 0.5 : 1.0;
                             double ch_hor = std::cosh(-f * p.dtau * hopHor[band]);
@@ -221,6 +224,8 @@ static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::ve
                             double a = ch_hor * ch_ver, b = ch_ver * sh_hor, c = ch_hor * sh_ver, d = sh_hor * sh_ver;
                             const double rows[4][4] = {{a, b, c, d}, {b, a, d, c}, {c, d, a, b}, {d, c, b, a}};
                             for (int r = 0; r < 4; ++r) for (int q = 0; q < 4; ++q) M[r * 4 + q] = rows[r][q];
+                            const double abcd[4] = {a, b, c, d};
+                            for (int q = 0; q < 4; ++q) pabcd[(tbl * 4 + q) * P + pidx] = abcd[q];
                         } else {
                             double hh = hopHor[band], hv = hopVer[band];
                             if (apbc_x && i1 == L - 1) hh *= -1;
@@ -242,6 +247,7 @@ static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::ve
                             herm4_exp(Hh, sign * (half ? 0.5 : 1.0) * p.dtau, E);
                             for (int r = 0; r < 4; ++r) for (int q = 0; q < 4; ++q) M[r * 4 + q] = E[r][q];
                         }
+                        for (int e = 0; e < 16; ++e) pmats[(tbl * 16 + e) * P + pidx] = M[e];
                     }
             }
     }
@@ -390,17 +396,20 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
 
     std::vector<int> psites, neigh;
     std::vector<hc> pmats;
-    build_tables(*p, psites, pmats, neigh);
-    int *d_psites, *d_neigh; cplx* d_pmats;
+    std::vector<double> pabcd;
+    build_tables(*p, psites, pmats, pabcd, neigh);
+    int *d_psites, *d_neigh; cplx* d_pmats; double* d_pabcd;
     int rc;
 #define A_(x) if ((rc = (x))) { dqmc_destroy(c); return rc; }
     A_(salloc(c, &d_psites, psites.size()));
     A_(salloc(c, &d_neigh, neigh.size()));
     A_(salloc(c, &d_pmats, pmats.size()));
+    A_(salloc(c, &d_pabcd, pabcd.size()));
+    HIPCHK(hipMemcpy(d_pabcd, pabcd.data(), pabcd.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_psites, psites.data(), psites.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_neigh, neigh.data(), neigh.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_pmats, pmats.data(), pmats.size() * sizeof(hc), hipMemcpyHostToDevice));
-    hm.psites = d_psites; hm.neigh = d_neigh; hm.pmats = d_pmats;
+    hm.psites = d_psites; hm.neigh = d_neigh; hm.pmats = d_pmats; hm.pabcd = d_pabcd; hm.pm_real = p->weakZflux ? 0 : 1;
     if (p->cb_none) {
         hm.dense = 1;
         hm.ov[0] = hm.ov[1] = hm.ovinv[0] = hm.ovinv[1] = 1.0;     // mu is part of K in setupPropK

@@ -31,12 +31,17 @@ struct DevModel {
     double dtau, r, c, u, lambda;   // r: chain 0's value at create time only -- kernels read DevUpdateState::r
     double ov[2];      // e^{+dtau mu_band}   (detsdwopdim.cpp:2037-2038)
     double ovinv[2];   // e^{-dtau mu_band}   (detsdwopdim.cpp:2137-2138)
-    // plaquette sites [sub][P][4] (sub 0: even corners, sub 1: odd corners; detsdwopdim.cpp:1776-1785)
+    // plaquette sites [sub][4][P] (sub 0: even corners, sub 1: odd corners; detsdwopdim.cpp:1776-1785).  All
+    // plaquette tables are structure-of-arrays over the plaquette index: lanes work on consecutive plaquettes
     const int* psites;
-    // 4x4 complex plaquette exponentials [band][signIdx][sub][P][16] row-major; sub 1 holds the
+    // 4x4 complex plaquette exponentials [band][signIdx][sub][16 (row-major entry)][P]; sub 1 holds the
     // half-step matrices, sub 0 the full-step ones (symmetric break-up, detsdwopdim.cpp:1846-1865);
-    // signIdx 0: e^{-dtau K}, 1: e^{+dtau K}
+    // signIdx 0: e^{-dtau K}, 1: e^{+dtau K}.  Used with a magnetic flux (complex Hermitian matrices).
     const cplx* pmats;
+    // without flux the matrices are real with four distinct entries, rows (a b c d)(b a d c)(c d a b)(d c b a)
+    // (cb_assaad_applyBondFactorsLeft, detsdwopdim.cpp:1688-1756): [band][signIdx][sub][4][P]
+    const double* pabcd;
+    int pm_real;
     // fields
     double* phi;       // [m+1][opdim][N]
     double* coshT;     // [m+1][N]

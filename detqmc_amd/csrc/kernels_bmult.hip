@@ -102,21 +102,39 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
                         int b = t % MSF;
                         int v = t / MSF;
                         int band = b & 1;
-                        const cplx* mat = dm.pmats + ((size_t)(((band * 2 + signIdx) * 2 + sub) * P + p)) * 16;
-                        const int* st = dm.psites + (sub * P + p) * 4;
+                        const size_t tbl = (size_t)((band * 2 + signIdx) * 2 + sub);
                         int e[4];
                         cplx x[4], y[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { e[q] = addr(v, b * N + st[q]); x[q] = sm[e[q]]; }
+                        for (int q = 0; q < 4; ++q) { e[q] = addr(v, b * N + dm.psites[(sub * 4 + q) * P + p]); x[q] = sm[e[q]]; }
+                        if (dm.pm_real) {
+                            // rows (a b c d)(b a d c)(c d a b)(d c b a): symmetric, so left and right agree
+                            double co[4];
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            cplx acc = make_double2(0.0, 0.0);
+                            for (int q = 0; q < 4; ++q) co[q] = dm.pabcd[(tbl * 4 + q) * P + p];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                cplx mm = RIGHT ? mat[q * 4 + a] : mat[a * 4 + q];
-                                acc = cfma(mm, x[q], acc);
+                            for (int a = 0; a < 4; ++a) {
+                                cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const double m = co[a ^ q];       // entry (a, q) of the pattern above
+                                    acc.x = fma(m, x[q].x, acc.x);
+                                    acc.y = fma(m, x[q].y, acc.y);
+                                }
+                                y[a] = acc;
                             }
-                            y[a] = acc;
+                        } else {
+                            const cplx* mat = dm.pmats + tbl * 16 * P + p;
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) {
+                                cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    cplx mm = RIGHT ? mat[(size_t)(q * 4 + a) * P] : mat[(size_t)(a * 4 + q) * P];
+                                    acc = cfma(mm, x[q], acc);
+                                }
+                                y[a] = acc;
+                            }
                         }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) sm[e[q]] = y[q];

@@ -120,13 +120,13 @@ __global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs) {
 // Delayed-update flush  G += X Gr  (reference: g += X * Y, src/detsdwopdim.cpp:3156) with K = MSF * (accepted
 // updates of the block) <= 64 read on the device.  This is a read-modify-write stream over G (2 x 16 n^2 bytes)
 // with a thin product riding on it, so it is built for the memory system, not for the matrix cores: no LDS, no
-// barrier -- every wave pulls its 32 x 32 tile of G and its MFMA operand fragments straight from global memory
-// into registers, all loads of a tile in flight at once (one round trip per workgroup instead of four).
+// barrier -- every wave pulls its MFMA operand fragments and then its 32 x 32 tile of G straight from global
+// memory into registers; two workgroups per CU so that one's loads overlap the other's MFMAs.
 // Fragment convention as in k_zgemm (operand roles swapped so that the stores coalesce).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flush(const cplx* __restrict__ X, int ldx, const cplx* __restrict__ Gr, int ldg,
-                                               cplx* __restrict__ G, int ldc, int n, int Kmax, const int* __restrict__ Kdev,
-                                               int Kmul, size_t cs) {
+__global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, int ldx, const cplx* __restrict__ Gr, int ldg,
+                                                  cplx* __restrict__ G, int ldc, int n, int Kmax, const int* __restrict__ Kdev,
+                                                  int Kmul, size_t cs) {
     CHAIN(X); CHAIN(Gr); CHAIN(G); CHAIN(Kdev);
     int K = Kmax;
     if (Kdev) { int kd = (*Kdev) * Kmul; K = kd < K ? kd : K; }
@@ -135,23 +135,12 @@ __global__ __launch_bounds__(256) void k_flush(const cplx* __restrict__ X, int l
     const int l15 = lane & 15, l4 = lane >> 4;
     const int i0 = blockIdx.x * 64 + (wave >> 1) * 32, j0 = blockIdx.y * 64 + (wave & 1) * 32;
     if (i0 >= n || j0 >= n) return;
-    // ---- the tile of G first: its latency hides behind the operand loads and the MFMAs ----
-    cplx c[2][2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = i0 + a * 16 + l15, gj = j0 + b * 16 + l4 + 4 * r;
-                c[a][b][r] = (gi < n && gj < n) ? G[(size_t)gj * ldc + gi] : make_double2(0.0, 0.0);
-            }
     v4d acc_re[2][2], acc_im[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); }
-#pragma unroll 4
+#pragma unroll 2
     for (int k0 = 0; k0 < K; k0 += 4) {
         const int gk = k0 + l4;
         cplx af[2], bf[2];
@@ -175,16 +164,25 @@ __global__ __launch_bounds__(256) void k_flush(const cplx* __restrict__ X, int l
                 acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
             }
     }
+    // The tile of G is read only now, 16 x 16 at a time: holding it across the MFMA loop costs 64 VGPRs, i.e. the
+    // second workgroup per CU whose loads would overlap this one's MFMAs (scripts/micro/flush_tiles.hip: 75 -> 55 us).
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+            cplx c[4];
+            const int gi = i0 + a * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gi = i0 + a * 16 + l15, gj = j0 + b * 16 + l4 + 4 * r;
-                if (gi < n && gj < n)
-                    G[(size_t)gj * ldc + gi] = make_double2(c[a][b][r].x + acc_re[a][b][r], c[a][b][r].y + acc_im[a][b][r]);
+                const int gj = j0 + b * 16 + l4 + 4 * r;
+                c[r] = (gi < n && gj < n) ? G[(size_t)gj * ldc + gi] : make_double2(0.0, 0.0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gj = j0 + b * 16 + l4 + 4 * r;
+                if (gi < n && gj < n) G[(size_t)gj * ldc + gi] = make_double2(c[r].x + acc_re[a][b][r], c[r].y + acc_im[a][b][r]);
+            }
+        }
 }
 
 void launch_flush(const Launch& lc, const cplx* X, int ldx, const cplx* Gr, int ldg, cplx* G, int ldc, int n, int Kmax,

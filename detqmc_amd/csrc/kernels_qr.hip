@@ -261,25 +261,33 @@ __global__ __launch_bounds__(256) void k_qr_panel(cplx* __restrict__ A, int lda,
 
 // Apply a block reflector to 16 columns of C per workgroup:  C <- (I - V op(T) V^H) C,  op(T) = T^H while
 // factoring (Q_p^H on the trailing matrix), T while forming Q.  Tn holds -T.  One launch replaces the three
-// small GEMMs (W = V^H C, W2 = -op(T) W, C += V W2); V and C are streamed through LDS in 64-row chunks.
+// small GEMMs (W = V^H C, W2 = -op(T) W, C += V W2), both big ones on the matrix cores
+// (v_mfma_f64_16x16x4_f64, 4 real MFMAs per complex 16x16x4 step):
+//   pass 1  W[i][j] = sum_row conj(V[row,i]) C[row,j]: V and C are streamed through LDS in 64-row chunks
+//           (coalesced loads), every wave contracts 16 rows of the chunk, the four partial W are summed in LDS;
+//   pass 2  C[row,j] += sum_k V[row,k] W2[k][j] as the transposed product (operand roles swapped) so that a lane
+//           owns 4 columns of ONE row and the 16 lanes of a group own 16 consecutive rows: the V fragments and
+//           the read-modify-write of C go straight to global memory, 256 contiguous bytes per group.
+typedef double q_v4d __attribute__((ext_vector_type(4)));
 template<bool TRANS_T>
 __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, int ldv, const cplx* __restrict__ Tn,
                                                    cplx* __restrict__ C, int ldc, int rows, int ncols, int nb, size_t cs) {
     __shared__ cplx sV[64][QR_NB + 1];
-    CHAIN(Vp); CHAIN(Tn); CHAIN(C);
     __shared__ cplx sC[64][QR_NB + 1];
     __shared__ cplx sW[QR_NB][QR_NB + 1];      // W, then W2, as [k][j]
     __shared__ cplx sT[QR_NB][QR_NB + 1];      // -T as [i][k]
-    const int tid = threadIdx.x;
+    __shared__ cplx sPart[4][QR_NB][QR_NB + 1];
+    CHAIN(Vp); CHAIN(Tn); CHAIN(C);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
     const int c0 = blockIdx.x * QR_NB;
     const int nc = min(QR_NB, ncols - c0);
     {
         int i = tid & 15, k = tid >> 4;
         sT[i][k] = (i < nb && k < nb) ? Tn[k * QR_NB + i] : make_double2(0.0, 0.0);
     }
-    // ---- pass 1: W[i][j] = sum_row conj(V[row,i]) C[row,j] ----
-    const int wi = tid & 15, wj = tid >> 4;
-    cplx acc = make_double2(0.0, 0.0);
+    // ---- pass 1: W = V^H C ----
+    q_v4d w_re = (q_v4d)(0.0), w_im = (q_v4d)(0.0);
     for (int r0 = 0; r0 < rows; r0 += 64) {
         __syncthreads();
         for (int idx = tid; idx < 64 * QR_NB; idx += 256) {
@@ -289,15 +297,24 @@ __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, i
             sC[rr][cc] = (row < rows && cc < nc) ? C[(size_t)(c0 + cc) * ldc + row] : make_double2(0.0, 0.0);
         }
         __syncthreads();
-#pragma unroll 8
-        for (int rr = 0; rr < 64; ++rr) {
-            cplx v = sV[rr][wi], x = sC[rr][wj];
-            acc.x += v.x * x.x + v.y * x.y;
-            acc.y += v.x * x.y - v.y * x.x;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int rl = wave * 16 + ks * 4 + l4;
+            const cplx v = sV[rl][l15], x = sC[rl][l15];       // A(m = i, k) = conj(v), B(k, n = j) = x
+            w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.x, w_re, 0, 0, 0);
+            w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.y, w_re, 0, 0, 0);
+            w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.y, w_im, 0, 0, 0);
+            w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, x.x, w_im, 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sPart[wave][l4 + 4 * r][l15] = make_double2(w_re[r], w_im[r]);   // D[m = l4 + 4r][n = l15]
     __syncthreads();
-    sW[wi][wj] = acc;
+    const int wi = tid & 15, wj = tid >> 4;
+    {
+        cplx p0 = sPart[0][wi][wj], p1 = sPart[1][wi][wj], p2 = sPart[2][wi][wj], p3 = sPart[3][wi][wj];
+        sW[wi][wj] = make_double2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+    }
     __syncthreads();
     // ---- W2 = (-T)^(H) W ----
     {
@@ -313,28 +330,36 @@ __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, i
         sW[wi][wj] = a2;
     }
     __syncthreads();
-    // ---- pass 2: C[row, j] += sum_k V[row,k] W2[k][j]; thread = (row in chunk, group of 4 columns) ----
-    const int pr = tid & 63, pg = tid >> 6;
-    for (int r0 = 0; r0 < rows; r0 += 64) {
-        int row = r0 + pr;
-        if (row >= rows) continue;
-        cplx v[QR_NB];
+    // ---- pass 2: C^T tile (16 columns x 16 rows) += W2^T V^T; lane: row = row0 + l15, columns c0 + l4 + 4r ----
+    cplx w2[4];
 #pragma unroll
-        for (int k = 0; k < QR_NB; ++k) v[k] = (k < nb) ? Vp[(size_t)k * ldv + row] : make_double2(0.0, 0.0);
+    for (int ks = 0; ks < 4; ++ks) w2[ks] = sW[ks * 4 + l4][l15];           // A(m = j = l15, k)
+    for (int row0 = wave * 16; row0 < rows; row0 += 64) {
+        const int row = row0 + l15;
+        const bool rok = row < rows;
+        cplx vf[4], cv[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            int j = pg * 4 + jj;
-            if (j < nc) {
-                size_t off = (size_t)(c0 + j) * ldc + row;
-                cplx c = C[off];
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 4 + l4;
+            vf[ks] = (rok && k < nb) ? Vp[(size_t)k * ldv + row] : make_double2(0.0, 0.0);   // B(k, n = row)
+        }
 #pragma unroll
-                for (int k = 0; k < QR_NB; ++k) {
-                    cplx w = sW[k][j];
-                    c.x += v[k].x * w.x - v[k].y * w.y;
-                    c.y += v[k].x * w.y + v[k].y * w.x;
-                }
-                C[off] = c;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int j = l4 + 4 * r;
+            cv[r] = (rok && j < nc) ? C[(size_t)(c0 + j) * ldc + row] : make_double2(0.0, 0.0);
+        }
+        q_v4d d_re = (q_v4d)(0.0), d_im = (q_v4d)(0.0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[ks].x, vf[ks].x, d_re, 0, 0, 0);
+            d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-w2[ks].y, vf[ks].y, d_re, 0, 0, 0);
+            d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[ks].x, vf[ks].y, d_im, 0, 0, 0);
+            d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[ks].y, vf[ks].x, d_im, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = l4 + 4 * r;                                       // D[m = j][n = row]
+            if (rok && j < nc) C[(size_t)(c0 + j) * ldc + row] = make_double2(cv[r].x + d_re[r], cv[r].y + d_im[r]);
         }
     }
 }

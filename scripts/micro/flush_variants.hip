@@ -24,11 +24,11 @@ __global__ __launch_bounds__(256) void k_flush(const cplx* __restrict__ X, int l
 #pragma unroll
             for (int r = 0; r < 4; ++r) c[a][b][r] = G[(size_t)(j0 + b * 16 + l4 + 4 * r) * ldc + i0 + a * 16 + l15];
     }
-    v4d acc_re[2][2], acc_im[2][2];
+    v4d acc_re[2][2], acc_im[2][2], acc_p3[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); }
+        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p3[a][b] = (v4d)(0.0); }
     if (MODE & 1) {
 #pragma unroll 4
     for (int k0 = 0; k0 < K; k0 += 4) {
@@ -42,7 +42,12 @@ __global__ __launch_bounds__(256) void k_flush(const cplx* __restrict__ X, int l
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                if (MODE & 2) {
+                if (MODE & 16) {
+                // Gauss: P1 = br ar, P2 = bi ai, P3 = (br + bi)(ar + ai): re = P1 - P2, im = P3 - P1 - P2
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].y, acc_im[a][b], 0, 0, 0);
+                acc_p3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x + bf[b].y, af[a].x + af[a].y, acc_p3[a][b], 0, 0, 0);
+                } else if (MODE & 2) {
                 acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
                 acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bf[b].y, af[a].y, acc_re[a][b], 0, 0, 0);
                 acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].x, acc_im[a][b], 0, 0, 0);
@@ -65,7 +70,9 @@ __global__ __launch_bounds__(256) void k_flush(const cplx* __restrict__ X, int l
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                G[(size_t)(j0 + b * 16 + l4 + 4 * r) * ldc + i0 + a * 16 + l15] = make_double2(c[a][b][r].x + acc_re[a][b][r], c[a][b][r].y + acc_im[a][b][r]);
+                G[(size_t)(j0 + b * 16 + l4 + 4 * r) * ldc + i0 + a * 16 + l15] = (MODE & 16)
+                    ? make_double2(c[a][b][r].x + (acc_re[a][b][r] - acc_im[a][b][r]), c[a][b][r].y + (acc_p3[a][b][r] - acc_re[a][b][r] - acc_im[a][b][r]))
+                    : make_double2(c[a][b][r].x + acc_re[a][b][r], c[a][b][r].y + acc_im[a][b][r]);
 }
 template<int MODE> float run(cplx* X, cplx* Gr, cplx* G, int* Kd, int n, int nb, size_t cs, hipEvent_t a, hipEvent_t b) {
     float best = 1e9;
@@ -93,5 +100,7 @@ int main(int argc, char** argv) {
     printf("+ operands + mfma   : %.1f us\n", run<3>(X, Gr, G, Kd, n, nb, cs, a, b));
     printf("full (Kdev)         : %.1f us\n", run<7>(X, Gr, G, Kd, n, nb, cs, a, b));
     printf("full, C loaded late : %.1f us\n", run<15>(X, Gr, G, Kd, n, nb, cs, a, b));
+    printf("gauss 3-mult        : %.1f us\n", run<1 + 4 + 16>(X, Gr, G, Kd, n, nb, cs, a, b));
+    printf("gauss, C late       : %.1f us\n", run<1 + 4 + 8 + 16>(X, Gr, G, Kd, n, nb, cs, a, b));
     return 0;
 }
