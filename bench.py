@@ -67,9 +67,11 @@ def cpu_baseline(max_seconds=200):
             "sample": "oracle/detsdw_oracle.py (numpy + scipy zgesvd): 1 sweepThermalization() after init, %.1f s" % dt}
 
 
-def worker(a):
+def worker(a, readline=None, emit=None):
     """One kernel context with a.batch chains in lockstep: build, warm up, wait for GO, run, report."""
     import dataclasses
+    readline = readline or sys.stdin.readline
+    emit = emit or (lambda line: print(line, flush=True))
     from detqmc_amd import DetSDWBatch, SDWParams
     B = max(1, a.batch)
     p0 = SDWParams(device=a.device, **WORKLOAD)
@@ -82,8 +84,8 @@ def worker(a):
         blocks0 = ctx.profile_read()["blocks_nonempty"]
         ctx.profile_enable(True)
     ctx.synchronize()
-    print("READY", flush=True)
-    if sys.stdin.readline().strip() != "GO":
+    emit("READY")
+    if readline().strip() != "GO":
         return
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -97,9 +99,9 @@ def worker(a):
         prof = ctx.profile_read()
         out["prof"] = {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}
         out["prof"]["blocks_nonempty"] -= blocks0
-    print("RESULT " + json.dumps(out), flush=True)
+    emit("RESULT " + json.dumps(out))
     # worker 0 is then asked to repeat the steps ALONE on the GPU: kernel durations free of the other contexts
-    if sys.stdin.readline().strip() == "SOLO":
+    if readline().strip() == "SOLO":
         blocks0 = ctx.profile_read()["blocks_nonempty"]
         ctx.profile_enable(True)
         t0 = time.perf_counter()
@@ -108,9 +110,45 @@ def worker(a):
         ctx.synchronize()
         prof = ctx.profile_read()
         prof["blocks_nonempty"] -= blocks0
-        print("SOLO " + json.dumps({"dt": time.perf_counter() - t0,
-                                    "prof": {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}}), flush=True)
+        emit("SOLO " + json.dumps({"dt": time.perf_counter() - t0,
+                                   "prof": {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}}))
     batch.close()
+
+
+class InprocWorker:
+    """The worker protocol inside this process (one context, no child processes): what `rocprofv3 -- python3 bench.py
+    --inprocess` can profile -- on this pool a profiled process must not spawn GPU children."""
+
+    def __init__(self, a):
+        import copy
+        import queue
+        import threading
+        self.inq, self.outq = queue.Queue(), queue.Queue()
+        wa = copy.copy(a)
+        wa.profile = True
+        self.stdin, self.stdout = self, self
+        self.th = threading.Thread(target=worker, args=(wa, self.inq.get, self.outq.put), daemon=True)
+        self.th.start()
+
+    def write(self, line):
+        self.inq.put(line)
+
+    def flush(self):
+        pass
+
+    def readline(self):
+        while self.th.is_alive() or not self.outq.empty():
+            try:
+                return self.outq.get(timeout=0.5)
+            except Exception:
+                continue
+        return ""
+
+    def poll(self):
+        return None if self.th.is_alive() else 0
+
+    def wait(self):
+        self.th.join()
 
 
 def main():
@@ -123,6 +161,8 @@ def main():
                     help="worker processes (kernel contexts) per GPU")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DQMC_CHAINS_PER_CONTEXT", str(DEFAULT_BATCH))),
                     help="independent Markov chains per context, advanced in lockstep (grid.z = chain)")
+    ap.add_argument("--inprocess", action="store_true",
+                    help="ONE context in this process instead of worker processes (for rocprofv3)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--simindex", type=int, default=0, help=argparse.SUPPRESS)
@@ -150,14 +190,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    R = max(1, a.workers)
+    R = 1 if a.inprocess else max(1, a.workers)
     B = max(1, a.batch)
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
               "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     procs = []
-    for i in range(R):
+    if a.inprocess:
+        a.device, a.simindex = local, rank
+        procs.append(InprocWorker(a))
+    for i in range(0 if a.inprocess else R):
         cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--device", str(local), "--simindex",
                str(rank * R + i), "--steps", str(a.steps), "--warmup", str(a.warmup), "--batch", str(B)] + (["--profile"] if i == 0 else [])
         procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env))
@@ -201,14 +244,17 @@ def main():
         def rooflines(rawprof, sharing):
             prof = {k: (tuple(v) if isinstance(v, list) else v) for k, v in rawprof.items()}
 
-            def hbm(name, kernel, ms, launches, bytes_per_chain, note):
+            def hbm(name, kernel, ms, launches, bytes_per_chain, note, work_launches=None):
+                """achieved = algorithmic bytes of the launches that had work / device time of ALL launches of the kernel;
+                avg_launch_us is over all launches, like rocprofv3's AverageNs."""
+                work = launches if work_launches is None else work_launches
                 bytes_per_launch = bytes_per_chain * B          # every launch carries all B chains of the context
                 us = 1e3 * ms / max(launches, 1)
-                ach = bytes_per_launch / (us * 1e-6) / 1e9 if launches else 0.0
+                ach = bytes_per_launch * work / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 return {"family": name, "kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
-                        "avg_launch_us": us, "launches": launches, "device_ms": ms, "chains_per_launch": B,
-                        "contexts_sharing_the_gpu": sharing, "note": note}
+                        "avg_launch_us": us, "launches": launches, "launches_with_work": work, "device_ms": ms,
+                        "chains_per_launch": B, "contexts_sharing_the_gpu": sharing, "note": note}
 
             roofs = []
             # decision kernel: per proposal (OPDIM+1) uniforms, 2*OPDIM field values of the neighbouring slices, cosh/sinh,
@@ -216,9 +262,10 @@ def main():
             # the launches that found work
             cand_bytes = (OPD + 1) * 8 + 2 * OPD * 8 + 16 + (2 * MSF * (MSF * D // 2) + 3 * MSF * MSF) * 16
             nblocks = max(prof["blocks_nonempty"], 1)
-            roofs.append(hbm("decide", "k_update_decide<2>", prof["decide"][0], nblocks, N * cand_bytes * (prof["decide"][1] // ((N + D - 1) // D)) / nblocks,
-                             "sequential Metropolis chain of one slice: one workgroup per chain by construction, latency bound; "
-                             "launches = blocks that found work (the rest exit at once)"))
+            nslices = prof["decide"][1] // ((N + D - 1) // D)
+            roofs.append(hbm("decide", "k_update_decide<2>", *prof["decide"], N * cand_bytes * nslices / nblocks,
+                             "sequential Metropolis chain of one slice: ONE workgroup per chain by construction -- a latency-bound "
+                             "kernel, HBM is not its limit; blocks without work exit at once", nblocks))
             if WORKLOAD["stabilisation"] == "svd":
                 r = hbm("decomp", "k_jacobi_round<8,2>", prof["decomp_round_ms"], prof["decomp_rounds"], 4.0 * n * n * 16.0,
                         "one Jacobi round reads and writes every column of A and V once")
@@ -228,20 +275,27 @@ def main():
                 np_ = (n + 15) // 16
                 qr_bytes = 2 * sum(2 * 16.0 * (n - 16 * p) * (n - 16 * p) for p in range(np_))
                 calls = max(prof["qr_calls"], 1)
-                roofs.append(hbm("decomp", "k_qr_panel + k_qr_apply (one UDT factorisation incl. explicit Q)", prof["decomp"][0], calls, qr_bytes,
-                                 "blocked Householder QR; launches = factorisations"))
+                napply = max(prof["decomp_rounds"], 1)
+                roofs.append(hbm("qr_apply", "k_qr_apply", prof["decomp_round_ms"], napply, qr_bytes * calls / napply,
+                                 "block reflector applied to the trailing matrix / to Q: reads and writes it once; bytes = average over the "
+                                 "panels of a factorisation"))
+                rest_ms = max(prof["decomp"][0] - prof["decomp_round_ms"], 0.0)
+                rest_l = max(prof["decomp"][1] - napply, 1)
+                roofs.append(hbm("qr_rest", "k_qr_panel, triangular solve, pivoting glue", rest_ms, rest_l, 0.0,
+                                 "panel factorisations (one workgroup per chain, a chain of dependent reductions: latency bound) and the "
+                                 "small kernels around the QR; no roofline claimed"))
             roofs.append(hbm("bmult", "k_bmult_chain", *prof["bmult"], 2 * 16.0 * n * n, "one read + one write of A per chain of slices"))
-            roofs.append(hbm("gather", "k_update_gather", prof["gather"][0], nblocks, 4 * 16.0 * n * MSF * D,
-                             "X = G[:,I] W and Gr = G[I,:] - E; launches = blocks that found work"))
-            roofs.append(hbm("flush", "k_flush (G += X Gr)", prof["flush"][0], nblocks, 2 * 16.0 * n * n,
-                             "read-modify-write of G once per delayed-update block; launches = blocks that accepted an update "
-                             "(launches for empty blocks return at once and are not counted)"))
+            roofs.append(hbm("gather", "k_update_gather", *prof["gather"], 4 * 16.0 * n * MSF * D,
+                             "X = G[:,I] W and Gr = G[I,:] - E; blocks without work exit at once", nblocks))
+            roofs.append(hbm("flush", "k_flush (G += X Gr)", *prof["flush"], 2 * 16.0 * n * n,
+                             "read-modify-write of G once per delayed-update block that accepted an update; the launches of the "
+                             "other blocks exit at once", nblocks))
             gms, gl = prof["gemm"]
             tf = prof["gemm_flops"] / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
             roofs.append({"family": "gemm", "kernel": "k_zgemm<2,2>", "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF,
                           "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF, "traffic": None,
                           "algorithmic_flops_per_launch": prof["gemm_flops"] / max(gl, 1), "avg_launch_us": 1e3 * gms / max(gl, 1),
-                          "launches": gl, "device_ms": gms, "chains_per_launch": B, "contexts_sharing_the_gpu": sharing,
+                          "launches": gl, "launches_with_work": gl, "device_ms": gms, "chains_per_launch": B, "contexts_sharing_the_gpu": sharing,
                           "note": "n_g^3 complex products on v_mfma_f64_16x16x4_f64"})
             roofs.sort(key=lambda r: -r["device_ms"])
             return prof, roofs

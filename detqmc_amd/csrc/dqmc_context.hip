@@ -116,20 +116,21 @@ template<class T> static T* selp(dqmc_ctx* c, T* p) { return (T*)((char*)p + (si
 template<class T> static T* chainp(dqmc_ctx* c, T* p, int b) { return (T*)((char*)p + (size_t)b * c->lc.cs); }
 
 struct ProfScope {
-    dqmc_ctx* c; int fam; uint64_t launches;
+    dqmc_ctx* c; int fam; uint64_t launches; int idx = -1;     // idx: this scope's begin event (scopes may nest)
     ProfScope(dqmc_ctx* c_, int fam_, uint64_t launches_) : c(c_), fam(fam_), launches(launches_) {
         c->fam_launches[fam] += launches;
         if (!c->prof) return;
         if (c->ev_used + 2 > c->ev_pool.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
         }
-        (void)hipEventRecord(c->ev_pool[c->ev_used], c->st);
-        c->ev_open.push_back({fam, (int)c->ev_used});
+        idx = (int)c->ev_used;
+        (void)hipEventRecord(c->ev_pool[idx], c->st);
+        c->ev_open.push_back({fam, idx});
         c->ev_used += 2;
     }
     ~ProfScope() {
-        if (!c->prof) return;
-        (void)hipEventRecord(c->ev_pool[c->ev_open.back().second + 1], c->st);
+        if (idx < 0) return;
+        (void)hipEventRecord(c->ev_pool[idx + 1], c->st);
     }
 };
 
@@ -605,6 +606,17 @@ static void svd_prof_end(void* u, int launches) {
     c->fam_launches[FAM_ROUNDS] += launches;
     c->fam_launches[FAM_JACOBI] += launches;
 }
+// QR mode: the FAM_ROUNDS slot times the k_qr_apply launches (the launch count of the family is kept by run_qr's caller)
+static void qr_apply_prof_end(void* u, int launches) {
+    dqmc_ctx* c = (dqmc_ctx*)u;
+    (void)hipEventRecord(c->ev_pool[c->ev_open.back().second + 1], c->st);
+    c->fam_launches[FAM_ROUNDS] += launches;
+}
+static const SvdProfHooks* qr_hooks(dqmc_ctx* c, SvdProfHooks& h) {
+    if (!c->prof) return nullptr;
+    h = SvdProfHooks{svd_prof_begin, qr_apply_prof_end, c};
+    return &h;
+}
 static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, UdVSlot out) {
     SvdProfHooks hooks{svd_prof_begin, svd_prof_end, c};
     int sweeps = run_svd(c->lc, c->n_g, M, c->n_g, colscale, rowscale, out.U, out.d, out.Vt, c->sw, c->max_jacobi_sweeps,
@@ -636,6 +648,8 @@ static int udt_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
     launch_udt_init(c->lc, M, n, colscale, rowscale, c->qr_perm, transpose, c->sw.A, n);
     cplx* Q = transpose ? out.Vt : out.U;
     cplx* Tt = transpose ? out.U : out.Vt;
+    SvdProfHooks hk;
+    c->qw.apply_hooks = qr_hooks(c, hk);
     int launches = run_qr(c->lc, n, c->sw.A, Q, c->qw);
     launch_udt_diag(c->lc, c->sw.A, n, out.d);
     launch_udt_tmat(c->lc, c->sw.A, out.d, c->qr_perm, n, Tt);
@@ -663,6 +677,8 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
         ProfScope ps(c, FAM_JACOBI, 0);
         launch_scaled_norms_rank(c->lc, c->T2, n, nullptr, nullptr, 0, n, c->sw.norms, c->qr_perm, c->sw.rnorms);
         launch_udt_init(c->lc, c->T2, n, nullptr, nullptr, c->qr_perm, 0, c->sw.A, n);
+        SvdProfHooks hk;
+        c->qw.apply_hooks = qr_hooks(c, hk);
         int launches = run_qr(c->lc, n, c->sw.A, c->T1, c->qw);          // sw.A = R factor, T1 = Q
         launch_permute_scale_cols(c->lc, L.Vt, c->lmax_inv, c->qr_perm, n, c->T3);
         launches += run_trsm_right_upper(c->lc, n, c->sw.A, c->T3, c->qw);   // T3 = (V_l Dlmax^-1 P) R^-1

@@ -124,7 +124,8 @@ void launch_copy_bytes(const Launch& lc, const void* src, void* dst, size_t byte
 void launch_phi_sq_sum(const Launch& lc, const DevModel& hm, double* out);
 
 // ---- QR / UDT building blocks (kernels_qr.hip) ------------------------------------------------
-struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; };
+struct SvdProfHooks;
+struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; const SvdProfHooks* apply_hooks; };   // hooks: optional timing of the k_qr_apply launches
 int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit
 int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w);   // C <- C R^-1
 void launch_udt_init(const Launch& lc, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,

@@ -403,7 +403,9 @@ int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
             const cplx* Vp = w.V + (size_t)j0 * n + j0;
             cplx* C = A + (size_t)(j0 + nb) * n + j0;
             // apply Q_p^H = I - V T^H V^H to the trailing columns
+            if (w.apply_hooks) w.apply_hooks->begin(w.apply_hooks->user);
             hipLaunchKernelGGL((k_qr_apply<true>), dim3((ntrail + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ntrail, nb, lc.cs);
+            if (w.apply_hooks) w.apply_hooks->end(w.apply_hooks->user, 1);
             launches += 1;
         }
     }
@@ -418,7 +420,9 @@ int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
         const cplx* Tn = w.T + (size_t)p * 2 * QR_NB * QR_NB + QR_NB * QR_NB;
         cplx* C = Q + (size_t)j0 * n + j0;
         // C <- (I - V T V^H) C
+        if (w.apply_hooks) w.apply_hooks->begin(w.apply_hooks->user);
         hipLaunchKernelGGL((k_qr_apply<false>), dim3((ncols + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ncols, nb, lc.cs);
+        if (w.apply_hooks) w.apply_hooks->end(w.apply_hooks->user, 1);
         launches += 1;
     }
     return launches;
