@@ -459,7 +459,7 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
         if (ng > 1024) { dqmc_destroy(c); return fail(DQMC_EINVAL, "QR stabilisation supports n_g <= 1024 on this build"); }
         const int np = (ng + 15) / 16;
         A_(dalloc(c, &c->qw.V, n2)); A_(dalloc(c, &c->qw.T, (size_t)np * 2 * 256));
-        A_(dalloc(c, &c->qw.W, (size_t)16 * ng)); A_(dalloc(c, &c->qw.W2, (size_t)16 * ng)); A_(dalloc(c, &c->qw.Rneg, (size_t)16 * ng));
+        A_(dalloc(c, &c->qw.W, (size_t)16 * ng)); A_(dalloc(c, &c->qw.W2, (size_t)16 * ng)); A_(dalloc(c, &c->qw.Rneg, (size_t)32 * ng));
         A_(dalloc(c, &c->qr_perm, (size_t)ng));
         A_(dalloc(c, &c->rmax_inv, (size_t)ng)); A_(dalloc(c, &c->rmin, (size_t)ng));
         A_(dalloc(c, &c->lmax_inv, (size_t)ng)); A_(dalloc(c, &c->lmin, (size_t)ng));

@@ -20,6 +20,23 @@ template<class T> __device__ __forceinline__ T* chain_ptr(T* p, size_t cs) {
     return p ? (T*)((char*)p + (size_t)blockIdx.z * cs) : p;
 }
 #define CHAIN(p) p = chain_ptr(p, cs)
+// XCD-aware launch shape for the wide MFMA kernels: consecutive workgroup ids go round-robin over the 8 XCDs (each with
+// its own L2), so with a 1-D grid and   xcd = id % 8,  chain = 8 * (id / 8 / tiles) + xcd,  tile = (id / 8) % tiles
+// all tiles of one chain run on ONE XCD and share the operand panels in that L2 instead of fetching them 8 times.
+// Used when the number of chains is a multiple of 8; otherwise grid.z = chain as everywhere else.
+template<class T> __device__ __forceinline__ T* chain_ptr_i(T* p, size_t cs, int chain) {
+    return p ? (T*)((char*)p + (size_t)chain * cs) : p;
+}
+__device__ __forceinline__ void xcd_chain_tile(int tiles, int nb, int& chain, int& tile) {
+    if (gridDim.z == 1 && nb > 1) {
+        const int id = blockIdx.x, xcd = id & 7, t = id >> 3;
+        chain = (t / tiles) * 8 + xcd;
+        tile = t % tiles;
+    } else {
+        chain = blockIdx.z;
+        tile = blockIdx.x;
+    }
+}
 
 // Everything a kernel needs to know about the model; lives in device memory, one per context.
 struct DevModel {

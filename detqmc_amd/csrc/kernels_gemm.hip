@@ -20,11 +20,15 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 template<int TM, int TN>
-__global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs) {
-    if (!g.sharedA) g.A = chain_ptr(g.A, cs);
-    if (!g.sharedB) g.B = chain_ptr(g.B, cs);
-    g.C = chain_ptr(g.C, cs); g.Kdev = chain_ptr(g.Kdev, cs); g.kscale = chain_ptr(g.kscale, cs);
-    g.rowscale = chain_ptr(g.rowscale, cs); g.colscale = chain_ptr(g.colscale, cs);
+__global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs, int nb) {
+    constexpr int BM_ = 32 * TM, BN_ = 32 * TN;
+    const int tm = (g.M + BM_ - 1) / BM_, tnn = (g.N + BN_ - 1) / BN_;
+    int chain, tile;
+    xcd_chain_tile(tm * tnn, nb, chain, tile);
+    if (!g.sharedA) g.A = chain_ptr_i(g.A, cs, chain);
+    if (!g.sharedB) g.B = chain_ptr_i(g.B, cs, chain);
+    g.C = chain_ptr_i(g.C, cs, chain); g.Kdev = chain_ptr_i(g.Kdev, cs, chain); g.kscale = chain_ptr_i(g.kscale, cs, chain);
+    g.rowscale = chain_ptr_i(g.rowscale, cs, chain); g.colscale = chain_ptr_i(g.colscale, cs, chain);
     constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16;
     __shared__ cplx sA[BK][BM + 1];
     __shared__ cplx sB[BK][BN + 1];
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    const int i0 = (tile % tm) * BM, j0 = (tile / tm) * BN;
     const int l15 = lane & 15, l4 = lane >> 4;
 
     v4d acc_re[TM][TN], acc_im[TM][TN];
@@ -126,14 +130,17 @@ __global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, int ldx, const cplx* __restrict__ Gr, int ldg,
                                                   cplx* __restrict__ G, int ldc, int n, int Kmax, const int* __restrict__ Kdev,
-                                                  int Kmul, size_t cs) {
-    CHAIN(X); CHAIN(Gr); CHAIN(G); CHAIN(Kdev);
+                                                  int Kmul, size_t cs, int nb) {
+    const int tn = (n + 63) / 64;
+    int chain, tile;
+    xcd_chain_tile(tn * tn, nb, chain, tile);
+    X = chain_ptr_i(X, cs, chain); Gr = chain_ptr_i(Gr, cs, chain); G = chain_ptr_i(G, cs, chain); Kdev = chain_ptr_i(Kdev, cs, chain);
     int K = Kmax;
     if (Kdev) { int kd = (*Kdev) * Kmul; K = kd < K ? kd : K; }
     if (K <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int i0 = blockIdx.x * 64 + (wave >> 1) * 32, j0 = blockIdx.y * 64 + (wave & 1) * 32;
+    const int i0 = (tile % tn) * 64 + (wave >> 1) * 32, j0 = (tile / tn) * 64 + (wave & 1) * 32;
     if (i0 >= n || j0 >= n) return;
     v4d acc_re[2][2], acc_im[2][2];
 #pragma unroll
@@ -187,18 +194,21 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
 
 void launch_flush(const Launch& lc, const cplx* X, int ldx, const cplx* Gr, int ldg, cplx* G, int ldc, int n, int Kmax,
                   const int* Kdev, int Kmul) {
-    dim3 grid((n + 63) / 64, (n + 63) / 64, lc.nb);
-    hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, lc.st, X, ldx, Gr, ldg, G, ldc, n, Kmax, Kdev, Kmul, lc.cs);
+    const int tn = (n + 63) / 64;
+    const dim3 grid = (lc.nb % 8 == 0) ? dim3(tn * tn * lc.nb, 1, 1) : dim3(tn * tn, 1, lc.nb);
+    hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, lc.st, X, ldx, Gr, ldg, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb);
 }
 
 void launch_gemm(const Launch& lc, const GemmArgs& a) {
     // fill the chip: 64x64 tiles only when they still give >= 256 workgroups
     long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * lc.nb;
-    if (tiles64 >= 256) {
-        dim3 grid((a.M + 63) / 64, (a.N + 63) / 64, lc.nb);
-        hipLaunchKernelGGL((k_zgemm<2, 2>), grid, dim3(256), 0, lc.st, a, lc.cs);
+    if (tiles64 >= 256 && a.N > 32 && a.M > 32) {
+        const int t = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+        const dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
+        hipLaunchKernelGGL((k_zgemm<2, 2>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
     } else {
-        dim3 grid((a.M + 31) / 32, (a.N + 31) / 32, lc.nb);
-        hipLaunchKernelGGL((k_zgemm<1, 1>), grid, dim3(256), 0, lc.st, a, lc.cs);
+        const int t = ((a.M + 31) / 32) * ((a.N + 31) / 32);
+        const dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
+        hipLaunchKernelGGL((k_zgemm<1, 1>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
     }
 }

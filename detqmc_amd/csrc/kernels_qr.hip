@@ -430,28 +430,29 @@ int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
 
 // ---------------------------------------------------------------------------------------------
 // right-hand triangular solve  Y R = C  (R upper triangular n x n), in place on C, blocked by NB:
-//   for each column block J:  C_J -= Y_{<J} R_{<J,J}  (GEMM);  C_J <- C_J R_JJ^-1  (one thread per row)
+//   for each column block J (32 wide):  C_J -= Y_{<J} R_{<J,J}  (GEMM);  C_J <- C_J R_JJ^-1  (one thread per row)
 // ---------------------------------------------------------------------------------------------
+#define TRSM_NB 32
 __global__ __launch_bounds__(256) void k_trsm_block(cplx* __restrict__ C, int ldc, const cplx* __restrict__ R, int ldr,
                                                      int n, int j0, int nb, size_t cs) {
-    __shared__ cplx sR[QR_NB][QR_NB + 1];
+    __shared__ cplx sR[TRSM_NB][TRSM_NB + 1];
     CHAIN(C); CHAIN(R);
-    for (int i = threadIdx.x; i < QR_NB * QR_NB; i += 256) {
-        int r = i % QR_NB, c = i / QR_NB;
+    for (int i = threadIdx.x; i < TRSM_NB * TRSM_NB; i += 256) {
+        int r = i % TRSM_NB, c = i / TRSM_NB;
         sR[r][c] = (r < nb && c < nb && r <= c) ? R[(size_t)(j0 + c) * ldr + (j0 + r)] : make_double2(0.0, 0.0);
     }
     __syncthreads();
     int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= n) return;
-    cplx y[QR_NB];
+    cplx y[TRSM_NB];
 #pragma unroll
-    for (int c = 0; c < QR_NB; ++c) y[c] = (c < nb) ? C[(size_t)(j0 + c) * ldc + row] : make_double2(0.0, 0.0);
+    for (int c = 0; c < TRSM_NB; ++c) y[c] = (c < nb) ? C[(size_t)(j0 + c) * ldc + row] : make_double2(0.0, 0.0);
 #pragma unroll
-    for (int c = 0; c < QR_NB; ++c) {
+    for (int c = 0; c < TRSM_NB; ++c) {
         if (c < nb) {
             cplx acc = y[c];
 #pragma unroll
-            for (int k = 0; k < QR_NB; ++k) {
+            for (int k = 0; k < TRSM_NB; ++k) {
                 if (k < c) {
                     cplx t = q_cmul(y[k], sR[k][c]);
                     acc.x -= t.x; acc.y -= t.y;
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(256) void k_trsm_block(cplx* __restrict__ C, int ld
         }
     }
 #pragma unroll
-    for (int c = 0; c < QR_NB; ++c)
+    for (int c = 0; c < TRSM_NB; ++c)
         if (c < nb) C[(size_t)(j0 + c) * ldc + row] = y[c];
 }
 
@@ -479,8 +480,8 @@ __global__ void k_negate_copy_block(const cplx* __restrict__ R, int ldr, int row
 
 int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w) {
     int launches = 0;
-    for (int j0 = 0; j0 < n; j0 += QR_NB) {
-        const int nb = (n - j0 < QR_NB) ? (n - j0) : QR_NB;
+    for (int j0 = 0; j0 < n; j0 += TRSM_NB) {
+        const int nb = (n - j0 < TRSM_NB) ? (n - j0) : TRSM_NB;
         if (j0 > 0) {
             // C_J += Y_{<J} (-R_{<J,J})
             hipLaunchKernelGGL(k_negate_copy_block, dim3((j0 * nb + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st,

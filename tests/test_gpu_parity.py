@@ -550,3 +550,26 @@ def test_batched_kernel_context_entry_points():
         B = rng.standard_normal(A.shape) + 1j * rng.standard_normal(A.shape)
         assert relerr(ctx.gemm(0, 1, A, B), A @ B.conj().T) < 1e-13
     ctx.close()
+
+
+def test_eight_chain_batch_matches_single_replicas():
+    """8 chains take the XCD-aware launch shape of the wide MFMA kernels (chain -> XCD); same chains as single runs."""
+    import dataclasses
+    from detqmc_amd import DetSDW, DetSDWBatch
+    g = load_golden("o2_L6_seed")
+    p0 = _sdw_params(g["params"], stabilisation="qr")
+    plist = [dataclasses.replace(p0, simindex=p0.simindex + b, r=p0.r + 0.05 * b) for b in range(8)]
+    batch = DetSDWBatch(plist)
+    singles = [DetSDW(p) for p in plist]
+    for i in range(2):
+        batch.sweepThermalization()
+        for sgl in singles:
+            sgl.sweepThermalization()
+    assert np.array_equal(batch.chain(0).phi[1:], _golden_phi(g, "sweep2_phi")[1:])
+    for b, sgl in enumerate(singles):
+        cb = batch.chain(b)
+        assert np.array_equal(cb.phi, sgl.phi), b
+        assert relerr(cb.g, sgl.g) < 1e-12, b
+    for sgl in singles:
+        sgl.close()
+    batch.close()
