@@ -51,19 +51,25 @@ def main():
     out = sys.argv[1]
     rvalues = json.loads(sys.argv[2])
     steps = int(sys.argv[3])
+    n_local = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    rep = OracleReplica(rank, rvalues[rank])
-    rep.o.phiDelta = 0.5 + 0.1 * rank             # make the control data distinguishable
-    st = ExchangeState.create(rvalues, rank, world)
-    hist = []
+    procs = [rank * n_local + b for b in range(n_local)]          # global replica numbers held by this rank
+    reps = [OracleReplica(p, rvalues[p]) for p in procs]
+    for p, rep in zip(procs, reps):
+        rep.o.phiDelta = 0.5 + 0.1 * p              # make the control data distinguishable
+    st = ExchangeState.create(rvalues, rank, world, n_local)
+    hist = [[] for _ in reps]
     for it in range(steps):
-        rep.sweepThermalization()
-        idx = replica_exchange_step(rep, st, dist)
-        replica_exchange_consistency_check(rep, st, dist)
-        hist.append(dict(index=idx, r=rep.get_exchange_parameter_value(), phiDelta=rep.o.phiDelta,
-                         action=rep.get_exchange_action_contribution()))
-    res = dict(rank=rank, hist=hist)
+        for rep in reps:
+            rep.sweepThermalization()
+        idx = replica_exchange_step(reps if n_local > 1 else reps[0], st, dist)
+        replica_exchange_consistency_check(reps, st, dist)
+        idx = idx if n_local > 1 else [idx]
+        for b, rep in enumerate(reps):
+            hist[b].append(dict(index=idx[b], r=rep.get_exchange_parameter_value(), phiDelta=rep.o.phiDelta,
+                                action=rep.get_exchange_action_contribution()))
+    res = dict(rank=rank, hist=hist[0], hist_all=hist)
     if rank == 0:
         res["proposed"] = st.par_swapUpProposed
         res["accepted"] = st.par_swapUpAccepted

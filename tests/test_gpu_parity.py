@@ -573,3 +573,39 @@ def test_eight_chain_batch_matches_single_replicas():
     for sgl in singles:
         sgl.close()
     batch.close()
+
+
+def test_replica_exchange_between_the_chains_of_a_batch():
+    """Parallel tempering inside one GPU: 4 batched chains on an r ladder exchange parameters (detqmc_amd/pt.py,
+    no process group) exactly like 4 single replicas driven the same way."""
+    import dataclasses
+    from detqmc_amd import DetSDW, DetSDWBatch
+    from detqmc_amd.pt import ExchangeState, ReplicaAdapter, replica_exchange_step, replica_exchange_consistency_check
+    g = load_golden("o2_L4")
+    p0 = _sdw_params(g["params"], stabilisation="qr")
+    rvals = [-1.2, -1.1, -1.0, -0.9]
+    plist = [dataclasses.replace(p0, r=rvals[p], simindex=p) for p in range(4)]
+    batch = DetSDWBatch(plist)
+    breps = [ReplicaAdapter(batch.chain(b)) for b in range(4)]
+    singles = [DetSDW(p) for p in plist]
+    sreps = [ReplicaAdapter(s) for s in singles]
+    stb = ExchangeState.create(rvals, 0, 1, n_local=4)
+    sts = ExchangeState.create(rvals, 0, 1, n_local=4)
+    moved = False
+    for it in range(4):
+        batch.sweepThermalization()
+        for s in singles:
+            s.sweepThermalization()
+        ib = replica_exchange_step(breps, stb, None)
+        isg = replica_exchange_step(sreps, sts, None)
+        replica_exchange_consistency_check(breps, stb, None)
+        assert ib == isg
+        moved |= ib != [0, 1, 2, 3]
+        for b in range(4):
+            assert batch.chain(b).get_exchange_parameter_value() == rvals[ib[b]]
+            assert np.array_equal(batch.chain(b).phi, singles[b].phi)
+            assert batch.chain(b).info.phiDelta == singles[b].info.phiDelta
+    assert moved, "ladder too steep for any swap: the test would not exercise the exchange of r on the device"
+    for s in singles:
+        s.close()
+    batch.close()

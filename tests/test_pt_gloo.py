@@ -69,6 +69,49 @@ def test_replica_exchange_two_ranks_gloo(tmp_path, rvalues):
         assert abs(last["phiDelta"] - (0.5 + 0.1 * last["index"])) < 0.11
 
 
+def test_replica_exchange_two_ranks_two_local_replicas_gloo(tmp_path):
+    """2 ranks x 2 replicas per rank (what a GPU holding a batch of chains does): global replica p = rank * 2 + b
+    takes the place of the reference's process p."""
+    rvalues, steps = [-1.0, -0.9, -0.8, -0.7], 3
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + ((os.getpid() + 7) % 500)), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "pt_worker.py"), str(tmp_path),
+           json.dumps(rvalues), str(steps), "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    got = [json.load(open(tmp_path / ("rank%d.json" % p))) for p in range(2)]
+    want = _serial_expectation(rvalues, steps)
+    for rank in range(2):
+        for b in range(2):
+            p = rank * 2 + b
+            for it in range(steps):
+                g, w = got[rank]["hist_all"][b][it], want[p][it]
+                assert g["index"] == w["index"] and g["r"] == w["r"] and g["phiDelta"] == w["phiDelta"], (p, it, g, w)
+    for it in range(steps):
+        assert sorted(got[r]["hist_all"][b][it]["index"] for r in range(2) for b in range(2)) == [0, 1, 2, 3]
+    assert got[0]["proposed"] == [steps, steps, steps, 0]
+
+
+def test_single_process_exchange_between_local_replicas():
+    """dist = None: the whole ensemble on one rank (one GPU), no collective at all."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from pt_worker import OracleReplica
+    from detqmc_amd.pt import ExchangeState, replica_exchange_step, replica_exchange_consistency_check
+    rvalues, steps = [0.5, -2.5], 2
+    reps = [OracleReplica(p, rvalues[p]) for p in range(2)]
+    for p, r in enumerate(reps):
+        r.o.phiDelta = 0.5 + 0.1 * p
+    st = ExchangeState.create(rvalues, 0, 1, n_local=2)
+    want = _serial_expectation(rvalues, steps)
+    for it in range(steps):
+        for r in reps:
+            r.sweepThermalization()
+        idx = replica_exchange_step(reps, st, None)
+        replica_exchange_consistency_check(reps, st, None)
+        for p in range(2):
+            assert idx[p] == want[p][it]["index"] and reps[p].get_exchange_parameter_value() == want[p][it]["r"]
+
+
 def test_rank_count_must_match_parameter_count():
     from detqmc_amd.pt import ExchangeState
     with pytest.raises(ValueError):
