@@ -21,17 +21,17 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 template<int TM, int TN>
 __global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs, int nb) {
-    constexpr int BM_ = 32 * TM, BN_ = 32 * TN;
-    const int tm = (g.M + BM_ - 1) / BM_, tnn = (g.N + BN_ - 1) / BN_;
+    constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16;
+    constexpr int NA = BM * BK / 256, NB_ = BN * BK / 256;      // elements of the A / B tile staged per thread
+    __shared__ cplx sA[2][BK][BM + 1];                            // double buffered: the loads of tile t + 1 are in
+    __shared__ cplx sB[2][BK][BN + 1];                            // flight while the MFMAs work on tile t
+    const int tm = (g.M + BM - 1) / BM, tnn = (g.N + BN - 1) / BN;
     int chain, tile;
     xcd_chain_tile(tm * tnn, nb, chain, tile);
     if (!g.sharedA) g.A = chain_ptr_i(g.A, cs, chain);
     if (!g.sharedB) g.B = chain_ptr_i(g.B, cs, chain);
     g.C = chain_ptr_i(g.C, cs, chain); g.Kdev = chain_ptr_i(g.Kdev, cs, chain); g.kscale = chain_ptr_i(g.kscale, cs, chain);
     g.rowscale = chain_ptr_i(g.rowscale, cs, chain); g.colscale = chain_ptr_i(g.colscale, cs, chain);
-    constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16;
-    __shared__ cplx sA[BK][BM + 1];
-    __shared__ cplx sB[BK][BN + 1];
 
     int K = g.K;
     if (g.Kdev) { int kd = (*g.Kdev) * g.Kmul; K = kd < K ? kd : K; }
@@ -48,13 +48,16 @@ __global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs, int nb) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); }
 
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        // ---- stage op(A) tile: sA[k][i] ----
-        for (int idx = tid; idx < BM * BK; idx += 256) {
+    cplx ra[NA], rb[NB_];
+    // global -> registers: op(A) tile element (i, k), op(B) tile element (k, j)
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int idx = tid + e * 256;
             int i, k;
             if (g.opA == 0) { i = idx % BM; k = idx / BM; } else { k = idx % BK; i = idx / BK; }
             cplx v = make_double2(0.0, 0.0);
-            int gi = i0 + i, gk = k0 + k;
+            const int gi = i0 + i, gk = k0 + k;
             if (gi < g.M && gk < K) {
                 if (g.opA == 0) v = g.A[(size_t)gk * g.lda + gi];
                 else { cplx t = g.A[(size_t)gi * g.lda + gk]; v = make_double2(t.x, -t.y); }
@@ -64,29 +67,51 @@ __global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs, int nb) {
                     v.x *= sc; v.y *= sc;
                 }
             }
-            sA[k][i] = v;
+            ra[e] = v;
         }
-        // ---- stage op(B) tile: sB[k][j] ----
-        for (int idx = tid; idx < BN * BK; idx += 256) {
+#pragma unroll
+        for (int e = 0; e < NB_; ++e) {
+            const int idx = tid + e * 256;
             int j, k;
             if (g.opB == 0) { k = idx % BK; j = idx / BK; } else { j = idx % BN; k = idx / BN; }
             cplx v = make_double2(0.0, 0.0);
-            int gj = j0 + j, gk = k0 + k;
+            const int gj = j0 + j, gk = k0 + k;
             if (gj < g.N && gk < K) {
                 if (g.opB == 0) v = g.B[(size_t)gj * g.ldb + gk];
                 else { cplx t = g.B[(size_t)gk * g.ldb + gj]; v = make_double2(t.x, -t.y); }
             }
-            sB[k][j] = v;
+            rb[e] = v;
         }
-        __syncthreads();
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int idx = tid + e * 256;
+            int i, k;
+            if (g.opA == 0) { i = idx % BM; k = idx / BM; } else { k = idx % BK; i = idx / BK; }
+            sA[buf][k][i] = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < NB_; ++e) {
+            const int idx = tid + e * 256;
+            int j, k;
+            if (g.opB == 0) { k = idx % BK; j = idx / BK; } else { j = idx % BN; k = idx / BN; }
+            sB[buf][k][j] = rb[e];
+        }
+    };
 
+    if (K > 0) { gload(0); sstore(0); }
+    __syncthreads();
+    for (int k0 = 0, buf = 0; k0 < K; k0 += BK, buf ^= 1) {
+        const bool more = k0 + BK < K;
+        if (more) gload(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             cplx af[TM], bf[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = sA[kk + l4][wm * 16 * TM + a * 16 + l15];
+            for (int a = 0; a < TM; ++a) af[a] = sA[buf][kk + l4][wm * 16 * TM + a * 16 + l15];
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = sB[kk + l4][wn * 16 * TN + b * 16 + l15];
+            for (int b = 0; b < TN; ++b) bf[b] = sB[buf][kk + l4][wn * 16 * TN + b * 16 + l15];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -98,7 +123,8 @@ __global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs, int nb) {
                     acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
                 }
         }
-        __syncthreads();
+        if (more) sstore(buf ^ 1);
+        __syncthreads();       // one barrier per tile: nobody refills a buffer that a slower wave still reads
     }
 
     // ---- epilogue: accumulator element r of lane: out-row (=j) = l4 + 4 r, out-col (=i) = l15 ----
