@@ -663,61 +663,68 @@ void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevMod
 }
 
 // X[:, i'] = sum_i G[:, I_i] W[i, i']   (n_g x nI, ld n_g);   Gr[i, :] = G[I_i, :] - E   (nI x n_g, ld WD)
-// One workgroup per 64 rows (of X) / 64 columns (of Gr).  The 64 x nI slab of G[:, I] is staged in LDS once
-// (coalesced along the rows) and every thread forms its X entries from LDS.
+// One workgroup per 32 rows of X / 32 columns of Gr, no LDS staging: the columns G[:, I_i] are contiguous, so the
+// MFMA operand fragments of X = G[:, I] W come straight from global memory (16 lanes = 16 consecutive rows);
+// wave w forms the 16 columns 16 w .. 16 w + 15 of the tile (operand roles swapped as in k_zgemm so that the stores
+// coalesce).  The rows G[I_i, :] are a strided gather by nature (16 useful bytes per 64-byte sector).
+typedef double u_v4d __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpdateState* __restrict__ us,
                                                         const cplx* __restrict__ G, const cplx* __restrict__ Wg,
                                                         cplx* __restrict__ X, cplx* __restrict__ Gr, size_t cs) {
-    extern __shared__ cplx sdyn[];
-    CHAIN(us); CHAIN(G); CHAIN(Wg); CHAIN(X); CHAIN(Gr);      // sW: [nI cols][WD] as stored by the decision kernel, then sG: [nI][65]
+    CHAIN(us); CHAIN(G); CHAIN(Wg); CHAIN(X); CHAIN(Gr);
     const int j = us->block_j;
     if (j <= 0) return;
     const int MSF = dm.MSF, N = dm.N, ng = dm.ng, WD = MSF * dm.D;
     const int nI = MSF * j;
-    cplx* sW = sdyn;
-    cplx* sG = sdyn + (size_t)WD * WD;
     __shared__ int sI[DQMC_MAX_WDIM];
     for (int t = threadIdx.x; t < nI; t += 256) sI[t] = us->block_sites[t / MSF] + (t % MSF) * N;
-    for (int t = threadIdx.x; t < nI * WD; t += 256) sW[t] = Wg[t];
     __syncthreads();
-    const int r0 = blockIdx.x * 64;
-    const int lr = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int r = r0 + lr;
-    for (int i = sub; i < nI; i += 4) {
-        cplx g = make_double2(0.0, 0.0);
-        if (r < ng) {
-            g = G[(size_t)sI[i] * ng + r];                 // G[r, I_i]: coalesced along r
-            cplx h = G[(size_t)r * ng + sI[i]];            // G[I_i, r]
-            if (r == sI[i]) h.x -= 1.0;
-            Gr[(size_t)r * WD + i] = h;
-        }
-        sG[i * 65 + lr] = g;
-    }
-    __syncthreads();
-    if (r < ng) {
-        for (int i2 = sub; i2 < nI; i2 += 4) {
-            cplx acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
-            const cplx* wcol = sW + (size_t)i2 * WD;
-#pragma unroll 4
-            for (int i = 0; i < nI; i += 2) {              // nI is even
-                acc0 = u_cfma(sG[i * 65 + lr], wcol[i], acc0);
-                acc1 = u_cfma(sG[(i + 1) * 65 + lr], wcol[i + 1], acc1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 32;
+    // ---- Gr[i, r] = G[I_i, r] - delta ----
+    {
+        const int r = r0 + (tid & 31);
+        if (r < ng)
+            for (int i = tid >> 5; i < nI; i += 8) {
+                cplx h = G[(size_t)r * ng + sI[i]];
+                if (r == sI[i]) h.x -= 1.0;
+                Gr[(size_t)r * WD + i] = h;
             }
-            X[(size_t)i2 * ng + r] = make_double2(acc0.x + acc1.x, acc0.y + acc1.y);
+    }
+    // ---- X tile: rows r0 .. r0 + 31, columns 16 wave .. 16 wave + 15 ----
+    const int c0 = wave * 16;
+    if (c0 >= nI) return;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    u_v4d acc_re[2], acc_im[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { acc_re[a] = (u_v4d)(0.0); acc_im[a] = (u_v4d)(0.0); }
+#pragma unroll 2
+    for (int k0 = 0; k0 < nI; k0 += 4) {
+        const int gk = k0 + l4;
+        const bool kok = gk < nI;
+        // first MFMA operand (m = column of X, k): W[k][c0 + l15];  second (k, n = row): G[r0 + a 16 + l15, I_k]
+        const cplx w = (kok && c0 + l15 < nI) ? Wg[(size_t)(c0 + l15) * WD + gk] : make_double2(0.0, 0.0);
+        const size_t col = kok ? (size_t)sI[gk] * ng : 0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int r = r0 + a * 16 + l15;
+            const cplx g = (kok && r < ng) ? G[col + r] : make_double2(0.0, 0.0);
+            acc_re[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, g.x, acc_re[a], 0, 0, 0);
+            acc_re[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w.y, g.y, acc_re[a], 0, 0, 0);
+            acc_im[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, g.x, acc_im[a], 0, 0, 0);
+            acc_im[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, g.y, acc_im[a], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int c = c0 + l4 + 4 * rr, r = r0 + a * 16 + l15;      // D[m = l4 + 4 rr][n = l15]
+            if (c < nI && r < ng) X[(size_t)c * ng + r] = make_double2(acc_re[a][rr], acc_im[a][rr]);
+        }
 }
 
 void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,
                           const cplx* W, cplx* X, cplx* Gr) {
-    const int WD = hm.MSF * hm.D;
-    size_t lds = ((size_t)WD * WD + (size_t)WD * 65) * sizeof(cplx);
-    if (lds > 48 * 1024) {
-        static size_t raised = 0;
-        if (lds > raised) {
-            if (hipFuncSetAttribute((const void*)k_update_gather, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised = lds;
-            else (void)hipGetLastError();
-        }
-    }
-    hipLaunchKernelGGL(k_update_gather, dim3((hm.ng + 63) / 64, 1, lc.nb), dim3(256), lds, lc.st, hm, us, G, W, X, Gr, lc.cs);
+    hipLaunchKernelGGL(k_update_gather, dim3((hm.ng + 31) / 32, 1, lc.nb), dim3(256), 0, lc.st, hm, us, G, W, X, Gr, lc.cs);
 }
