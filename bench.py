@@ -26,14 +26,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=int(os.environ.get("DQMC_DELAY_STEPS", "16")), r=-1.0, c=3.0, u=1.0, lambda_=1.0,
+# delaySteps: depth of the delayed-update blocks -- a performance knob, the Markov chain does not depend on it (tests:
+# test_update_slice_delay_steps_invariance, test_qr_mode_headline_size_vs_reference_checksums[32]); 32 halves the
+# read-modify-write traffic of G per accepted update.  The reference CPU baseline runs with its own setting (16).
+WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=int(os.environ.get("DQMC_DELAY_STEPS", "32")), r=-1.0, c=3.0, u=1.0, lambda_=1.0,
                 mu=-0.5, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, bc="pbc", accRatio=0.5,
                 rngSeed=1020304050,
                 # same Green's functions and Markov chain as the reference-exact "svd" mode (tests), ~10x cheaper
                 stabilisation=os.environ.get("DQMC_STABILISATION", "qr"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
-DEFAULT_BATCH = 32             # chains per kernel context (lockstep batch): fills the 256 CUs
+DEFAULT_BATCH = 64             # chains per kernel context (lockstep batch); 4 x 64 chains = 61 GB of the 288 GB HBM
 DEFAULT_WORKERS = 4            # contexts per GPU: the latency-bound kernels of one overlap the streaming kernels of the others
 
 
@@ -318,7 +321,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (random initial field, fixed seed)",
-            "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(16) "
+            "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(%d) " % WORKLOAD["delaySteps"] +
                                    "sweepThermalization, %d independent chains per GPU (%d kernel contexts x %d lockstep chains), stabilisation=%s"
                                    % (R * B, R, B, WORKLOAD["stabilisation"]),
                        "n_g": n, "m": r0["m"], "replicas_per_gpu": R * B, "contexts_per_gpu": R,

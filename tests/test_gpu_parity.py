@@ -426,10 +426,13 @@ def test_qr_mode_replica_trajectory_vs_reference(name):
     rep.close()
 
 
-def test_qr_mode_headline_size_vs_reference_checksums():
+@pytest.mark.parametrize("delaySteps", [16, 32])
+def test_qr_mode_headline_size_vs_reference_checksums(delaySteps):
+    """delaySteps = 32 (bench.py's setting) against the fixture the reference produced with 16: the depth of the
+    delayed-update blocks is a performance knob, the Markov chain does not depend on it."""
     from detqmc_amd import DetSDW
     g = load_golden("o2_L16_b10")
-    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr"))
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr", delaySteps=delaySteps))
     G = rep.g
     assert relerr(G[::16, ::16], g["init_g_sub16"]) < TOL
     assert relerr(np.diag(G), g["init_g_diag"]) < TOL
