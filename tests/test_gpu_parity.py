@@ -373,7 +373,7 @@ def test_headline_size_vs_reference_checksums():
 # ------------------------------------------------------------------------------------------------
 # QR ("UDT") stabilisation mode: different factorisation, same Green's functions and same Markov chain
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("L,opdim", [(4, 2), (6, 2), (8, 2), (4, 3)])
+@pytest.mark.parametrize("L,opdim", [(4, 2), (6, 2), (8, 2), (4, 3), (16, 2), (12, 3), (16, 3)])   # n_g up to 1024: all panel depths
 def test_qr_udt_decompose(L, opdim):
     from detqmc_amd import KernelContext
     ctx = KernelContext(opdim, L, 20, 10, 0.1, delaySteps=4, stabilisation="qr")
