@@ -364,6 +364,108 @@ __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, i
     }
 }
 
+// The same update with the 16 columns of C held in REGISTERS between the two passes (rows <= 512): every wave owns a
+// slab of rows, its lanes keep the slab in MFMA fragment order -- element e of lane (l15, l4) is C[slab + 4 e + l4,
+// c0 + l15], which is at once the B fragment of pass 1 (k = row, n = column) and the accumulator layout of pass 2
+// (m = row = l4 + 4 r, n = column) -- so C is read once and written once instead of read twice, and pass 1 needs no
+// LDS staging or barrier per chunk.  V comes from global memory (all workgroups of a chain read the same panel: L2).
+template<bool TRANS_T>
+__global__ __launch_bounds__(256) void k_qr_apply_reg(const cplx* __restrict__ Vp, int ldv, const cplx* __restrict__ Tn,
+                                                       cplx* __restrict__ C, int ldc, int rows, int ncols, int nb, size_t cs) {
+    __shared__ cplx sW[QR_NB][QR_NB + 1];      // W, then W2, as [k][j]
+    __shared__ cplx sT[QR_NB][QR_NB + 1];      // -T as [i][k]
+    __shared__ cplx sPart[4][QR_NB][QR_NB + 1];
+    CHAIN(Vp); CHAIN(Tn); CHAIN(C);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int c0 = blockIdx.x * QR_NB;
+    const int nc = min(QR_NB, ncols - c0);
+    {
+        int i = tid & 15, k = tid >> 4;
+        sT[i][k] = (i < nb && k < nb) ? Tn[k * QR_NB + i] : make_double2(0.0, 0.0);
+    }
+    const int RW = ((rows + 63) / 64) * 16;        // rows per wave, a multiple of 16 (<= 128)
+    const int ne = RW / 4;                          // elements per lane (<= 32)
+    const int slab = wave * RW;
+    cplx* Ccol = C + (size_t)(c0 + l15) * ldc;
+    const cplx* Vcol = Vp + (size_t)l15 * ldv;
+    const bool cok = l15 < nc, vok = l15 < nb;
+    cplx creg[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const int row = slab + 4 * e + l4;
+        creg[e] = (e < ne && cok && row < rows) ? Ccol[row] : make_double2(0.0, 0.0);
+    }
+    // ---- pass 1: W = V^H C over this wave's slab ----
+    q_v4d w_re = (q_v4d)(0.0), w_im = (q_v4d)(0.0);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        if (e < ne) {
+            const int row = slab + 4 * e + l4;
+            const cplx v = (vok && row < rows) ? Vcol[row] : make_double2(0.0, 0.0);     // A(m = i, k) = conj(v)
+            const cplx x = creg[e];                                                       // B(k, n = j)
+            w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.x, w_re, 0, 0, 0);
+            w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.y, w_re, 0, 0, 0);
+            w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.y, w_im, 0, 0, 0);
+            w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, x.x, w_im, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sPart[wave][l4 + 4 * r][l15] = make_double2(w_re[r], w_im[r]);   // D[m = l4 + 4r][n = l15]
+    __syncthreads();
+    const int wi = tid & 15, wj = tid >> 4;
+    {
+        cplx p0 = sPart[0][wi][wj], p1 = sPart[1][wi][wj], p2 = sPart[2][wi][wj], p3 = sPart[3][wi][wj];
+        sW[wi][wj] = make_double2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+    }
+    __syncthreads();
+    // ---- W2 = (-T)^(H) W ----
+    {
+        cplx a2 = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < QR_NB; ++k) {
+            cplx t = TRANS_T ? make_double2(sT[k][wi].x, -sT[k][wi].y) : sT[wi][k];
+            cplx w = sW[k][wj];
+            a2.x += t.x * w.x - t.y * w.y;
+            a2.y += t.x * w.y + t.y * w.x;
+        }
+        __syncthreads();
+        sW[wi][wj] = a2;
+    }
+    __syncthreads();
+    // ---- pass 2: C tile (16 rows x 16 columns) += V W2, accumulated straight into the registers that hold C ----
+    cplx w2[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w2[ks] = sW[ks * 4 + l4][l15];           // B(k, n = column)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (4 * t < ne) {
+            const int vrow = slab + 16 * t + l15;                            // A(m = row, k)
+            cplx vf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = ks * 4 + l4;
+                vf[ks] = (vrow < rows && k < nb) ? Vp[(size_t)k * ldv + vrow] : make_double2(0.0, 0.0);
+            }
+            q_v4d d_re, d_im;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { d_re[r] = creg[4 * t + r].x; d_im[r] = creg[4 * t + r].y; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].x, d_re, 0, 0, 0);
+                d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-vf[ks].y, w2[ks].y, d_re, 0, 0, 0);
+                d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].y, d_im, 0, 0, 0);
+                d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].y, w2[ks].x, d_im, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = slab + 16 * t + l4 + 4 * r;                  // D[m = l4 + 4r][n = l15]
+                if (cok && row < rows) Ccol[row] = make_double2(d_re[r], d_im[r]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // driver: A (n x n, ld n) -> R in place (strict lower part zeroed), Q explicit; V/T workspace
 // ---------------------------------------------------------------------------------------------
@@ -404,7 +506,10 @@ int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
             cplx* C = A + (size_t)(j0 + nb) * n + j0;
             // apply Q_p^H = I - V T^H V^H to the trailing columns
             if (w.apply_hooks) w.apply_hooks->begin(w.apply_hooks->user);
-            hipLaunchKernelGGL((k_qr_apply<true>), dim3((ntrail + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ntrail, nb, lc.cs);
+            if (rows <= 512)
+                hipLaunchKernelGGL((k_qr_apply_reg<true>), dim3((ntrail + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ntrail, nb, lc.cs);
+            else
+                hipLaunchKernelGGL((k_qr_apply<true>), dim3((ntrail + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ntrail, nb, lc.cs);
             if (w.apply_hooks) w.apply_hooks->end(w.apply_hooks->user, 1);
             launches += 1;
         }
@@ -421,7 +526,10 @@ int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
         cplx* C = Q + (size_t)j0 * n + j0;
         // C <- (I - V T V^H) C
         if (w.apply_hooks) w.apply_hooks->begin(w.apply_hooks->user);
-        hipLaunchKernelGGL((k_qr_apply<false>), dim3((ncols + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ncols, nb, lc.cs);
+        if (rows <= 512)
+            hipLaunchKernelGGL((k_qr_apply_reg<false>), dim3((ncols + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ncols, nb, lc.cs);
+        else
+            hipLaunchKernelGGL((k_qr_apply<false>), dim3((ncols + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ncols, nb, lc.cs);
         if (w.apply_hooks) w.apply_hooks->end(w.apply_hooks->user, 1);
         launches += 1;
     }
