@@ -202,8 +202,11 @@ static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::ve
     const double pi = M_PI;
     for (int sub = 0; sub < 2; ++sub) {
         int pidx = 0;
-        for (int i1 = sub; i1 < L; i1 += 2)
-            for (int i2 = sub; i2 < L; i2 += 2, ++pidx) {
+        // plaquettes of a subgroup are disjoint, so their order is free: x runs fastest so that lanes working on
+        // consecutive plaquettes touch LDS / memory 2 sites apart (the reference's y-fastest order would put them
+        // 2 L sites = a multiple of the LDS bank period apart: 64-way bank conflicts in k_bmult_chain)
+        for (int i2 = sub; i2 < L; i2 += 2)
+            for (int i1 = sub; i1 < L; i1 += 2, ++pidx) {
                 int i = i2 * L + i1, j = neigh[0 * N + i], k = neigh[2 * N + i], l = neigh[0 * N + k];
                 const int corner[4] = {i, j, k, l};
                 for (int q = 0; q < 4; ++q) psites[(sub * 4 + q) * P + pidx] = corner[q];

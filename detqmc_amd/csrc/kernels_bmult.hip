@@ -15,6 +15,7 @@
 // vectors are contiguous in the column-major matrix; row vectors are staged as 64-byte pieces.
 #include "dqmc_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
@@ -66,7 +67,10 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
     if (nv <= 0) return;
     const int tid = threadIdx.x, nth = blockDim.x;
     // LDS address of element e of vector v
-    auto addr = [&](int v, int e) -> int { return RIGHT ? (e * nvec + v) : (v * ng + e); };
+    // RIGHT: rows are staged as pieces of nvec elements per column; one padding element per column keeps lanes that
+    // work on sites 2 apart off the same LDS banks
+    const int rstride = nvec + 1;
+    auto addr = [&](int v, int e) -> int { return RIGHT ? (e * rstride + v) : (v * ng + e); };
 
     // ---- stage in ----
     if (!RIGHT) {
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
     } else {
         for (int idx = tid; idx < nvec * ng; idx += nth) {
             int e = idx / nvec, v = idx - e * nvec;
-            if (v < nv) sm[e * nvec + v] = A[(size_t)e * lda + (v0 + v)];
+            if (v < nv) sm[e * rstride + v] = A[(size_t)e * lda + (v0 + v)];
         }
     }
     __syncthreads();
@@ -97,10 +101,9 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
                     const int sub = (pass == 1) ? 0 : 1;
                     const int items = nv * MSF * P;
                     for (int idx = tid; idx < items; idx += nth) {
-                        int p = idx % P;
-                        int t = idx / P;
-                        int b = t % MSF;
-                        int v = t / MSF;
+                        int p, b, v;
+                        if (RIGHT) { v = idx % nv; int t = idx / nv; p = t % P; b = t / P; }     // vectors fastest: contiguous in LDS
+                        else { p = idx % P; int t = idx / P; b = t % MSF; v = t / MSF; }
                         int band = b & 1;
                         const size_t tbl = (size_t)((band * 2 + signIdx) * 2 + sub);
                         int e[4];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
     } else {
         for (int idx = tid; idx < nvec * ng; idx += nth) {
             int e = idx / nvec, v = idx - e * nvec;
-            if (v < nv) A[(size_t)e * lda + (v0 + v)] = sm[e * nvec + v];
+            if (v < nv) A[(size_t)e * lda + (v0 + v)] = sm[e * rstride + v];
         }
     }
 }
@@ -199,17 +202,19 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
 void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, int side, int inverse,
                   int kfirst, int kstep, int kcount, cplx* A, int lda) {
     const int ng = hm.ng;
-    const int max_fit = (int)(65536 / ((size_t)ng * sizeof(cplx)));   // keep <= 64 KiB of LDS
+    const int max_fit = (int)(65536 / ((size_t)ng * sizeof(cplx))) - (side == DQMC_LEFT ? 0 : 1);   // keep <= 64 KiB of LDS
+    static const int env_l = getenv("DQMC_BMULT_NVEC_L") ? atoi(getenv("DQMC_BMULT_NVEC_L")) : 0;   // developer knobs
+    static const int env_r = getenv("DQMC_BMULT_NVEC_R") ? atoi(getenv("DQMC_BMULT_NVEC_R")) : 0;
     int nvec;
     if (side == DQMC_LEFT) {
-        nvec = ng / 256;                 // aim at >= 256 workgroups
+        nvec = env_l ? env_l : ng / 256;                 // aim at >= 256 workgroups
     } else {
-        nvec = 4;                        // 64-byte pieces of each column per row tile
+        nvec = env_r ? env_r : 4;                        // 64-byte pieces of each column per row tile
     }
     if (nvec > max_fit) nvec = max_fit;
     if (nvec < 1) nvec = 1;
     const int grid = (ng + nvec - 1) / nvec;
-    const size_t lds = (size_t)nvec * ng * sizeof(cplx);
+    const size_t lds = (size_t)(side == DQMC_LEFT ? nvec : nvec + 1) * ng * sizeof(cplx);
 #define LAUNCH(MSFV, R, I)                                                                              \
     hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I>), dim3(grid, 1, lc.nb), dim3(256), lds, lc.st, hm, A, lda, nvec, \
                        kfirst, kstep, kcount, lc.cs)
