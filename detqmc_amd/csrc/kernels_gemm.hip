@@ -20,7 +20,7 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 template<int TM, int TN>
-__global__ __launch_bounds__(256) void k_zgemm(GemmArgs g, size_t cs, int nb) {
+__global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb) {   // 2 workgroups per CU: <= 256 registers
     constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16;
     constexpr int NA = BM * BK / 256, NB_ = BN * BK / 256;      // elements of the A / B tile staged per thread
     __shared__ cplx sA[2][BK][BM + 1];                            // double buffered: the loads of tile t + 1 are in

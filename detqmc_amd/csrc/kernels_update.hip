@@ -173,8 +173,9 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     const int N = dm.N, ng = dm.ng, D = dm.D, m = dm.m;
     const int WD = MSF * D;
     extern __shared__ cplx smem[];
-    cplx* W = smem;                       // [WD][WD] row-major: W[i*WD + i']
-    cplx* su2 = W + WD * WD;              // u[a][i]  = G[c_a, I_i]      2 x [MSF][WD]  (ping-pong per proposal)
+    const int WS = WD + 1;                // row stride of W in LDS: odd, so rows do not start on the same banks
+    cplx* W = smem;                       // [WD][WS] row-major: W[i*WS + i']
+    cplx* su2 = W + WD * WS;              // u[a][i]  = G[c_a, I_i]      2 x [MSF][WD]  (ping-pong per proposal)
     cplx* sv2 = su2 + 2 * MSF * WD;       // v[i][b]  = G[I_i, c_b]      2 x [WD][MSF]
     cplx* sp = sv2 + 2 * WD * MSF;        // p = W v                     [WD][MSF]
     cplx* sq = sp + WD * MSF;             // q = u W                     [MSF][WD]
@@ -374,13 +375,13 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 cplx* dst;
                 if (item < nI * MSF) {
                     int i = item / MSF, b = item - i * MSF;
-                    const cplx* wrow = W + i * WD;
+                    const cplx* wrow = W + i * WS;
                     for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(wrow[i2], sv[i2 * MSF + b], acc);
                     dst = sp + i * MSF + b;
                 } else {
                     int it2 = item - nI * MSF;
                     int a = it2 / nI, i = it2 - a * nI;
-                    for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(su[a * WD + i2], W[i2 * WD + i], acc);
+                    for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(su[a * WD + i2], W[i2 * WS + i], acc);
                     dst = sq + a * WD + i;
                 }
                 acc.x = u_dpp_add<0xB1, 0xf>(acc.x); acc.y = u_dpp_add<0xB1, 0xf>(acc.y);     // quad sum
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 cplx pi[MSF];
 #pragma unroll
                 for (int q = 0; q < MSF; ++q) pi[q] = sp[i * MSF + q];
-                cplx acc = W[i * WD + i2];
+                cplx acc = W[i * WS + i2];
 #pragma unroll
                 for (int b = 0; b < MSF; ++b) {
                     cplx pf = make_double2(0.0, 0.0);
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                     for (int q = 0; q < MSF; ++q) pf = u_cfma(pi[q], F[q][b], pf);
                     acc = u_cfma(pf, sq[b * WD + i2], acc);
                 }
-                W[i * WD + i2] = acc;
+                W[i * WS + i2] = acc;
             }
             for (int i = tid; i < nI; i += 256) {
                 cplx pi[MSF];
@@ -552,15 +553,15 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                         pf = u_cfma(pi[q], F[q][b], pf);
                         fq = u_cfma(F[b][q], sq[q * WD + i], fq);
                     }
-                    W[i * WD + (nI + b)] = pf;
-                    W[(nI + b) * WD + i] = fq;
+                    W[i * WS + (nI + b)] = pf;
+                    W[(nI + b) * WS + i] = fq;
                 }
             }
             if (tid == 0) {
 #pragma unroll
                 for (int a = 0; a < MSF; ++a)
 #pragma unroll
-                    for (int b = 0; b < MSF; ++b) W[(nI + a) * WD + (nI + b)] = F[a][b];
+                    for (int b = 0; b < MSF; ++b) W[(nI + a) * WS + (nI + b)] = F[a][b];
             }
             j += 1;
         }
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     const int nI = MSF * j;
     for (int t = tid; t < nI * nI; t += 256) {
         int i = t / nI, i2 = t - i * nI;
-        Wout[(size_t)i2 * WD + i] = W[i * WD + i2];        // column-major, ld = WD
+        Wout[(size_t)i2 * WD + i] = W[i * WS + i2];        // column-major, ld = WD
     }
     if (tid == 0) {
         us->site_cursor = site;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
 void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, DevUpdateState* us,
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal) {
     const int WD = hm.MSF * hm.D;
-    size_t lds = ((size_t)WD * WD + 6 * (size_t)hm.MSF * WD) * sizeof(cplx) + (size_t)hm.opdim * hm.N * sizeof(double);
+    size_t lds = ((size_t)WD * (WD + 1) + 6 * (size_t)hm.MSF * WD) * sizeof(cplx) + (size_t)hm.opdim * hm.N * sizeof(double);
     if (lds > 48 * 1024) {     // deep delay blocks: raise the dynamic LDS limit of the instantiation to what is needed
         static size_t raised[4] = {0, 0, 0, 0};
         if (lds > raised[hm.opdim]) {
