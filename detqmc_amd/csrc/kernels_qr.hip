@@ -370,99 +370,110 @@ __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, i
 // (m = row = l4 + 4 r, n = column) -- so C is read once and written once instead of read twice, and pass 1 needs no
 // LDS staging or barrier per chunk.  V comes from global memory (all workgroups of a chain read the same panel: L2).
 template<bool TRANS_T>
-__global__ __launch_bounds__(256) void k_qr_apply_reg(const cplx* __restrict__ Vp, int ldv, const cplx* __restrict__ Tn,
-                                                       cplx* __restrict__ C, int ldc, int rows, int ncols, int nb, size_t cs) {
+__global__ __launch_bounds__(256) void k_qr_apply_reg(const cplx* __restrict__ V1, const cplx* __restrict__ T1n, int nb1,
+                                                       const cplx* __restrict__ V2, const cplx* __restrict__ T2n, int nb2,
+                                                       int ldv, cplx* __restrict__ C, int ldc, int rows, int ncols, size_t cs) {
     __shared__ cplx sW[QR_NB][QR_NB + 1];      // W, then W2, as [k][j]
     __shared__ cplx sT[QR_NB][QR_NB + 1];      // -T as [i][k]
     __shared__ cplx sPart[4][QR_NB][QR_NB + 1];
-    CHAIN(Vp); CHAIN(Tn); CHAIN(C);
+    CHAIN(V1); CHAIN(T1n); CHAIN(V2); CHAIN(T2n); CHAIN(C);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int c0 = blockIdx.x * QR_NB;
     const int nc = min(QR_NB, ncols - c0);
-    {
-        int i = tid & 15, k = tid >> 4;
-        sT[i][k] = (i < nb && k < nb) ? Tn[k * QR_NB + i] : make_double2(0.0, 0.0);
-    }
     const int RW = ((rows + 63) / 64) * 16;        // rows per wave, a multiple of 16 (<= 128)
     const int ne = RW / 4;                          // elements per lane (<= 32)
     const int slab = wave * RW;
     cplx* Ccol = C + (size_t)(c0 + l15) * ldc;
-    const cplx* Vcol = Vp + (size_t)l15 * ldv;
-    const bool cok = l15 < nc, vok = l15 < nb;
+    const bool cok = l15 < nc;
     cplx creg[32];
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
         const int row = slab + 4 * e + l4;
         creg[e] = (e < ne && cok && row < rows) ? Ccol[row] : make_double2(0.0, 0.0);
     }
-    // ---- pass 1: W = V^H C over this wave's slab ----
-    q_v4d w_re = (q_v4d)(0.0), w_im = (q_v4d)(0.0);
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-        if (e < ne) {
-            const int row = slab + 4 * e + l4;
-            const cplx v = (vok && row < rows) ? Vcol[row] : make_double2(0.0, 0.0);     // A(m = i, k) = conj(v)
-            const cplx x = creg[e];                                                       // B(k, n = j)
-            w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.x, w_re, 0, 0, 0);
-            w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.y, w_re, 0, 0, 0);
-            w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.y, w_im, 0, 0, 0);
-            w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, x.x, w_im, 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sPart[wave][l4 + 4 * r][l15] = make_double2(w_re[r], w_im[r]);   // D[m = l4 + 4r][n = l15]
-    __syncthreads();
+    // Up to two block reflectors are applied one after the other while C stays in registers (the second one is the
+    // next panel's, whose rows above its own first row are zero in V): the trailing matrix is then read and written
+    // once per PAIR of panels.
     const int wi = tid & 15, wj = tid >> 4;
-    {
-        cplx p0 = sPart[0][wi][wj], p1 = sPart[1][wi][wj], p2 = sPart[2][wi][wj], p3 = sPart[3][wi][wj];
-        sW[wi][wj] = make_double2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
-    }
-    __syncthreads();
-    // ---- W2 = (-T)^(H) W ----
-    {
-        cplx a2 = make_double2(0.0, 0.0);
+    for (int rf = 0; rf < 2; ++rf) {
+        const cplx* Vp = rf == 0 ? V1 : V2;
+        const cplx* Tn = rf == 0 ? T1n : T2n;
+        const int nb = rf == 0 ? nb1 : nb2;
+        if (nb <= 0) break;
+        __syncthreads();                            // sT / sW / sPart of the previous reflector are no longer read
+        sT[wi][wj] = (wi < nb && wj < nb) ? Tn[wj * QR_NB + wi] : make_double2(0.0, 0.0);
+        const cplx* Vcol = Vp + (size_t)l15 * ldv;
+        const bool vok = l15 < nb;
+        // ---- pass 1: W = V^H C over this wave's slab ----
+        q_v4d w_re = (q_v4d)(0.0), w_im = (q_v4d)(0.0);
 #pragma unroll
-        for (int k = 0; k < QR_NB; ++k) {
-            cplx t = TRANS_T ? make_double2(sT[k][wi].x, -sT[k][wi].y) : sT[wi][k];
-            cplx w = sW[k][wj];
-            a2.x += t.x * w.x - t.y * w.y;
-            a2.y += t.x * w.y + t.y * w.x;
+        for (int e = 0; e < 32; ++e) {
+            if (e < ne) {
+                const int row = slab + 4 * e + l4;
+                const cplx v = (vok && row < rows) ? Vcol[row] : make_double2(0.0, 0.0);     // A(m = i, k) = conj(v)
+                const cplx x = creg[e];                                                       // B(k, n = j)
+                w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.x, w_re, 0, 0, 0);
+                w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.y, w_re, 0, 0, 0);
+                w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.y, w_im, 0, 0, 0);
+                w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, x.x, w_im, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPart[wave][l4 + 4 * r][l15] = make_double2(w_re[r], w_im[r]);   // D[m = l4 + 4r][n = l15]
+        __syncthreads();
+        {
+            cplx p0 = sPart[0][wi][wj], p1 = sPart[1][wi][wj], p2 = sPart[2][wi][wj], p3 = sPart[3][wi][wj];
+            sW[wi][wj] = make_double2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
         }
         __syncthreads();
-        sW[wi][wj] = a2;
-    }
-    __syncthreads();
-    // ---- pass 2: C tile (16 rows x 16 columns) += V W2, accumulated straight into the registers that hold C ----
-    cplx w2[4];
+        // ---- W2 = (-T)^(H) W ----
+        {
+            cplx a2 = make_double2(0.0, 0.0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) w2[ks] = sW[ks * 4 + l4][l15];           // B(k, n = column)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        if (4 * t < ne) {
-            const int vrow = slab + 16 * t + l15;                            // A(m = row, k)
-            cplx vf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int k = ks * 4 + l4;
-                vf[ks] = (vrow < rows && k < nb) ? Vp[(size_t)k * ldv + vrow] : make_double2(0.0, 0.0);
+            for (int k = 0; k < QR_NB; ++k) {
+                cplx t = TRANS_T ? make_double2(sT[k][wi].x, -sT[k][wi].y) : sT[wi][k];
+                cplx w = sW[k][wj];
+                a2.x += t.x * w.x - t.y * w.y;
+                a2.y += t.x * w.y + t.y * w.x;
             }
-            q_v4d d_re, d_im;
+            __syncthreads();
+            sW[wi][wj] = a2;
+        }
+        __syncthreads();
+        // ---- pass 2: C tile (16 rows x 16 columns) += V W2, accumulated straight into the registers that hold C ----
+        cplx w2[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { d_re[r] = creg[4 * t + r].x; d_im[r] = creg[4 * t + r].y; }
+        for (int ks = 0; ks < 4; ++ks) w2[ks] = sW[ks * 4 + l4][l15];           // B(k, n = column)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].x, d_re, 0, 0, 0);
-                d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-vf[ks].y, w2[ks].y, d_re, 0, 0, 0);
-                d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].y, d_im, 0, 0, 0);
-                d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].y, w2[ks].x, d_im, 0, 0, 0);
-            }
+        for (int t = 0; t < 8; ++t) {
+            if (4 * t < ne) {
+                const int vrow = slab + 16 * t + l15;                            // A(m = row, k)
+                cplx vf[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = slab + 16 * t + l4 + 4 * r;                  // D[m = l4 + 4r][n = l15]
-                if (cok && row < rows) Ccol[row] = make_double2(d_re[r], d_im[r]);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int k = ks * 4 + l4;
+                    vf[ks] = (vrow < rows && k < nb) ? Vp[(size_t)k * ldv + vrow] : make_double2(0.0, 0.0);
+                }
+                q_v4d d_re, d_im;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { d_re[r] = creg[4 * t + r].x; d_im[r] = creg[4 * t + r].y; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].x, d_re, 0, 0, 0);
+                    d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-vf[ks].y, w2[ks].y, d_re, 0, 0, 0);
+                    d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].y, d_im, 0, 0, 0);
+                    d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].y, w2[ks].x, d_im, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) creg[4 * t + r] = make_double2(d_re[r], d_im[r]);   // D[m = l4 + 4r][n = l15]
             }
         }
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const int row = slab + 4 * e + l4;
+        if (e < ne && cok && row < rows) Ccol[row] = creg[e];
     }
 }
 
@@ -493,45 +504,62 @@ static void launch_panel(const Launch& lc, cplx* A, int n, int j0, cplx* V, cplx
 int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
     int launches = 0;
     const int np = (n + QR_NB - 1) / QR_NB;
-    for (int p = 0; p < np; ++p) {
-        const int j0 = p * QR_NB;
-        const int nb = (n - j0 < QR_NB) ? (n - j0) : QR_NB;   // n is a multiple of 8: a last half panel is padded by the kernel guards
-        cplx* Tp = w.T + (size_t)p * 2 * QR_NB * QR_NB;
-        cplx* Tn = Tp + QR_NB * QR_NB;
-        launch_panel(lc, A, n, j0, w.V, Tp, Tn);
+    const bool reg = n <= 512;                          // register-resident update kernel, panels applied in pairs
+    auto Tneg = [&](int p) { return w.T + (size_t)p * 2 * QR_NB * QR_NB + QR_NB * QR_NB; };
+    auto Vat = [&](int pcol, int prow) { return w.V + (size_t)(pcol * QR_NB) * n + prow * QR_NB; };   // panel pcol's V from row block prow
+    auto nbof = [&](int p) { return (n - p * QR_NB < QR_NB) ? (n - p * QR_NB) : QR_NB; };
+    // block reflector(s) p1 (then p2, < 0: none) applied to ncols columns of M starting at column block cb, rows from block rb
+    auto apply = [&](bool transT, cplx* M, int rb, int cb_col0, int ncols, int p1, int p2) {
+        const int rows = n - rb * QR_NB;
+        cplx* C = M + (size_t)cb_col0 * n + rb * QR_NB;
+        const dim3 grid((ncols + QR_NB - 1) / QR_NB, 1, lc.nb);
+        if (w.apply_hooks) w.apply_hooks->begin(w.apply_hooks->user);
+        if (reg) {
+            const cplx* V2 = p2 >= 0 ? Vat(p2, rb) : nullptr;
+            const cplx* T2 = p2 >= 0 ? Tneg(p2) : nullptr;
+            const int nb2 = p2 >= 0 ? nbof(p2) : 0;
+            if (transT) hipLaunchKernelGGL((k_qr_apply_reg<true>), grid, dim3(256), 0, lc.st, Vat(p1, rb), Tneg(p1), nbof(p1), V2, T2, nb2, n, C, n, rows, ncols, lc.cs);
+            else        hipLaunchKernelGGL((k_qr_apply_reg<false>), grid, dim3(256), 0, lc.st, Vat(p1, rb), Tneg(p1), nbof(p1), V2, T2, nb2, n, C, n, rows, ncols, lc.cs);
+        } else {
+            if (transT) hipLaunchKernelGGL((k_qr_apply<true>), grid, dim3(256), 0, lc.st, Vat(p1, rb), n, Tneg(p1), C, n, rows, ncols, nbof(p1), lc.cs);
+            else        hipLaunchKernelGGL((k_qr_apply<false>), grid, dim3(256), 0, lc.st, Vat(p1, rb), n, Tneg(p1), C, n, rows, ncols, nbof(p1), lc.cs);
+        }
+        if (w.apply_hooks) w.apply_hooks->end(w.apply_hooks->user, 1);
         ++launches;
-        const int rows = n - j0, ntrail = n - j0 - nb;
-        if (ntrail > 0) {
-            const cplx* Vp = w.V + (size_t)j0 * n + j0;
-            cplx* C = A + (size_t)(j0 + nb) * n + j0;
-            // apply Q_p^H = I - V T^H V^H to the trailing columns
-            if (w.apply_hooks) w.apply_hooks->begin(w.apply_hooks->user);
-            if (rows <= 512)
-                hipLaunchKernelGGL((k_qr_apply_reg<true>), dim3((ntrail + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ntrail, nb, lc.cs);
-            else
-                hipLaunchKernelGGL((k_qr_apply<true>), dim3((ntrail + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ntrail, nb, lc.cs);
-            if (w.apply_hooks) w.apply_hooks->end(w.apply_hooks->user, 1);
-            launches += 1;
+    };
+    auto panel = [&](int p) {
+        cplx* Tp = w.T + (size_t)p * 2 * QR_NB * QR_NB;
+        launch_panel(lc, A, n, p * QR_NB, w.V, Tp, Tp + QR_NB * QR_NB);
+        ++launches;
+    };
+    // ---- factorisation: Q_p^H = I - V T^H V^H applied to the trailing columns ----
+    for (int p = 0; p < np;) {
+        const int j0 = p * QR_NB;
+        panel(p);
+        const int ntrail = n - j0 - nbof(p);
+        if (ntrail <= 0) break;
+        const bool pair = reg && p + 1 < np && nbof(p + 1) == QR_NB && n - j0 - 2 * QR_NB > 0;
+        if (!pair) {
+            apply(true, A, p, j0 + QR_NB, ntrail, p, -1);
+            p += 1;
+        } else {
+            apply(true, A, p, j0 + QR_NB, QR_NB, p, -1);                       // only the columns of the next panel
+            panel(p + 1);
+            apply(true, A, p, j0 + 2 * QR_NB, n - j0 - 2 * QR_NB, p, p + 1);   // both reflectors, one pass over the rest
+            p += 2;
         }
     }
-    // ---- Q = H_0 H_1 ... applied to the identity, block reflectors in reverse order (zungqr) ----
+    // ---- Q = H_0 H_1 ... applied to the identity, block reflectors in reverse order (zungqr): C <- (I - V T V^H) C ----
     launch_set_identity(lc, Q, n);
     ++launches;
-    for (int p = np - 1; p >= 0; --p) {
-        const int j0 = p * QR_NB;
-        const int nb = (n - j0 < QR_NB) ? (n - j0) : QR_NB;
-        const int rows = n - j0, ncols = n - j0;
-        const cplx* Vp = w.V + (size_t)j0 * n + j0;
-        const cplx* Tn = w.T + (size_t)p * 2 * QR_NB * QR_NB + QR_NB * QR_NB;
-        cplx* C = Q + (size_t)j0 * n + j0;
-        // C <- (I - V T V^H) C
-        if (w.apply_hooks) w.apply_hooks->begin(w.apply_hooks->user);
-        if (rows <= 512)
-            hipLaunchKernelGGL((k_qr_apply_reg<false>), dim3((ncols + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ncols, nb, lc.cs);
-        else
-            hipLaunchKernelGGL((k_qr_apply<false>), dim3((ncols + QR_NB - 1) / QR_NB, 1, lc.nb), dim3(256), 0, lc.st, Vp, n, Tn, C, n, rows, ncols, nb, lc.cs);
-        if (w.apply_hooks) w.apply_hooks->end(w.apply_hooks->user, 1);
-        launches += 1;
+    for (int p = np - 1; p >= 0;) {
+        if (reg && p >= 1 && nbof(p) == QR_NB) {
+            apply(false, Q, p - 1, (p - 1) * QR_NB, n - (p - 1) * QR_NB, p, p - 1);   // H_p first, then H_{p-1}
+            p -= 2;
+        } else {
+            apply(false, Q, p, p * QR_NB, n - p * QR_NB, p, -1);
+            p -= 1;
+        }
     }
     return launches;
 }
