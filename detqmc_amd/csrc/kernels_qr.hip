@@ -369,14 +369,14 @@ __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, i
 // c0 + l15], which is at once the B fragment of pass 1 (k = row, n = column) and the accumulator layout of pass 2
 // (m = row = l4 + 4 r, n = column) -- so C is read once and written once instead of read twice, and pass 1 needs no
 // LDS staging or barrier per chunk.  V comes from global memory (all workgroups of a chain read the same panel: L2).
+#define QR_MAXREF 4
+struct QrRefs { const cplx* V[QR_MAXREF]; const cplx* Tn[QR_MAXREF]; int nb[QR_MAXREF]; int n; };
 template<bool TRANS_T>
-__global__ __launch_bounds__(256) void k_qr_apply_reg(const cplx* __restrict__ V1, const cplx* __restrict__ T1n, int nb1,
-                                                       const cplx* __restrict__ V2, const cplx* __restrict__ T2n, int nb2,
-                                                       int ldv, cplx* __restrict__ C, int ldc, int rows, int ncols, size_t cs) {
+__global__ __launch_bounds__(256) void k_qr_apply_reg(QrRefs refs, int ldv, cplx* __restrict__ C, int ldc, int rows, int ncols, size_t cs) {
     __shared__ cplx sW[QR_NB][QR_NB + 1];      // W, then W2, as [k][j]
     __shared__ cplx sT[QR_NB][QR_NB + 1];      // -T as [i][k]
     __shared__ cplx sPart[4][QR_NB][QR_NB + 1];
-    CHAIN(V1); CHAIN(T1n); CHAIN(V2); CHAIN(T2n); CHAIN(C);
+    CHAIN(C);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int c0 = blockIdx.x * QR_NB;
@@ -392,15 +392,14 @@ __global__ __launch_bounds__(256) void k_qr_apply_reg(const cplx* __restrict__ V
         const int row = slab + 4 * e + l4;
         creg[e] = (e < ne && cok && row < rows) ? Ccol[row] : make_double2(0.0, 0.0);
     }
-    // Up to two block reflectors are applied one after the other while C stays in registers (the second one is the
-    // next panel's, whose rows above its own first row are zero in V): the trailing matrix is then read and written
-    // once per PAIR of panels.
+    // Up to four block reflectors are applied one after the other while C stays in registers (the later ones are the
+    // next panels', whose rows above their own first row are zero in V): the trailing matrix is then read and written
+    // once per GROUP of panels.
     const int wi = tid & 15, wj = tid >> 4;
-    for (int rf = 0; rf < 2; ++rf) {
-        const cplx* Vp = rf == 0 ? V1 : V2;
-        const cplx* Tn = rf == 0 ? T1n : T2n;
-        const int nb = rf == 0 ? nb1 : nb2;
-        if (nb <= 0) break;
+    for (int rf = 0; rf < refs.n; ++rf) {
+        const cplx* Vp = chain_ptr(refs.V[rf], cs);
+        const cplx* Tn = chain_ptr(refs.Tn[rf], cs);
+        const int nb = refs.nb[rf];
         __syncthreads();                            // sT / sW / sPart of the previous reflector are no longer read
         sT[wi][wj] = (wi < nb && wj < nb) ? Tn[wj * QR_NB + wi] : make_double2(0.0, 0.0);
         const cplx* Vcol = Vp + (size_t)l15 * ldv;
@@ -504,25 +503,27 @@ static void launch_panel(const Launch& lc, cplx* A, int n, int j0, cplx* V, cplx
 int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
     int launches = 0;
     const int np = (n + QR_NB - 1) / QR_NB;
-    const bool reg = n <= 512;                          // register-resident update kernel, panels applied in pairs
+    const bool reg = n <= 512;                          // register-resident update kernel, panels applied in groups
     auto Tneg = [&](int p) { return w.T + (size_t)p * 2 * QR_NB * QR_NB + QR_NB * QR_NB; };
     auto Vat = [&](int pcol, int prow) { return w.V + (size_t)(pcol * QR_NB) * n + prow * QR_NB; };   // panel pcol's V from row block prow
     auto nbof = [&](int p) { return (n - p * QR_NB < QR_NB) ? (n - p * QR_NB) : QR_NB; };
-    // block reflector(s) p1 (then p2, < 0: none) applied to ncols columns of M starting at column block cb, rows from block rb
-    auto apply = [&](bool transT, cplx* M, int rb, int cb_col0, int ncols, int p1, int p2) {
+    // the block reflectors of panels p0, p0 + step, ... (count of them, in that order) applied to ncols columns of M
+    // starting at column col0, rows from row block rb (the first row of the lowest-numbered panel involved)
+    auto apply = [&](bool transT, cplx* M, int rb, int col0, int ncols, int p0, int step, int count) {
         const int rows = n - rb * QR_NB;
-        cplx* C = M + (size_t)cb_col0 * n + rb * QR_NB;
+        cplx* C = M + (size_t)col0 * n + rb * QR_NB;
         const dim3 grid((ncols + QR_NB - 1) / QR_NB, 1, lc.nb);
         if (w.apply_hooks) w.apply_hooks->begin(w.apply_hooks->user);
         if (reg) {
-            const cplx* V2 = p2 >= 0 ? Vat(p2, rb) : nullptr;
-            const cplx* T2 = p2 >= 0 ? Tneg(p2) : nullptr;
-            const int nb2 = p2 >= 0 ? nbof(p2) : 0;
-            if (transT) hipLaunchKernelGGL((k_qr_apply_reg<true>), grid, dim3(256), 0, lc.st, Vat(p1, rb), Tneg(p1), nbof(p1), V2, T2, nb2, n, C, n, rows, ncols, lc.cs);
-            else        hipLaunchKernelGGL((k_qr_apply_reg<false>), grid, dim3(256), 0, lc.st, Vat(p1, rb), Tneg(p1), nbof(p1), V2, T2, nb2, n, C, n, rows, ncols, lc.cs);
+            QrRefs r;
+            r.n = count;
+            for (int i = 0; i < QR_MAXREF; ++i) { r.V[i] = nullptr; r.Tn[i] = nullptr; r.nb[i] = 0; }
+            for (int i = 0; i < count; ++i) { const int p = p0 + i * step; r.V[i] = Vat(p, rb); r.Tn[i] = Tneg(p); r.nb[i] = nbof(p); }
+            if (transT) hipLaunchKernelGGL((k_qr_apply_reg<true>), grid, dim3(256), 0, lc.st, r, n, C, n, rows, ncols, lc.cs);
+            else        hipLaunchKernelGGL((k_qr_apply_reg<false>), grid, dim3(256), 0, lc.st, r, n, C, n, rows, ncols, lc.cs);
         } else {
-            if (transT) hipLaunchKernelGGL((k_qr_apply<true>), grid, dim3(256), 0, lc.st, Vat(p1, rb), n, Tneg(p1), C, n, rows, ncols, nbof(p1), lc.cs);
-            else        hipLaunchKernelGGL((k_qr_apply<false>), grid, dim3(256), 0, lc.st, Vat(p1, rb), n, Tneg(p1), C, n, rows, ncols, nbof(p1), lc.cs);
+            if (transT) hipLaunchKernelGGL((k_qr_apply<true>), grid, dim3(256), 0, lc.st, Vat(p0, rb), n, Tneg(p0), C, n, rows, ncols, nbof(p0), lc.cs);
+            else        hipLaunchKernelGGL((k_qr_apply<false>), grid, dim3(256), 0, lc.st, Vat(p0, rb), n, Tneg(p0), C, n, rows, ncols, nbof(p0), lc.cs);
         }
         if (w.apply_hooks) w.apply_hooks->end(w.apply_hooks->user, 1);
         ++launches;
@@ -532,34 +533,44 @@ int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
         launch_panel(lc, A, n, p * QR_NB, w.V, Tp, Tp + QR_NB * QR_NB);
         ++launches;
     };
-    // ---- factorisation: Q_p^H = I - V T^H V^H applied to the trailing columns ----
+    // ---- factorisation: Q_p^H = I - V T^H V^H applied to the trailing columns.  Groups of 4 (or 2) full panels: the
+    //      columns of the group's later panels are brought up to date by small launches (look-ahead), the rest of the
+    //      trailing matrix sees all reflectors of the group in ONE pass. ----
     for (int p = 0; p < np;) {
         const int j0 = p * QR_NB;
-        panel(p);
-        const int ntrail = n - j0 - nbof(p);
-        if (ntrail <= 0) break;
-        const bool pair = reg && p + 1 < np && nbof(p + 1) == QR_NB && n - j0 - 2 * QR_NB > 0;
-        if (!pair) {
-            apply(true, A, p, j0 + QR_NB, ntrail, p, -1);
-            p += 1;
-        } else {
-            apply(true, A, p, j0 + QR_NB, QR_NB, p, -1);                       // only the columns of the next panel
+        const int left = n - j0;                                  // columns from this panel on
+        if (reg && left > 4 * QR_NB) {                            // p .. p+3 are full and something remains after them
+            panel(p);
+            apply(true, A, p, j0 + QR_NB, QR_NB, p, 1, 1);                     // -> columns of p+1
             panel(p + 1);
-            apply(true, A, p, j0 + 2 * QR_NB, n - j0 - 2 * QR_NB, p, p + 1);   // both reflectors, one pass over the rest
+            apply(true, A, p, j0 + 2 * QR_NB, 2 * QR_NB, p, 1, 2);             // -> columns of p+2, p+3
+            panel(p + 2);
+            apply(true, A, p + 2, j0 + 3 * QR_NB, QR_NB, p + 2, 1, 1);         // -> columns of p+3
+            panel(p + 3);
+            apply(true, A, p, j0 + 4 * QR_NB, left - 4 * QR_NB, p, 1, 4);      // -> everything behind the group
+            p += 4;
+        } else if (reg && left > 2 * QR_NB) {
+            panel(p);
+            apply(true, A, p, j0 + QR_NB, QR_NB, p, 1, 1);
+            panel(p + 1);
+            apply(true, A, p, j0 + 2 * QR_NB, left - 2 * QR_NB, p, 1, 2);
             p += 2;
+        } else {
+            panel(p);
+            const int ntrail = left - nbof(p);
+            if (ntrail > 0) apply(true, A, p, j0 + nbof(p), ntrail, p, 1, 1);
+            p += 1;
         }
     }
     // ---- Q = H_0 H_1 ... applied to the identity, block reflectors in reverse order (zungqr): C <- (I - V T V^H) C ----
     launch_set_identity(lc, Q, n);
     ++launches;
     for (int p = np - 1; p >= 0;) {
-        if (reg && p >= 1 && nbof(p) == QR_NB) {
-            apply(false, Q, p - 1, (p - 1) * QR_NB, n - (p - 1) * QR_NB, p, p - 1);   // H_p first, then H_{p-1}
-            p -= 2;
-        } else {
-            apply(false, Q, p, p * QR_NB, n - p * QR_NB, p, -1);
-            p -= 1;
-        }
+        int cnt = 1;
+        if (reg && nbof(p) == QR_NB) cnt = (p >= 3) ? 4 : (p >= 1 ? 2 : 1);
+        const int lo = p - (cnt - 1);                             // H_p first, ..., H_lo last; rows / columns from block lo
+        apply(false, Q, lo, lo * QR_NB, n - lo * QR_NB, p, -1, cnt);
+        p -= cnt;
     }
     return launches;
 }
