@@ -59,7 +59,9 @@ class detsdw_params(C.Structure):
                 ("txhor", C.c_double), ("txver", C.c_double), ("tyhor", C.c_double), ("tyver", C.c_double),
                 ("mu", C.c_double), ("mux", C.c_double), ("muy", C.c_double),
                 ("accRatio", C.c_double), ("cdwU", C.c_double),
-                ("stabilisation", C.c_int32), ("cb_none", C.c_int32)]
+                ("stabilisation", C.c_int32), ("cb_none", C.c_int32),
+                ("wolffClusterUpdate", C.c_int32), ("wolffClusterShiftUpdate", C.c_int32),
+                ("repeatWolffPerSweep", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class detsdw_info(C.Structure):
@@ -68,6 +70,9 @@ class detsdw_info(C.Structure):
                 ("performedSweeps", C.c_int32), ("lastSweepDir", C.c_int32),
                 ("acceptedGlobalShifts", C.c_int32), ("attemptedGlobalShifts", C.c_int32),
                 ("currentTimeslice", C.c_int32), ("reserved", C.c_int32),
+                ("acceptedWolffClusterUpdates", C.c_int32), ("attemptedWolffClusterUpdates", C.c_int32),
+                ("acceptedWolffClusterShiftUpdates", C.c_int32), ("attemptedWolffClusterShiftUpdates", C.c_int32),
+                ("addedWolffClusterSize", C.c_double),
                 ("beta", C.c_double), ("dtau", C.c_double),
                 ("phiDelta", C.c_double), ("lastAccRatioLocal_phi", C.c_double), ("r", C.c_double),
                 ("rngDrawn", C.c_uint64)]
@@ -75,6 +80,9 @@ class detsdw_info(C.Structure):
 
 class detsdw_control_data(C.Structure):
     _fields_ = [("acceptedGlobalShifts", C.c_int32), ("attemptedGlobalShifts", C.c_int32),
+                ("acceptedWolffClusterUpdates", C.c_int32), ("attemptedWolffClusterUpdates", C.c_int32),
+                ("acceptedWolffClusterShiftUpdates", C.c_int32), ("attemptedWolffClusterShiftUpdates", C.c_int32),
+                ("addedWolffClusterSize", C.c_double),
                 ("adjust", dqmc_update_state)]
 
 

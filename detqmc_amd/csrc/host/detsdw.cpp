@@ -51,7 +51,12 @@ void DetSDW::normalise(detsdw_params& p, int& bcv) {
     const int N = p.L * p.L;
     if (p.updateMethod == 2 && (p.delaySteps <= 0 || p.delaySteps > N))
         throw ParameterWrong("Parameter delaySteps has incorrect value");
-    if (p.globalShift && p.globalUpdateInterval == 0) throw ParameterWrong("Parameter globalUpdateInterval has incorrect value");
+    if (p.repeatWolffPerSweep == 0) p.repeatWolffPerSweep = 1;
+    if ((p.globalShift || p.wolffClusterUpdate || p.wolffClusterShiftUpdate) && p.globalUpdateInterval == 0)
+        throw ParameterWrong("Parameter globalUpdateInterval has incorrect value");                      // detsdwparams.cpp:89-93
+    if (p.wolffClusterShiftUpdate && (p.globalShift || p.wolffClusterUpdate))
+        throw ParameterWrong("Either use combined wolffClusterShiftUpdate or individual global updates");   // :94-96
+    if (p.repeatWolffPerSweep < 1) throw ParameterWrong("Parameter repeatWolffPerSweep has incorrect value");
     if (p.L % 2 != 0) throw ParameterWrong("Checker board decomposition only supported for even linear lattice sizes");
     if (p.cdwU != 0.0) throw ParameterWrong("cdwU != 0 is not supported by this build");
     if (p.stabilisation != 0 && p.stabilisation != 1) throw ParameterWrong("Parameter stabilisation has incorrect value");
@@ -197,11 +202,15 @@ void DetSDW::sweep_skeleton(bool thermalization) {
 void DetSDW::sweep(bool /*takeMeasurements*/) { sweep_skeleton(false); }
 void DetSDW::sweepThermalization() { sweep_skeleton(true); }
 
-// detsdwopdim.cpp:3461-3486 -- all chains of a batch attempt their global move in the same sweep
+// detsdwopdim.cpp:3461-3486 -- all chains of a batch attempt their global moves in the same sweep, in the reference's
+// order: shift, Wolff cluster, combined cluster + shift
 void DetSDW::globalMove() {
     const detsdw_params& p = ch_[0].pars;
-    if (p.globalShift && p.globalUpdateInterval > 0 && performedSweeps_ % p.globalUpdateInterval == 0)
-        attemptGlobalShiftMove();
+    if (p.globalUpdateInterval > 0 && performedSweeps_ % p.globalUpdateInterval == 0) {
+        if (p.globalShift) attemptGlobalMove(MoveShift);
+        if (p.wolffClusterUpdate) attemptGlobalMove(MoveWolff);
+        if (p.wolffClusterShiftUpdate) attemptGlobalMove(MoveWolffShift);
+    }
 }
 
 void DetSDW::syncPhiFromDevice(int b) {
@@ -245,12 +254,90 @@ double DetSDW::phiAction(const Chain& ch) const {
     return action;
 }
 
-// detsdwopdim.cpp:3565-3644, for every chain of the batch: the proposal of each chain is drawn from its own
-// RNG stream, the UdV storage / G of all chains are rebuilt by ONE batched setup, then each chain accepts or
-// restores on its own.
-void DetSDW::attemptGlobalShiftMove() {
+// addGlobalRandomDisplacement (:3755-3763): all slices (incl. the unused slice 0) shifted
+void DetSDW::addGlobalRandomDisplacement(Chain& c) {
+    for (int dim = 0; dim < opdim_; ++dim) {
+        const double rr = c.rng.randRange(-c.phiDelta, +c.phiDelta);
+        for (int k = 0; k <= m_; ++k)
+            for (int site = 0; site < N_; ++site) c.phi[phiIdx(site, dim, k)] += rr;
+    }
+}
+
+// arma::dot on the OPDIM-vectors (op_dot::direct_dot_arma: two accumulators over even / odd elements)
+static inline double adot(const double* a, const double* b, int n) {
+    double v1 = 0.0, v2 = 0.0;
+    int i = 0;
+    for (; i + 1 < n; i += 2) { v1 += a[i] * b[i]; v2 += a[i + 1] * b[i + 1]; }
+    if (i < n) v1 += a[i] * b[i];
+    return v1 + v2;
+}
+
+// buildAndFlipCluster with randomDirection<OPDIM> (detsdwopdim.cpp:3765-3883): Wolff single cluster over the
+// (site, time slice) lattice, reflection phi -> phi - 2 (phi . rd) rd; works on the host mirror of the field
+unsigned DetSDW::buildAndFlipCluster(Chain& c) {
+    const int L = c.pars.L;
+    const double dtau = c.pars.dtau;
+    double rd[3] = {0.0, 0.0, 0.0};
+    if (opdim_ == 1) rd[0] = (c.rng.rand01() <= 0.5) ? -1.0 : +1.0;
+    else if (opdim_ == 2) c.rng.randPointOnCircle(rd[0], rd[1]);
+    else c.rng.randPointOnSphere(rd[0], rd[1], rd[2]);
+    auto getPhi = [&](int site, int k, double* out) { for (int d = 0; d < opdim_; ++d) out[d] = c.phi[phiIdx(site, d, k)]; };
+    auto projected = [&](int site, int k) { double ph[3]; getPhi(site, k, ph); return adot(ph, rd, opdim_); };
+    auto flip = [&](int site, int k) {
+        double ph[3];
+        getPhi(site, k, ph);
+        const double f = 2. * adot(ph, rd, opdim_);
+        for (int d = 0; d < opdim_; ++d) c.phi[phiIdx(site, d, k)] = ph[d] - f * rd[d];
+    };
+    std::vector<char> visited((size_t)N_ * (m_ + 1), 0);
+    std::vector<std::pair<int, int>> next_sites;                      // std::stack in the reference
+    int timeslice = c.rng.randInt(1, m_);
+    int site = c.rng.randInt(0, N_ - 1);
+    flip(site, timeslice);
+    visited[(size_t)timeslice * N_ + site] = 1;
+    next_sites.push_back({site, timeslice});
+    unsigned cluster_size = 1;
+    do {
+        site = next_sites.back().first; timeslice = next_sites.back().second;
+        next_sites.pop_back();
+        const int x = site % L, y = site / L;
+        const int nb[4] = {y * L + (x + 1) % L, y * L + (x - 1 + L) % L, ((y + 1) % L) * L + x, ((y - 1 + L) % L) * L + x};
+        for (int d = 0; d < 4; ++d) {                                 // XPLUS, XMINUS, YPLUS, YMINUS
+            const int ns = nb[d];
+            if (!visited[(size_t)timeslice * N_ + ns]) {
+                const double bond_arg = 2. * dtau * projected(site, timeslice) * projected(ns, timeslice);
+                if (bond_arg < 0 && c.rng.rand01() <= (1. - std::exp(bond_arg))) {
+                    flip(ns, timeslice);
+                    visited[(size_t)timeslice * N_ + ns] = 1;
+                    next_sites.push_back({ns, timeslice});
+                    ++cluster_size;
+                }
+            }
+        }
+        const int tn[2] = {timeslice < m_ ? timeslice + 1 : 1, timeslice > 1 ? timeslice - 1 : m_};   // ChainDir PLUS, MINUS
+        for (int t = 0; t < 2; ++t) {
+            const int nt = tn[t];
+            if (!visited[(size_t)nt * N_ + site]) {
+                const double bond_arg = (2. / dtau) * projected(site, timeslice) * projected(site, nt);
+                if (bond_arg < 0 && c.rng.rand01() <= (1. - std::exp(bond_arg))) {
+                    flip(site, nt);
+                    visited[(size_t)nt * N_ + site] = 1;
+                    next_sites.push_back({site, nt});
+                    ++cluster_size;
+                }
+            }
+        }
+    } while (!next_sites.empty());
+    return cluster_size;
+}
+
+// attemptGlobalShiftMove (detsdwopdim.cpp:3565-3644), attemptWolffClusterUpdate (:3488-3562),
+// attemptWolffClusterShiftUpdate (:3647-3751) for every chain of the batch: the proposal of each chain is drawn from
+// its own RNG stream on the host mirror of its field, the UdV storage / G of all chains are rebuilt by ONE batched
+// set-up, then each chain accepts or restores on its own.
+void DetSDW::attemptGlobalMove(GlobalMoveKind kind) {
     const int nb = (int)ch_.size();
-    std::vector<double> old_action(nb), old_sv((size_t)nb * ng_), new_sv(ng_);
+    std::vector<double> prob_scalar(nb, 1.0), old_sv((size_t)nb * ng_), new_sv(ng_), added(nb, 0.0);
     std::vector<std::vector<double>> phi_backup(nb);
     for (int b = 0; b < nb; ++b) {
         Chain& c = ch_[b];
@@ -258,18 +345,19 @@ void DetSDW::attemptGlobalShiftMove() {
         dqmc_update_state st;
         check(dqmc_get_update_state_host(ctx_, &st), "dqmc_get_update_state_host");
         c.phiDelta = st.phiDelta;
-        old_action[b] = phiAction(c);
         check(dqmc_get_sv_host(ctx_, &old_sv[(size_t)b * ng_]), "dqmc_get_sv_host");
     }
     check(dqmc_backup(ctx_), "globalMoveStoreBackups");
     for (int b = 0; b < nb; ++b) {
         Chain& c = ch_[b];
         phi_backup[b] = c.phi;
-        // addGlobalRandomDisplacement (:3755-3763): all slices (incl. the unused slice 0) shifted
-        for (int dim = 0; dim < opdim_; ++dim) {
-            const double rr = c.rng.randRange(-c.phiDelta, +c.phiDelta);
-            for (int k = 0; k <= m_; ++k)
-                for (int site = 0; site < N_; ++site) c.phi[phiIdx(site, dim, k)] += rr;
+        if (kind != MoveShift)
+            for (int r = 0; r < c.pars.repeatWolffPerSweep; ++r) added[b] += (double)buildAndFlipCluster(c);
+        if (kind != MoveWolff) {
+            const double old_scalar_action = phiAction(c);            // for the combined move: after the cluster flips
+            addGlobalRandomDisplacement(c);
+            const double new_scalar_action = phiAction(c);
+            prob_scalar[b] = std::exp(-(new_scalar_action - old_scalar_action));
         }
         select(b);
         check(dqmc_set_fields_host(ctx_, c.phi.data()), "updateCoshSinhTermsPhi");
@@ -277,18 +365,21 @@ void DetSDW::attemptGlobalShiftMove() {
     setupUdVStorage_and_calculateGreen();
     for (int b = 0; b < nb; ++b) {
         Chain& c = ch_[b];
-        const double new_scalar_action = phiAction(c);
-        const double prob_scalar = std::exp(-(new_scalar_action - old_action[b]));
         select(b);
         check(dqmc_get_sv_host(ctx_, new_sv.data()), "dqmc_get_sv_host");
         double log_prob = 0.0;
         for (int j = 0; j < ng_; ++j) log_prob += std::log(new_sv[j]) - std::log(old_sv[(size_t)b * ng_ + j]);
         double prob_fermion = std::exp(log_prob);
         if (opdim_ < 3) prob_fermion = prob_fermion * prob_fermion;
-        const double prob = prob_scalar * prob_fermion;
-        c.attemptedGlobalShifts += 1;
+        const double prob = (kind == MoveWolff) ? prob_fermion : prob_scalar[b] * prob_fermion;
+        int& attempted = kind == MoveShift ? c.attemptedGlobalShifts : kind == MoveWolff ? c.attemptedWolffClusterUpdates
+                                                                                          : c.attemptedWolffClusterShiftUpdates;
+        int& accepted = kind == MoveShift ? c.acceptedGlobalShifts : kind == MoveWolff ? c.acceptedWolffClusterUpdates
+                                                                                        : c.acceptedWolffClusterShiftUpdates;
+        attempted += 1;
         if (prob >= 1.0 || c.rng.rand01() < prob) {
-            c.acceptedGlobalShifts += 1;
+            accepted += 1;
+            c.addedWolffClusterSize += added[b];
         } else {
             check(dqmc_restore(ctx_), "globalMoveRestoreBackups");
             c.phi = phi_backup[b];
@@ -311,12 +402,22 @@ void DetSDW::get_control_data(detsdw_control_data& out, int b) {
     select(b);
     out.acceptedGlobalShifts = ch_[b].acceptedGlobalShifts;
     out.attemptedGlobalShifts = ch_[b].attemptedGlobalShifts;
+    out.acceptedWolffClusterUpdates = ch_[b].acceptedWolffClusterUpdates;
+    out.attemptedWolffClusterUpdates = ch_[b].attemptedWolffClusterUpdates;
+    out.acceptedWolffClusterShiftUpdates = ch_[b].acceptedWolffClusterShiftUpdates;
+    out.attemptedWolffClusterShiftUpdates = ch_[b].attemptedWolffClusterShiftUpdates;
+    out.addedWolffClusterSize = ch_[b].addedWolffClusterSize;
     check(dqmc_get_update_state_host(ctx_, &out.adjust), "get_control_data");
 }
 void DetSDW::set_control_data(const detsdw_control_data& in, int b) {
     select(b);
     ch_[b].acceptedGlobalShifts = in.acceptedGlobalShifts;
     ch_[b].attemptedGlobalShifts = in.attemptedGlobalShifts;
+    ch_[b].acceptedWolffClusterUpdates = in.acceptedWolffClusterUpdates;
+    ch_[b].attemptedWolffClusterUpdates = in.attemptedWolffClusterUpdates;
+    ch_[b].acceptedWolffClusterShiftUpdates = in.acceptedWolffClusterShiftUpdates;
+    ch_[b].attemptedWolffClusterShiftUpdates = in.attemptedWolffClusterShiftUpdates;
+    ch_[b].addedWolffClusterSize = in.addedWolffClusterSize;
     dqmc_update_state st = in.adjust;
     st.rng_consumed = 0; st.rng_avail = 0; st.error = 0;      // the RNG window is per replica, never exchanged
     check(dqmc_set_update_state_host(ctx_, &st), "set_control_data");
@@ -331,6 +432,10 @@ void DetSDW::getInfo(detsdw_info& o, int b) {
     o.opdim = opdim_; o.L = c.pars.L; o.N = N_; o.MSF = MSF_; o.n_g = ng_; o.m = m_; o.s = s_; o.n = n_;
     o.performedSweeps = performedSweeps_; o.lastSweepDir = (int)lastSweepDir_;
     o.acceptedGlobalShifts = c.acceptedGlobalShifts; o.attemptedGlobalShifts = c.attemptedGlobalShifts;
+    o.acceptedWolffClusterUpdates = c.acceptedWolffClusterUpdates; o.attemptedWolffClusterUpdates = c.attemptedWolffClusterUpdates;
+    o.acceptedWolffClusterShiftUpdates = c.acceptedWolffClusterShiftUpdates;
+    o.attemptedWolffClusterShiftUpdates = c.attemptedWolffClusterShiftUpdates;
+    o.addedWolffClusterSize = c.addedWolffClusterSize;
     o.currentTimeslice = dqmc_current_timeslice(ctx_);
     o.beta = c.pars.beta; o.dtau = c.pars.dtau; o.phiDelta = c.phiDelta; o.lastAccRatioLocal_phi = c.lastAccRatio;
     o.r = c.pars.r; o.rngDrawn = c.rng.drawn();

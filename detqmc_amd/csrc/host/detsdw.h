@@ -59,7 +59,10 @@ private:
         detsdw_params pars;
         RngStream rng;
         std::vector<double> phi;               // host mirror, valid after syncPhiFromDevice(b)
-        int acceptedGlobalShifts = 0, attemptedGlobalShifts = 0;
+        int acceptedGlobalShifts = 0, attemptedGlobalShifts = 0;          // UpdateStatistics (detsdwopdim.h:285-311)
+        int acceptedWolffClusterUpdates = 0, attemptedWolffClusterUpdates = 0;
+        int acceptedWolffClusterShiftUpdates = 0, attemptedWolffClusterShiftUpdates = 0;
+        double addedWolffClusterSize = 0.0;
         double phiDelta = 0.5, lastAccRatio = 0.0;
         Chain(const detsdw_params& p) : pars(p), rng(p.rngSeed, (uint32_t)p.simindex + 1u) {}   // detqmc.h:181
     };
@@ -81,7 +84,10 @@ private:
     void beginLocalUpdates();
     void endLocalUpdates();
     void globalMove();
-    void attemptGlobalShiftMove();
+    enum GlobalMoveKind { MoveShift, MoveWolff, MoveWolffShift };
+    void attemptGlobalMove(GlobalMoveKind kind);
+    unsigned buildAndFlipCluster(Chain& c);
+    void addGlobalRandomDisplacement(Chain& c);
     double phiAction(const Chain& c) const;
     void syncPhiFromDevice(int b);
     size_t phiIdx(int site, int dim, int k) const { return (size_t)site + (size_t)N_ * (dim + (size_t)opdim_ * k); }

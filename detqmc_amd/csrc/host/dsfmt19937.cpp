@@ -1,4 +1,5 @@
 #include "dsfmt19937.h"
+#include <cmath>
 #include <cstring>
 
 namespace detqmc {
@@ -78,6 +79,20 @@ void RngStream::consume(size_t n) {
     drawn_ += n;
     pos_ += n;
     if (pos_ >= buf_.size()) { buf_.clear(); pos_ = 0; }
+}
+
+void RngStream::randPointOnCircle(double& x, double& y) {
+    const double phi = randRange(0., 2. * M_PI);
+    x = std::cos(phi);
+    y = std::sin(phi);
+}
+void RngStream::randPointOnSphere(double& x, double& y, double& z) {
+    const double phi = randRange(0., 2. * M_PI);
+    const double costheta = randRange(-1., 1.0);
+    const double sintheta = std::sqrt(1. - costheta * costheta);
+    x = std::cos(phi) * sintheta;
+    y = std::sin(phi) * sintheta;
+    z = costheta;
 }
 
 }  // namespace detqmc

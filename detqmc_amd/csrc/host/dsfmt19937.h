@@ -31,6 +31,9 @@ public:
     RngStream(uint32_t seed = 0, uint32_t processIndex = 0);
     double rand01();                                       // rngwrapper.h:54-57
     double randRange(double low, double high) { return low + (high - low) * rand01(); }
+    int randInt(int low, int high) { return low + static_cast<int>((high - low + 1.0) * rand01()); }   // rngwrapper.h:66-68
+    void randPointOnCircle(double& x, double& y);                                                   // rngwrapper.h:82-87
+    void randPointOnSphere(double& x, double& y, double& z);                                        // rngwrapper.h:70-80
     const double* peek(size_t n);                          // next n draws, not consumed
     void consume(size_t n);
     uint64_t drawn() const { return drawn_; }

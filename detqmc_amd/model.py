@@ -50,6 +50,9 @@ class SDWParams:
     bc: str = "pbc"
     weakZflux: bool = False
     globalShift: bool = False
+    wolffClusterUpdate: bool = False
+    wolffClusterShiftUpdate: bool = False
+    repeatWolffPerSweep: int = 1
     globalUpdateInterval: int = 100
     phi2bosons: bool = False
     cdwU: float = 0.0
@@ -263,7 +266,9 @@ def _host_params(pars: SDWParams):
         beta=pars.beta, dtau=pars.dtau, r=pars.r, c=pars.c, u=pars.u, lambda_=pars.lambda_,
         txhor=pars.txhor, txver=pars.txver, tyhor=pars.tyhor, tyver=pars.tyver,
         mu=pars.mu, mux=pars.mux or 0.0, muy=pars.muy or 0.0, accRatio=pars.accRatio, cdwU=pars.cdwU,
-        stabilisation=STABILISATION[pars.stabilisation], cb_none=int(not pars.checkerboard))
+        stabilisation=STABILISATION[pars.stabilisation], cb_none=int(not pars.checkerboard),
+        wolffClusterUpdate=int(pars.wolffClusterUpdate), wolffClusterShiftUpdate=int(pars.wolffClusterShiftUpdate),
+        repeatWolffPerSweep=int(pars.repeatWolffPerSweep))
 
 
 class DetSDW:

@@ -25,7 +25,7 @@ typedef struct detsdw_replica detsdw_replica;
 
 /* ModelParamsDetSDW (src/detsdwparams.h:24-120) + rngSeed/simindex of DetQMCParams
  * (src/detqmcparams.h) as far as the sweep path uses them.  Unsupported reference options
- * (cdwU != 0, turnoffFermions, rotate/scale proposals, Wolff cluster moves) are rejected by
+ * (cdwU != 0, turnoffFermions, rotate/scale proposals) are rejected by
  * detsdw_create with DQMC_EINVAL and a message naming the option. */
 typedef struct detsdw_params {
     int32_t opdim;
@@ -51,6 +51,10 @@ typedef struct detsdw_params {
     double cdwU;                 /* must be 0 */
     int32_t stabilisation;       /* 0 = SVD (as the reference), 1 = QR/UDT (same G to rounding, much faster) */
     int32_t cb_none;             /* 0 = checkerboard (default), 1 = checkerboard=false: dense B matrices (CB_NONE) */
+    int32_t wolffClusterUpdate;       /* attemptWolffClusterUpdate every globalUpdateInterval sweeps (detsdwopdim.cpp:3488-3562) */
+    int32_t wolffClusterShiftUpdate;  /* combined cluster + global shift (:3647-3751); excludes the two individual moves */
+    int32_t repeatWolffPerSweep;      /* cluster flips per attempt, 0 is read as 1 */
+    int32_t reserved3;
 } detsdw_params;
 
 typedef struct detsdw_info {
@@ -60,6 +64,9 @@ typedef struct detsdw_info {
     int32_t acceptedGlobalShifts, attemptedGlobalShifts;
     int32_t currentTimeslice;
     int32_t reserved;
+    int32_t acceptedWolffClusterUpdates, attemptedWolffClusterUpdates;
+    int32_t acceptedWolffClusterShiftUpdates, attemptedWolffClusterShiftUpdates;
+    double addedWolffClusterSize;
     double beta, dtau;
     double phiDelta, lastAccRatioLocal_phi;
     double r;                    /* exchange parameter */
@@ -70,6 +77,9 @@ typedef struct detsdw_info {
  * (src/detsdwopdim.cpp:5219-5247), fixed-size POD instead of a boost archive */
 typedef struct detsdw_control_data {
     int32_t acceptedGlobalShifts, attemptedGlobalShifts;
+    int32_t acceptedWolffClusterUpdates, attemptedWolffClusterUpdates;
+    int32_t acceptedWolffClusterShiftUpdates, attemptedWolffClusterShiftUpdates;
+    double addedWolffClusterSize;
     dqmc_update_state adjust;
 } detsdw_control_data;
 

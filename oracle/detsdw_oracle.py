@@ -50,6 +50,9 @@ class SDWParams:
     bc: str = "pbc"
     weakZflux: bool = False
     globalShift: bool = False
+    wolffClusterUpdate: bool = False
+    wolffClusterShiftUpdate: bool = False
+    repeatWolffPerSweep: int = 1
     globalUpdateInterval: int = 100
     phi2bosons: bool = False
     checkerboard: bool = True     # False = CB_NONE: dense B = e^{-dtau V} e^{-dtau K} (detsdwopdim.h:1305-1375)
@@ -80,8 +83,12 @@ class SDWParams:
         self.N = self.L * self.L
         if self.delaySteps <= 0 or self.delaySteps > self.N:
             raise ValueError("delaySteps")
-        if self.globalShift and self.globalUpdateInterval == 0:
-            raise ValueError("globalUpdateInterval")
+        if (self.globalShift or self.wolffClusterUpdate or self.wolffClusterShiftUpdate) and self.globalUpdateInterval == 0:
+            raise ValueError("globalUpdateInterval")            # detsdwparams.cpp:89-93
+        if self.wolffClusterShiftUpdate and (self.globalShift or self.wolffClusterUpdate):
+            raise ValueError("Either use combined wolffClusterShiftUpdate or individual global updates")   # :94-96
+        if self.repeatWolffPerSweep < 1:
+            raise ValueError("repeatWolffPerSweep")
         # createReplica (detsdwopdim.cpp:75-79)
         if self.mux is None or self.muy is None:
             self.mux = self.mu
@@ -176,6 +183,11 @@ class DetSDWOracle:
         self.accRatioLocal_box_RA = RunningAverage(self.AccRatioAdjustmentSamples)
         self.acceptedGlobalShifts = 0
         self.attemptedGlobalShifts = 0
+        self.acceptedWolffClusterUpdates = 0
+        self.attemptedWolffClusterUpdates = 0
+        self.acceptedWolffClusterShiftUpdates = 0
+        self.attemptedWolffClusterShiftUpdates = 0
+        self.addedWolffClusterSize = 0.0
         self.performedSweeps = 0
         self._setup_lattice()
         if phi is None:
@@ -726,8 +738,126 @@ class DetSDWOracle:
     def globalMove(self):
         """detsdwopdim.cpp:3461-3486."""
         p = self.pars
-        if self.performedSweeps % p.globalUpdateInterval == 0 and p.globalShift:
-            self.attemptGlobalShiftMove()
+        if self.performedSweeps % p.globalUpdateInterval == 0:
+            if p.globalShift:
+                self.attemptGlobalShiftMove()
+            if p.wolffClusterUpdate:
+                self.attemptWolffClusterUpdate()
+            if p.wolffClusterShiftUpdate:
+                self.attemptWolffClusterShiftUpdate()
+
+    def _fermion_ratio(self, old_sv):
+        log_prob = float(np.sum(np.log(self.g_inv_sv) - np.log(old_sv)))
+        prob_fermion = math.exp(log_prob)
+        if self.OPDIM < 3:
+            prob_fermion = prob_fermion ** 2
+        return prob_fermion
+
+    def _backup(self):
+        return (self.phi.copy(), self.coshTermPhi.copy(), self.sinhTermPhi.copy(), self.g, self.g_inv_sv,
+                self.UdVStorage)
+
+    def _restore(self, bak):
+        (self.phi, self.coshTermPhi, self.sinhTermPhi, self.g, self.g_inv_sv, self.UdVStorage) = bak
+
+    def buildAndFlipCluster(self):
+        """detsdwopdim.cpp:3806-3883 with randomDirection<OPDIM> (:3765-3803).  The cosh/sinh terms are refreshed
+        for the whole field by the callers here (the reference updates them site by site when asked to)."""
+        p, m, N, dtau = self.pars, self.m, self.N, self.dtau
+        if self.OPDIM == 1:
+            rd = np.array([-1.0 if self.rng.rand01() <= 0.5 else +1.0])
+        elif self.OPDIM == 2:
+            rd = np.array(self.rng.randPointOnCircle())
+        else:
+            rd = np.array(self.rng.randPointOnSphere())
+        phi = self.phi
+
+        def adot(a, b):
+            # arma::dot on short vectors (op_dot::direct_dot_arma): two accumulators over even / odd elements, no fma
+            v1 = v2 = 0.0
+            n = len(a)
+            i = 0
+            while i + 1 < n:
+                v1 += float(a[i]) * float(b[i])
+                v2 += float(a[i + 1]) * float(b[i + 1])
+                i += 2
+            if i < n:
+                v1 += float(a[i]) * float(b[i])
+            return v1 + v2
+
+        def projected(site, k):
+            return adot(phi[k, site], rd)
+
+        def flip(site, k):
+            ph = phi[k, site]
+            f = 2.0 * adot(ph, rd)
+            phi[k, site] = np.array([float(ph[d]) - f * float(rd[d]) for d in range(self.OPDIM)])
+
+        visited = np.zeros((N, m + 1), dtype=bool)
+        k = self.rng.randInt(1, m)
+        site = self.rng.randInt(0, N - 1)
+        flip(site, k)
+        visited[site, k] = True
+        stack = [(site, k)]
+        cluster_size = 1
+        while stack:
+            site, k = stack.pop()
+            for d in range(4):                                   # XPLUS, XMINUS, YPLUS, YMINUS
+                nb = int(self.neigh[d, site])
+                if not visited[nb, k]:
+                    bond_arg = 2.0 * dtau * projected(site, k) * projected(nb, k)
+                    if bond_arg < 0 and self.rng.rand01() <= (1.0 - math.exp(bond_arg)):
+                        flip(nb, k)
+                        visited[nb, k] = True
+                        stack.append((nb, k))
+                        cluster_size += 1
+            for kn in ((k + 1 if k < m else 1), (k - 1 if k > 1 else m)):      # ChainDir PLUS, MINUS over 1..m
+                if not visited[site, kn]:
+                    bond_arg = (2.0 / dtau) * projected(site, k) * projected(site, kn)
+                    if bond_arg < 0 and self.rng.rand01() <= (1.0 - math.exp(bond_arg)):
+                        flip(site, kn)
+                        visited[site, kn] = True
+                        stack.append((site, kn))
+                        cluster_size += 1
+        return cluster_size
+
+    def attemptWolffClusterUpdate(self):
+        """detsdwopdim.cpp:3488-3562."""
+        assert self.currentTimeslice == self.m
+        bak = self._backup()
+        old_sv = self.g_inv_sv
+        sizes = [self.buildAndFlipCluster() for _ in range(self.pars.repeatWolffPerSweep)]
+        self.updateCoshSinhTermsPhi()
+        self.setupUdVStorage_and_calculateGreen()
+        prob_fermion = self._fermion_ratio(old_sv)
+        self.attemptedWolffClusterUpdates += 1
+        if prob_fermion >= 1.0 or self.rng.rand01() < prob_fermion:
+            self.acceptedWolffClusterUpdates += 1
+            self.addedWolffClusterSize += float(sum(sizes))
+        else:
+            self._restore(bak)
+
+    def attemptWolffClusterShiftUpdate(self):
+        """detsdwopdim.cpp:3647-3751."""
+        assert self.currentTimeslice == self.m
+        bak = self._backup()
+        old_sv = self.g_inv_sv
+        sizes = [self.buildAndFlipCluster() for _ in range(self.pars.repeatWolffPerSweep)]
+        old_action = self.phiAction()                # after the cluster flips
+        for d in range(self.OPDIM):
+            rr = self.rng.randRange(-self.phiDelta, +self.phiDelta)
+            self.phi[:, :, d] += rr
+        new_action = self.phiAction()
+        prob_scalar = math.exp(-(new_action - old_action))
+        self.updateCoshSinhTermsPhi()
+        self.setupUdVStorage_and_calculateGreen()
+        prob = prob_scalar * self._fermion_ratio(old_sv)
+        self.attemptedWolffClusterShiftUpdates += 1
+        if prob >= 1.0 or self.rng.rand01() < prob:
+            self.acceptedWolffClusterShiftUpdates += 1
+            self.addedWolffClusterSize += float(sum(sizes))
+        else:
+            self._restore(bak)
 
     def attemptGlobalShiftMove(self):
         """detsdwopdim.cpp:3565-3644, backups :3886-3917, displacement :3755-3763."""

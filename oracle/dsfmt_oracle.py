@@ -118,3 +118,17 @@ class RngWrapper:
 
     def randInt(self, low, high):
         return low + int((high - low + 1.0) * self.rand01())
+
+    def randPointOnSphere(self):
+        """rngwrapper.h:70-80"""
+        import math
+        phi = self.randRange(0.0, 2.0 * math.pi)
+        costheta = self.randRange(-1.0, 1.0)
+        sintheta = math.sqrt(1.0 - costheta * costheta)
+        return (math.cos(phi) * sintheta, math.sin(phi) * sintheta, costheta)
+
+    def randPointOnCircle(self):
+        """rngwrapper.h:82-87"""
+        import math
+        phi = self.randRange(0.0, 2.0 * math.pi)
+        return (math.cos(phi), math.sin(phi))

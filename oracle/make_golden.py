@@ -31,6 +31,15 @@ CASES = {
                                  mux=-0.4, muy=-0.7, mu=-0.5, r=0.5, c=2.0, u=0.7)),
     "o2_L4_gshift": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=6, globalShift=1,
                                    globalUpdateInterval=2, sliceTrace=0)),
+    # Wolff cluster moves (a21): single cluster update, combined cluster + shift, all three order-parameter dimensions
+    "o2_L4_wolff": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=6, wolffClusterUpdate=1, globalShift=1,
+                                  globalUpdateInterval=1, repeatWolffPerSweep=2, sliceTrace=0)),
+    "o2_L4_wolffshift": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=6, wolffClusterShiftUpdate=1,
+                                       globalUpdateInterval=2, sliceTrace=0)),
+    "o1_L4_wolff": dict(args=dict(opdim=1, L=4, beta=2, s=10, delaySteps=6, sweeps=5, wolffClusterUpdate=1,
+                                  globalUpdateInterval=1, sliceTrace=0)),
+    "o3_L4_wolff": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=5, wolffClusterShiftUpdate=1,
+                                  globalUpdateInterval=1, sliceTrace=0)),
     "o2_L6_seed": dict(args=dict(opdim=2, L=6, beta=3, s=10, delaySteps=8, sweeps=2, rngSeed=5555, simindex=3)),
     # checkerboard=false (CB_NONE): dense B = e^{-dtau V} e^{-dtau K}, inverse by arma::inv
     "o2_L4_dense": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, checkerboard=0)),

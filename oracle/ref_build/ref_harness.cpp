@@ -153,8 +153,9 @@ static ModelParamsDetSDW make_params(const std::map<std::string, std::string>& k
     p.bc_string = gets(kv, "bc", "pbc"); p.specified.insert("bc");
     p.weakZflux = get<int>(kv, "weakZflux", 0) != 0; p.specified.insert("weakZflux");
     p.globalShift = get<int>(kv, "globalShift", 0) != 0; p.specified.insert("globalShift");
-    p.wolffClusterUpdate = false; p.specified.insert("wolffClusterUpdate");
-    p.wolffClusterShiftUpdate = false; p.specified.insert("wolffClusterShiftUpdate");
+    p.wolffClusterUpdate = get<int>(kv, "wolffClusterUpdate", 0) != 0; p.specified.insert("wolffClusterUpdate");
+    p.wolffClusterShiftUpdate = get<int>(kv, "wolffClusterShiftUpdate", 0) != 0; p.specified.insert("wolffClusterShiftUpdate");
+    p.repeatWolffPerSweep = get<uint32_t>(kv, "repeatWolffPerSweep", 1);
     p.turnoffFermionMeasurements = true; p.specified.insert("turnoffFermionMeasurements");
     p.phiFixed = get<int>(kv, "phiFixed", 0) != 0;
     return p;
@@ -178,6 +179,11 @@ static void dump_state(SDW& rep, const std::string& tag) {
     dump_scalar(tag + "_lastAccRatio", rep.ad.lastAccRatioLocal_phi);
     dump_scalar(tag + "_accGlobalShifts", rep.us.acceptedGlobalShifts);
     dump_scalar(tag + "_attGlobalShifts", rep.us.attemptedGlobalShifts);
+    dump_scalar(tag + "_accWolff", rep.us.acceptedWolffClusterUpdates);
+    dump_scalar(tag + "_attWolff", rep.us.attemptedWolffClusterUpdates);
+    dump_scalar(tag + "_accWolffShift", rep.us.acceptedWolffClusterShiftUpdates);
+    dump_scalar(tag + "_attWolffShift", rep.us.attemptedWolffClusterShiftUpdates);
+    dump_scalar(tag + "_addedWolffClusterSize", rep.us.addedWolffClusterSize);
 }
 
 template<class SDW>

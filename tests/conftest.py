@@ -40,6 +40,9 @@ def oracle_params(args):
     kw["weakZflux"] = bool(int(a.get("weakZflux", 0)))
     kw["globalShift"] = bool(int(a.get("globalShift", 0)))
     kw["checkerboard"] = bool(int(a.get("checkerboard", 1)))
+    kw["wolffClusterUpdate"] = bool(int(a.get("wolffClusterUpdate", 0)))
+    kw["wolffClusterShiftUpdate"] = bool(int(a.get("wolffClusterShiftUpdate", 0)))
+    kw["repeatWolffPerSweep"] = int(a.get("repeatWolffPerSweep", 1))
     kw["rngSeed"] = int(a.get("rngSeed", 1020304050))
     kw["simindex"] = int(a.get("simindex", 0))
     return SDWParams(**kw)

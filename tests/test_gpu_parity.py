@@ -35,6 +35,8 @@ def _sdw_params(a, **over):
               lambda_=op.lambda_, txhor=op.txhor, txver=op.txver, tyhor=op.tyhor, tyver=op.tyver, mu=op.mu,
               mux=op.mux, muy=op.muy, accRatio=op.accRatio, delaySteps=op.delaySteps, bc=op.bc,
               weakZflux=op.weakZflux, globalShift=op.globalShift, globalUpdateInterval=op.globalUpdateInterval,
+              wolffClusterUpdate=op.wolffClusterUpdate, wolffClusterShiftUpdate=op.wolffClusterShiftUpdate,
+              repeatWolffPerSweep=op.repeatWolffPerSweep,
               rngSeed=op.rngSeed, simindex=op.simindex, checkerboard=op.checkerboard)
     kw.update(over)
     return SDWParams(**kw)
@@ -478,7 +480,7 @@ def test_cold_and_large_o3_trajectories_vs_reference(name, stab):
 # batched chains: nb replicas in lockstep through one context (grid.z = chain)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("stab", ["svd", "qr"])
-@pytest.mark.parametrize("name", ["o2_L4_gshift", "o3_L4", "o2_L6_seed"])
+@pytest.mark.parametrize("name", ["o2_L4_gshift", "o3_L4", "o2_L6_seed", "o2_L4_wolff", "o3_L4_wolff"])
 def test_batched_chains_follow_the_single_replica_chains(name, stab):
     """Chain 0 of the batch has the fixture's parameters -> must reproduce the REFERENCE trajectory; the other
     chains (other seeds, other r) must be identical to single-replica runs with the same parameters."""
@@ -612,3 +614,43 @@ def test_replica_exchange_between_the_chains_of_a_batch():
     for s in singles:
         s.close()
     batch.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# Wolff cluster moves (a21): attemptWolffClusterUpdate / attemptWolffClusterShiftUpdate / buildAndFlipCluster
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stab", ["svd", "qr"])
+@pytest.mark.parametrize("name", ["o2_L4_wolff", "o2_L4_wolffshift", "o1_L4_wolff", "o3_L4_wolff"])
+def test_wolff_cluster_moves_vs_reference(name, stab):
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    rep = DetSDW(_sdw_params(g["params"], stabilisation=stab))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}: trajectory diverged"
+        assert relerr(rep.g, g[f"sweep{i}_g"]) < TOL, f"sweep {i}"
+        inf = rep.info
+        assert inf.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert inf.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+        assert inf.attemptedWolffClusterUpdates == int(g[f"sweep{i}_attWolff"][0])
+        assert inf.acceptedWolffClusterUpdates == int(g[f"sweep{i}_accWolff"][0])
+        assert inf.attemptedWolffClusterShiftUpdates == int(g[f"sweep{i}_attWolffShift"][0])
+        assert inf.acceptedWolffClusterShiftUpdates == int(g[f"sweep{i}_accWolffShift"][0])
+        assert inf.addedWolffClusterSize == g[f"sweep{i}_addedWolffClusterSize"][0]
+        i += 1
+    nxt = np.array([rep.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"]), "RNG stream position differs from the reference"
+    rep.close()
+
+
+def test_wolff_parameter_rules():
+    """detsdwparams.cpp:89-96"""
+    import dataclasses
+    from detqmc_amd import DetSDW, DqmcError
+    g = load_golden("o2_L4")
+    p0 = _sdw_params(g["params"])
+    with pytest.raises(DqmcError):
+        DetSDW(dataclasses.replace(p0, wolffClusterShiftUpdate=True, globalShift=True))
+    with pytest.raises(DqmcError):
+        DetSDW(dataclasses.replace(p0, wolffClusterUpdate=True, globalUpdateInterval=0))

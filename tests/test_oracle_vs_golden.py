@@ -121,6 +121,31 @@ def test_global_shift_trajectory():
     assert np.array_equal(nxt, g["rng_next"])
 
 
+@pytest.mark.parametrize("name", ["o2_L4_wolff", "o2_L4_wolffshift", "o1_L4_wolff", "o3_L4_wolff"])
+def test_wolff_cluster_moves_trajectory(name):
+    """attemptWolffClusterUpdate / attemptWolffClusterShiftUpdate / buildAndFlipCluster (detsdwopdim.cpp:3488-3883)"""
+    g = load_golden(name)
+    o = DetSDWOracle(oracle_params(g["params"]))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        o.sweepThermalization()
+        phi_ref = np.transpose(g[f"sweep{i}_phi"], (2, 0, 1))
+        assert np.array_equal(o.phi[1:], phi_ref[1:]), f"sweep {i}"
+        assert relerr(o.g, g[f"sweep{i}_g"]) < TOL
+        assert o.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert o.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+        assert o.attemptedWolffClusterUpdates == int(g[f"sweep{i}_attWolff"][0])
+        assert o.acceptedWolffClusterUpdates == int(g[f"sweep{i}_accWolff"][0])
+        assert o.attemptedWolffClusterShiftUpdates == int(g[f"sweep{i}_attWolffShift"][0])
+        assert o.acceptedWolffClusterShiftUpdates == int(g[f"sweep{i}_accWolffShift"][0])
+        assert o.addedWolffClusterSize == g[f"sweep{i}_addedWolffClusterSize"][0]
+        i += 1
+    assert o.attemptedWolffClusterUpdates + o.attemptedWolffClusterShiftUpdates >= 2
+    assert o.acceptedWolffClusterUpdates + o.acceptedWolffClusterShiftUpdates >= 1, "fixture exercises no accepted cluster move"
+    nxt = np.array([o.rng.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"])
+
+
 def test_headline_size_checksums():
     """BASELINE config 3 (L=16, beta=10): the reference's G is pinned through sub-samples, its
     diagonal, Frobenius norm and singular values; the field trajectory must be identical."""
