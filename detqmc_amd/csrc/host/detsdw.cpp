@@ -8,6 +8,7 @@
 // All numerics go through the C ABI in include/dqmc_hip.h.
 #include "detsdw.h"
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace detqmc {
@@ -451,6 +452,23 @@ void DetSDW::setPhi(const double* in, int b) {
     check(dqmc_set_fields_host(ctx_, ch_[b].phi.data()), "dqmc_set_fields_host");
     setupUdVStorage_and_calculateGreen();
 }
+// detsdwopdim.cpp:4991-5012
+void DetSDW::saveConfigurationStreamBinary(const std::string& directory, int b) {
+    syncPhiFromDevice(b);
+    const std::string path = directory + "/configs-phi.binarystream";
+    std::FILE* f = std::fopen(path.c_str(), "ab");
+    if (!f) throw GeneralError(DQMC_EINVAL, "Could not open file " + path + " for writing");
+    const int L = ch_[b].pars.L;
+    bool ok = true;
+    for (int ix = 0; ix < L; ++ix)
+        for (int iy = 0; iy < L; ++iy) {
+            const int i = iy * L + ix;
+            for (int k = 1; k <= m_; ++k)
+                for (int dim = 0; dim < opdim_; ++dim) ok &= std::fwrite(&ch_[b].phi[phiIdx(i, dim, k)], sizeof(double), 1, f) == 1;
+        }
+    ok &= std::fclose(f) == 0;
+    if (!ok) throw GeneralError(DQMC_EINVAL, "write error on " + path);
+}
 void DetSDW::getGreen(dqmc_cplx* g, int b) { select(b); check(dqmc_get_green_host(ctx_, g), "dqmc_get_green_host"); }
 void DetSDW::getGreenInvSv(double* sv, int b) { select(b); check(dqmc_get_sv_host(ctx_, sv), "dqmc_get_sv_host"); }
 
@@ -494,6 +512,9 @@ extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { GUARD(r->impl->g
 extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { GUARD(r->impl->setPhi(phi, r->sel)) }
 extern "C" int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g) { GUARD(r->impl->getGreen(g, r->sel)) }
 extern "C" int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv) { GUARD(r->impl->getGreenInvSv(sv, r->sel)) }
+extern "C" int detsdw_save_configuration_stream_binary(detsdw_replica* r, const char* directory) {
+    GUARD(r->impl->saveConfigurationStreamBinary(directory ? directory : ".", r->sel))
+}
 extern "C" double detsdw_rng_rand01(detsdw_replica* r) { return r->impl->rand01(r->sel); }
 extern "C" dqmc_ctx* detsdw_ctx(detsdw_replica* r) { return r ? r->impl->ctx() : nullptr; }
 extern "C" double detsdw_get_exchange_parameter_value(detsdw_replica* r) { return r->impl->get_exchange_parameter_value(r->sel); }

@@ -50,6 +50,7 @@ public:
     void setPhi(const double* phi, int b = 0);
     void getGreen(dqmc_cplx* g, int b = 0);
     void getGreenInvSv(double* sv, int b = 0);
+    void saveConfigurationStreamBinary(const std::string& directory, int b = 0);
     double rand01(int b = 0) { return ch_[b].rng.rand01(); }
     dqmc_ctx* ctx() { return ctx_; }
 

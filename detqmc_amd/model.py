@@ -356,6 +356,11 @@ class DetSDW:
         check(self.lib.detsdw_get_green_inv_sv(self.h, sv.ctypes.data_as(_lib._DP)), host=True)
         return sv
 
+    def saveConfigurationStreamBinary(self, directory="."):
+        """appends to <directory>/configs-phi.binarystream (reference format, src/detsdwopdim.cpp:4991-5012)"""
+        self._sel()
+        check(self.lib.detsdw_save_configuration_stream_binary(self.h, str(directory).encode()), host=True)
+
     def rand01(self):
         self._sel()
         return self.lib.detsdw_rng_rand01(self.h)

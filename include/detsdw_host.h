@@ -111,6 +111,11 @@ int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv);
 double detsdw_rng_rand01(detsdw_replica* r);                   /* draws from the replica's stream */
 dqmc_ctx* detsdw_ctx(detsdw_replica* r);
 
+/* saveConfigurationStreamBinary (src/detsdwopdim.cpp:4991-5012): appends the current field configuration to
+ * <directory>/configs-phi.binarystream in the reference's order (x outer, y, k = 1..m, component; raw fp64), the
+ * format its evaluation tools (sdwcorr, deteval) read */
+int detsdw_save_configuration_stream_binary(detsdw_replica* r, const char* directory);
+
 /* replica-exchange surface (src/detsdwopdim.h:116-153, src/detsdwopdim.cpp:5185-5247) */
 double detsdw_get_exchange_parameter_value(detsdw_replica* r);
 int detsdw_set_exchange_parameter_value(detsdw_replica* r, double value);

@@ -25,7 +25,7 @@ OUTDIR = os.path.join(ROOT, "tests", "golden")
 # name -> (harness args, keep-filter or None, subsample big matrices?)
 CASES = {
     "o2_L4": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=4, dumpUdV=1)),
-    "o2_L4_s7": dict(args=dict(opdim=2, L=4, beta=2.3, s=7, delaySteps=16, sweeps=3)),
+    "o2_L4_s7": dict(args=dict(opdim=2, L=4, beta=2.3, s=7, delaySteps=16, sweeps=3, cfgStream=1)),
     "o2_L4_flux": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, weakZflux=1)),
     "o2_L4_apbc": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, bc="apbc-xy",
                                  mux=-0.4, muy=-0.7, mu=-0.5, r=0.5, c=2.0, u=0.7)),
@@ -87,6 +87,9 @@ def run_case(name, spec):
                 a = a[::ss, ::ss].copy()
                 nm = nm + f"_sub{ss}"
             arrays[nm] = np.ascontiguousarray(a)
+        stream = os.path.join(td, "configs-phi.binarystream")
+        if os.path.exists(stream):
+            arrays["cfgstream_phi_bytes"] = np.fromfile(stream, dtype=np.uint8)     # the file as the reference wrote it
         arrays["params_json"] = np.array(json.dumps(spec["args"]))
     os.makedirs(OUTDIR, exist_ok=True)
     out = os.path.join(OUTDIR, name + ".npz")

@@ -302,6 +302,11 @@ static int run(const std::map<std::string, std::string>& kv) {
         }
     }
     dump_scalar("exchange_action", rep->get_exchange_action_contribution());
+    // on-disk configuration stream (detsdwopdim.cpp:4991-5012): the reference appends to <dir>/configs-phi.binarystream
+    if (get<int>(kv, "cfgStream", 0)) {
+        rep->saveConfigurationStreamBinary(g_outdir);
+        rep->saveConfigurationStreamBinary(g_outdir);      // twice: the file is opened in append mode
+    }
     // what the generator hands out next: pins the number of draws consumed so far
     {
         arma::Col<double> nxt(4);

@@ -654,3 +654,21 @@ def test_wolff_parameter_rules():
         DetSDW(dataclasses.replace(p0, wolffClusterShiftUpdate=True, globalShift=True))
     with pytest.raises(DqmcError):
         DetSDW(dataclasses.replace(p0, wolffClusterUpdate=True, globalUpdateInterval=0))
+
+
+def test_configuration_stream_file_matches_the_reference(tmp_path):
+    """saveConfigurationStreamBinary (detsdwopdim.cpp:4991-5012): byte-identical configs-phi.binarystream, appended twice
+    like the reference harness did after the last sweep of the fixture."""
+    from detqmc_amd import DetSDW
+    g = load_golden("o2_L4_s7")
+    rep = DetSDW(_sdw_params(g["params"]))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        i += 1
+    rep.saveConfigurationStreamBinary(tmp_path)
+    rep.saveConfigurationStreamBinary(tmp_path)
+    got = np.fromfile(tmp_path / "configs-phi.binarystream", dtype=np.uint8)
+    assert got.size == g["cfgstream_phi_bytes"].size == 2 * 16 * rep.info.m * 2 * 8
+    assert np.array_equal(got, g["cfgstream_phi_bytes"])
+    rep.close()
