@@ -78,6 +78,11 @@ class detsdw_info(C.Structure):
                 ("rngDrawn", C.c_uint64)]
 
 
+class detsdw_observables(C.Structure):
+    _fields_ = [("meanPhi", C.c_double * 3), ("normMeanPhi", C.c_double), ("associatedEnergy", C.c_double),
+                ("phiRhoS_Gc", C.c_double), ("phiRhoS_Gs", C.c_double), ("valid", C.c_int32), ("reserved", C.c_int32)]
+
+
 class detsdw_control_data(C.Structure):
     _fields_ = [("acceptedGlobalShifts", C.c_int32), ("attemptedGlobalShifts", C.c_int32),
                 ("acceptedWolffClusterUpdates", C.c_int32), ("attemptedWolffClusterUpdates", C.c_int32),
@@ -131,6 +136,7 @@ SYMBOLS = [
     ("detsdw_sweep", C.c_int, [_P, C.c_int]),
     ("detsdw_sweep_thermalization", C.c_int, [_P]),
     ("detsdw_get_info", C.c_int, [_P, C.POINTER(detsdw_info)]),
+    ("detsdw_get_observables", C.c_int, [_P, C.POINTER(detsdw_observables)]),
     ("detsdw_get_phi", C.c_int, [_P, _DP]),
     ("detsdw_set_phi", C.c_int, [_P, _DP]),
     ("detsdw_get_green", C.c_int, [_P, _P]),

@@ -200,7 +200,61 @@ void DetSDW::sweep_skeleton(bool thermalization) {
     ++performedSweeps_;
 }
 
-void DetSDW::sweep(bool /*takeMeasurements*/) { sweep_skeleton(false); }
+// sweep(takeMeasurements): the bosonic observables depend on the field only, and measure(k) runs right after the
+// updates of slice k (updateInSliceAndMaybeMeasure, detmodel.h:1279-1285, 1346-1352) -- no slice changes again within
+// the sweep, so they are accumulated afterwards from the final field, in the slice order of the sweep just done.
+void DetSDW::sweep(bool takeMeasurements) {
+    sweep_skeleton(false);
+    for (int b = 0; b < (int)ch_.size(); ++b) {
+        if (takeMeasurements) {
+            syncPhiFromDevice(b);
+            measureBosonic(ch_[b], lastSweepDir_ == Down);
+        } else {
+            ch_[b].obs.valid = 0;
+        }
+    }
+}
+
+// initMeasurements / measure / finishMeasurements, bosonic part (detsdwopdim.cpp:441-456, :509-545, :903-921)
+void DetSDW::measureBosonic(Chain& c, bool descending) {
+    const int L = c.pars.L;
+    double meanPhi[3] = {0.0, 0.0, 0.0};
+    double Gc = 0.0, Gs = 0.0, assoc = 0.0;
+    auto dot = [&](const double* a, const double* bb) {       // arma::dot on short vectors: two accumulators
+        double v1 = 0.0, v2 = 0.0;
+        int i = 0;
+        for (; i + 1 < opdim_; i += 2) { v1 += a[i] * bb[i]; v2 += a[i + 1] * bb[i + 1]; }
+        if (i < opdim_) v1 += a[i] * bb[i];
+        return v1 + v2;
+    };
+    for (int kk = 0; kk < m_; ++kk) {
+        const int k = descending ? m_ - kk : 1 + kk;
+        auto get = [&](int site, double* out) { for (int d = 0; d < opdim_; ++d) out[d] = c.phi[phiIdx(site, d, k)]; };
+        if (opdim_ == 2) {
+            for (int site = 0; site < N_; ++site) {
+                const int x = site % L, y = site / L;
+                double ps[3], px[3], py[3];
+                get(site, ps); get(y * L + (x + 1) % L, px); get(((y + 1) % L) * L + x, py);
+                Gc += dot(ps, px) + dot(ps, py);
+                Gs += px[0] * ps[1] - px[1] * ps[0];
+            }
+        }
+        for (int site = 0; site < N_; ++site) {
+            double ps[3];
+            get(site, ps);
+            for (int d = 0; d < opdim_; ++d) meanPhi[d] += ps[d];
+            assoc += dot(ps, ps);
+        }
+    }
+    detsdw_observables& o = c.obs;
+    std::memset(&o, 0, sizeof(o));
+    double nrm2 = 0.0;
+    for (int d = 0; d < opdim_; ++d) { o.meanPhi[d] = meanPhi[d] / double(N_ * m_); nrm2 += o.meanPhi[d] * o.meanPhi[d]; }
+    o.normMeanPhi = std::sqrt(nrm2);
+    if (opdim_ == 2) { o.phiRhoS_Gc = Gc * (0.5 * c.pars.dtau); o.phiRhoS_Gs = Gs * c.pars.dtau; }
+    o.associatedEnergy = assoc / (2.0 * N_ * m_);
+    o.valid = 1;
+}
 void DetSDW::sweepThermalization() { sweep_skeleton(true); }
 
 // detsdwopdim.cpp:3461-3486 -- all chains of a batch attempt their global moves in the same sweep, in the reference's
@@ -508,6 +562,9 @@ extern "C" void detsdw_destroy(detsdw_replica* r) { if (r) { delete r->impl; del
 extern "C" int detsdw_sweep(detsdw_replica* r, int tm) { GUARD(r->impl->sweep(tm != 0)) }
 extern "C" int detsdw_sweep_thermalization(detsdw_replica* r) { GUARD(r->impl->sweepThermalization()) }
 extern "C" int detsdw_get_info(detsdw_replica* r, detsdw_info* out) { GUARD(r->impl->getInfo(*out, r->sel)) }
+extern "C" int detsdw_get_observables(detsdw_replica* r, detsdw_observables* out) {
+    GUARD(r->impl->getObservables(*out, r->sel))
+}
 extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { GUARD(r->impl->getPhi(phi, r->sel)) }
 extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { GUARD(r->impl->setPhi(phi, r->sel)) }
 extern "C" int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g) { GUARD(r->impl->getGreen(g, r->sel)) }

@@ -46,6 +46,7 @@ public:
     void set_control_data(const detsdw_control_data& in, int b = 0);
 
     void getInfo(detsdw_info& out, int b = 0);
+    void getObservables(detsdw_observables& out, int b = 0) const { out = ch_[b].obs; }
     void getPhi(double* phi, int b = 0);
     void setPhi(const double* phi, int b = 0);
     void getGreen(dqmc_cplx* g, int b = 0);
@@ -65,6 +66,7 @@ private:
         int acceptedWolffClusterShiftUpdates = 0, attemptedWolffClusterShiftUpdates = 0;
         double addedWolffClusterSize = 0.0;
         double phiDelta = 0.5, lastAccRatio = 0.0;
+        detsdw_observables obs{};
         Chain(const detsdw_params& p) : pars(p), rng(p.rngSeed, (uint32_t)p.simindex + 1u) {}   // detqmc.h:181
     };
     std::vector<Chain> ch_;
@@ -79,6 +81,7 @@ private:
     void setupRandomField(Chain& c);
     void setupUdVStorage_and_calculateGreen();
     void sweep_skeleton(bool thermalization);
+    void measureBosonic(Chain& c, bool descending);
     void sweepDown(bool thermalization);
     void sweepUp(bool thermalization);
     void updateInSlice(int k, bool thermalization);

@@ -328,6 +328,14 @@ class DetSDW:
         return i
 
     @property
+    def observables(self):
+        """bosonic observables of the last sweep(takeMeasurements=True) (reference: measure / finishMeasurements)"""
+        self._sel()
+        o = _lib.detsdw_observables()
+        check(self.lib.detsdw_get_observables(self.h, C.byref(o)), host=True)
+        return o
+
+    @property
     def phi(self):
         """(m+1, N, OPDIM) like the oracle; the ABI hands out the reference layout."""
         self._sel()

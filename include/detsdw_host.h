@@ -83,6 +83,18 @@ typedef struct detsdw_control_data {
     dqmc_update_state adjust;
 } detsdw_control_data;
 
+/* bosonic observables of a measurement sweep: initMeasurements / measure / finishMeasurements with
+ * turnoffFermionMeasurements (src/detsdwopdim.cpp:441-456, :509-545, :903-921); valid after detsdw_sweep(r, 1).
+ * The fermionic observables (pairing, k-space occupation, ...) are not built yet. */
+typedef struct detsdw_observables {
+    double meanPhi[3];
+    double normMeanPhi;
+    double associatedEnergy;
+    double phiRhoS_Gc, phiRhoS_Gs;      /* opdim == 2 only */
+    int32_t valid;                      /* 1 after a sweep with takeMeasurements */
+    int32_t reserved;
+} detsdw_observables;
+
 /* createReplica (src/detsdwopdim.cpp:49-84) + DetSDW ctor (:158-361): checks parameters, seeds the
  * RNG with (rngSeed, simindex + 1) (src/detqmc.h:181), draws the random field, builds UdV storage and
  * G(beta) */
@@ -103,6 +115,7 @@ int detsdw_sweep(detsdw_replica* r, int takeMeasurements);
 int detsdw_sweep_thermalization(detsdw_replica* r);
 
 int detsdw_get_info(detsdw_replica* r, detsdw_info* out);
+int detsdw_get_observables(detsdw_replica* r, detsdw_observables* out);
 /* phi in the reference layout (N, OPDIM, m+1) column-major */
 int detsdw_get_phi(detsdw_replica* r, double* phi);
 int detsdw_set_phi(detsdw_replica* r, const double* phi);      /* also rebuilds UdV storage and G */

@@ -708,8 +708,65 @@ class DetSDWOracle:
         self._sweep(self.updateInSliceThermalization)
 
     def sweep(self, takeMeasurements=False):
-        """detsdwopdim.cpp:4423-4471 (fermion measurements out of scope)."""
-        self._sweep(self.updateInSlice)
+        """detsdwopdim.cpp:4423-4471; with takeMeasurements the bosonic observables of initMeasurements / measure /
+        finishMeasurements (:441-456, :509-545, :903-921) -- the reference run with turnoffFermionMeasurements; the
+        fermionic observables are SURVEY 8f."""
+        if not takeMeasurements:
+            self._sweep(self.updateInSlice)
+            return
+        self.initMeasurements()
+
+        def update_and_measure(k):               # updateInSliceAndMaybeMeasure, detmodel.h:1279-1285, 1346-1352
+            self.updateInSlice(k)
+            self.measure(k)
+        self._sweep(update_and_measure)
+        self.finishMeasurements()
+
+    @staticmethod
+    def _adot(a, b):
+        v1 = v2 = 0.0
+        n = len(a)
+        i = 0
+        while i + 1 < n:
+            v1 += float(a[i]) * float(b[i])
+            v2 += float(a[i + 1]) * float(b[i + 1])
+            i += 2
+        if i < n:
+            v1 += float(a[i]) * float(b[i])
+        return v1 + v2
+
+    def initMeasurements(self):
+        self.meanPhi = np.zeros(self.OPDIM)
+        self.normMeanPhi = 0.0
+        self.phiRhoS_Gs = 0.0
+        self.phiRhoS_Gc = 0.0
+        self.associatedEnergy = 0.0
+        self._measured_slices = set()
+
+    def measure(self, k):
+        self._measured_slices.add(k)
+        phi = self.phi
+        if self.OPDIM == 2:
+            for site in range(self.N):
+                ps = phi[k, site]
+                px = phi[k, int(self.neigh[0, site])]      # XPLUS
+                py = phi[k, int(self.neigh[2, site])]      # YPLUS
+                self.phiRhoS_Gc += self._adot(ps, px) + self._adot(ps, py)
+                self.phiRhoS_Gs += float(px[0]) * float(ps[1]) - float(px[1]) * float(ps[0])
+        for site in range(self.N):
+            ps = phi[k, site]
+            self.meanPhi = self.meanPhi + ps
+            self.associatedEnergy += self._adot(ps, ps)
+
+    def finishMeasurements(self):
+        N, m = self.N, self.m
+        assert len(self._measured_slices) == m
+        self.meanPhi = self.meanPhi / float(N * m)
+        self.normMeanPhi = math.sqrt(sum(float(x) * float(x) for x in self.meanPhi))
+        if self.OPDIM == 2:
+            self.phiRhoS_Gc *= (0.5 * self.dtau)
+            self.phiRhoS_Gs *= self.dtau
+        self.associatedEnergy /= (2.0 * N * m)
 
     # ------------------------------------------------------------------ global shift move (a21)
     def phiAction(self):

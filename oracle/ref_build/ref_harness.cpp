@@ -301,6 +301,23 @@ static int run(const std::map<std::string, std::string>& kv) {
             dump_state(*rep, "sweep" + std::to_string(i));
         }
     }
+    // measurement sweeps: sweep(true) with the bosonic observables of measure()/finishMeasurements()
+    // (detsdwopdim.cpp:509-545, :903-921); the harness runs with turnoffFermionMeasurements
+    {
+        uint32_t nmeas = get<uint32_t>(kv, "measureSweeps", 0);
+        for (uint32_t i = 1; i <= nmeas; ++i) {
+            rep->sweep(true);
+            std::string tag = "meas" + std::to_string(i);
+            dump_state(*rep, tag);
+            arma::Col<double> mp(HARNESS_OPDIM);
+            for (int d = 0; d < HARNESS_OPDIM; ++d) mp[d] = rep->meanPhi[d];
+            dump(tag + "_meanPhi", mp);
+            dump_scalar(tag + "_normMeanPhi", rep->normMeanPhi);
+            dump_scalar(tag + "_associatedEnergy", rep->associatedEnergy);
+            dump_scalar(tag + "_phiRhoS_Gc", rep->phiRhoS_Gc);
+            dump_scalar(tag + "_phiRhoS_Gs", rep->phiRhoS_Gs);
+        }
+    }
     dump_scalar("exchange_action", rep->get_exchange_action_contribution());
     // on-disk configuration stream (detsdwopdim.cpp:4991-5012): the reference appends to <dir>/configs-phi.binarystream
     if (get<int>(kv, "cfgStream", 0)) {

@@ -672,3 +672,37 @@ def test_configuration_stream_file_matches_the_reference(tmp_path):
     assert got.size == g["cfgstream_phi_bytes"].size == 2 * 16 * rep.info.m * 2 * 8
     assert np.array_equal(got, g["cfgstream_phi_bytes"])
     rep.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# measurement sweeps: sweep(takeMeasurements=True), bosonic observables (reference with turnoffFermionMeasurements)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stab", ["svd", "qr"])
+@pytest.mark.parametrize("name", ["o2_L4_meas", "o3_L4_meas"])
+def test_measurement_sweeps_vs_reference(name, stab):
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    rep = DetSDW(_sdw_params(g["params"], stabilisation=stab))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        i += 1
+    assert not rep.observables.valid
+    j = 1
+    while f"meas{j}_phi" in g:
+        rep.sweep(True)
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"meas{j}_phi")[1:]), f"measurement sweep {j}: trajectory diverged"
+        assert relerr(rep.g, g[f"meas{j}_g"]) < TOL
+        assert rep.info.phiDelta == g[f"meas{j}_phiDelta"][0], "measurement sweeps must not adapt the step size"
+        o = rep.observables
+        assert o.valid
+        d = rep.info.opdim
+        assert np.array_equal(np.array(o.meanPhi[:d]), g[f"meas{j}_meanPhi"].ravel())
+        assert o.normMeanPhi == g[f"meas{j}_normMeanPhi"][0]
+        assert o.associatedEnergy == g[f"meas{j}_associatedEnergy"][0]
+        if d == 2:
+            assert o.phiRhoS_Gc == g[f"meas{j}_phiRhoS_Gc"][0]
+            assert o.phiRhoS_Gs == g[f"meas{j}_phiRhoS_Gs"][0]
+        j += 1
+    assert j > 2
+    rep.close()

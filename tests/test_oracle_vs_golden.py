@@ -146,6 +146,29 @@ def test_wolff_cluster_moves_trajectory(name):
     assert np.array_equal(nxt, g["rng_next"])
 
 
+@pytest.mark.parametrize("name", ["o2_L4_meas", "o3_L4_meas"])
+def test_measurement_sweeps(name):
+    """sweep(true): bosonic observables of measure / finishMeasurements (detsdwopdim.cpp:509-545, :903-921), bit for bit"""
+    g = load_golden(name)
+    o = DetSDWOracle(oracle_params(g["params"]))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        o.sweepThermalization()
+        i += 1
+    j = 1
+    while f"meas{j}_phi" in g:
+        o.sweep(True)
+        assert np.array_equal(o.phi[1:], np.transpose(g[f"meas{j}_phi"], (2, 0, 1))[1:])
+        assert o.phiDelta == g[f"meas{j}_phiDelta"][0]
+        assert np.array_equal(o.meanPhi, g[f"meas{j}_meanPhi"].ravel())
+        assert o.normMeanPhi == g[f"meas{j}_normMeanPhi"][0]
+        assert o.associatedEnergy == g[f"meas{j}_associatedEnergy"][0]
+        if o.OPDIM == 2:
+            assert o.phiRhoS_Gc == g[f"meas{j}_phiRhoS_Gc"][0] and o.phiRhoS_Gs == g[f"meas{j}_phiRhoS_Gs"][0]
+        j += 1
+    assert j > 2
+
+
 def test_headline_size_checksums():
     """BASELINE config 3 (L=16, beta=10): the reference's G is pinned through sub-samples, its
     diagonal, Frobenius norm and singular values; the field trajectory must be identical."""
