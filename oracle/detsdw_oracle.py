@@ -55,6 +55,7 @@ class SDWParams:
     repeatWolffPerSweep: int = 1
     globalUpdateInterval: int = 100
     phi2bosons: bool = False
+    turnoffFermionMeasurements: bool = True   # False: measure() also takes the G-dependent observables
     checkerboard: bool = True     # False = CB_NONE: dense B = e^{-dtau V} e^{-dtau K} (detsdwopdim.h:1305-1375)
     rngSeed: int = 1020304050
     simindex: int = 0
@@ -735,7 +736,136 @@ class DetSDWOracle:
             v1 += float(a[i]) * float(b[i])
         return v1 + v2
 
+    # ------------------------------------------------------------------ fermionic observables
+    def shiftGreenSymmetric(self):
+        """detsdwopdim.cpp:4507-4612: e^{-dtau K/2} G e^{+dtau K/2} with the checkerboard half steps
+        (right: sub 1 then sub 0 with +sinh; left: sub 1 then sub 0 with -sinh), or the dense half propagators."""
+        N, M = self.N, self.MSF
+        g = self.g
+        tmp = np.zeros_like(g)
+        new = np.zeros_like(g)
+        if not self.pars.checkerboard:
+            self._dense_propK()
+        for row in range(M):
+            for col in range(M):
+                band = col % 2
+                blk = np.array(g[self._blk(row), self._blk(col)], dtype=complex, copy=True)
+                if self.pars.checkerboard:
+                    self._apply_plaq_right(blk, 1, self.plaq_mats[(band, 1, True, +1)])
+                    self._apply_plaq_right(blk, 0, self.plaq_mats[(band, 0, True, +1)])
+                else:
+                    blk = blk @ self._propK_half_inv[band]
+                tmp[self._blk(row), self._blk(col)] = blk
+        for col in range(M):
+            for row in range(M):
+                band = row % 2
+                blk = np.array(tmp[self._blk(row), self._blk(col)], dtype=complex, copy=True)
+                if self.pars.checkerboard:
+                    self._apply_plaq_left(blk, 1, self.plaq_mats[(band, 1, True, -1)])
+                    self._apply_plaq_left(blk, 0, self.plaq_mats[(band, 0, True, -1)])
+                else:
+                    blk = self._propK_half[band] @ blk
+                new[self._blk(row), self._blk(col)] = blk
+        return new
+
+    def _gl1_blocks(self, gs):
+        """gl1 (detsdwopdim.cpp:594-612) as a 4 x 4 table of N x N blocks indexed by BandSpin XUP=0, YDOWN=1, XDOWN=2,
+        YUP=3; for OPDIM < 3 the lower 2 x 2 sector is the complex conjugate of the upper one, the rest is zero."""
+        N = self.N
+        B = [[None] * 4 for _ in range(4)]
+        for b1 in range(4):
+            for b2 in range(4):
+                if self.OPDIM == 3:
+                    B[b1][b2] = gs[b1 * N:(b1 + 1) * N, b2 * N:(b2 + 1) * N]
+                elif b1 < 2 and b2 < 2:
+                    B[b1][b2] = gs[b1 * N:(b1 + 1) * N, b2 * N:(b2 + 1) * N]
+                elif b1 >= 2 and b2 >= 2:
+                    B[b1][b2] = np.conj(gs[(b1 - 2) * N:(b1 - 1) * N, (b2 - 2) * N:(b2 - 1) * N])
+                else:
+                    B[b1][b2] = np.zeros((N, N), dtype=complex)
+        return B
+
+    def measureFermionic(self, k):
+        """measure(), fermionic part (detsdwopdim.cpp:545-899)."""
+        N, L = self.N, self.L
+        gs = self.shiftGreenSymmetric()
+        if self.OPDIM == 3:
+            self.greenK0 += float(np.real(np.sum(gs)))
+            self.greenLocal += float(np.real(np.trace(gs))) / (4.0 * N)
+        else:
+            self.greenK0 += 2.0 * float(np.real(np.sum(gs)))
+            self.greenLocal += 2.0 * float(np.real(np.trace(gs))) / (4.0 * N)
+        B = self._gl1_blocks(gs)
+        XUP, YDOWN, XDOWN, YUP = 0, 1, 2, 3
+
+        def bs(band, spin):          # getBandSpin (detsdwopdim.h:268-273); spin: 0 up, 1 down
+            if band == XBAND:
+                return XUP if spin == 0 else XDOWN
+            return YUP if spin == 0 else YDOWN
+        UP, DN = 0, 1
+        # k-space occupation (:616-659)
+        p = self.pars
+        offx = 0.5 if p.bc in ("apbc-x", "apbc-xy") else 0.0
+        offy = 0.5 if p.bc in ("apbc-y", "apbc-xy") else 0.0
+        ix = np.arange(N) % L
+        iy = np.arange(N) // L
+        dx = (ix[:, None] - ix[None, :]).astype(float)
+        dy = (iy[:, None] - iy[None, :]).astype(float)
+        gx = B[XUP][XUP] + B[XDOWN][XDOWN]
+        gy = B[YUP][YUP] + B[YDOWN][YDOWN]
+        for ksite in range(N):
+            ky = -math.pi + (float(ksite // L) + offy) * 2 * math.pi / float(L)
+            kx = -math.pi + (float(ksite % L) + offx) * 2 * math.pi / float(L)
+            phase = np.exp(1j * (kx * dx + ky * dy))
+            self.kOccX[ksite] += float(np.real(np.sum(phase * gx)))
+            self.kOccY[ksite] += float(np.real(np.sum(phase * gy)))
+        # equal-time pairing correlations (:661-722)
+        for i in range(N):
+            plus = 0j
+            minus = 0j
+            for (A, Bs) in ((i, 0), (0, i)):
+                def gl(b1, s1, b2, s2):
+                    return complex(B[bs(b1, s1)][bs(b2, s2)][A, Bs])
+                X, Y = XBAND, YBAND
+                t = [gl(X, DN, X, UP) * gl(X, UP, X, DN), gl(X, DN, X, DN) * gl(X, UP, X, UP),
+                     gl(X, DN, Y, UP) * gl(X, UP, Y, DN), gl(X, DN, Y, DN) * gl(X, UP, Y, UP),
+                     gl(Y, DN, X, UP) * gl(Y, UP, X, DN), gl(Y, DN, X, DN) * gl(Y, UP, X, UP),
+                     gl(Y, DN, Y, UP) * gl(Y, UP, Y, DN), gl(Y, DN, Y, DN) * gl(Y, UP, Y, UP)]
+                plus += -4.0 * (t[0] - t[1] + t[2] - t[3] + t[4] - t[5] + t[6] - t[7])
+                minus += -4.0 * (t[0] - t[1] - t[2] + t[3] - t[4] + t[5] + t[6] - t[7])
+            self.pairPlus[i] += plus.real
+            self.pairMinus[i] += minus.real
+        # occDiffSq (:866-897)
+        contrib = 0j
+        X, Y = XBAND, YBAND
+        for i in range(N):
+            def gl(b1, s1, b2, s2):
+                return complex(B[bs(b1, s1)][bs(b2, s2)][i, i])
+            contrib += (-2.0 * gl(X, DN, X, UP) * gl(X, UP, X, DN) + gl(X, UP, X, UP)
+                        + 2.0 * gl(X, DN, Y, DN) * gl(Y, DN, X, DN)
+                        + 2.0 * gl(X, UP, Y, DN) * gl(Y, DN, X, UP)
+                        + gl(Y, DN, Y, DN)
+                        - 2.0 * gl(X, UP, X, UP) * gl(Y, DN, Y, DN)
+                        + 2.0 * gl(X, DN, Y, UP) * gl(Y, UP, X, DN)
+                        + 2.0 * gl(X, UP, Y, UP) * gl(Y, UP, X, UP)
+                        - 2.0 * gl(Y, DN, Y, UP) * gl(Y, UP, Y, DN)
+                        + gl(X, DN, X, DN) * (1.0 + 2.0 * gl(X, UP, X, UP) - 2.0 * gl(Y, DN, Y, DN) - 2.0 * gl(Y, UP, Y, UP))
+                        + gl(Y, UP, Y, UP)
+                        - 2.0 * gl(X, UP, X, UP) * gl(Y, UP, Y, UP)
+                        + 2.0 * gl(Y, DN, Y, DN) * gl(Y, UP, Y, UP))
+        self.occDiffSq += contrib.real / float(N)
+
     def initMeasurements(self):
+        N = self.N
+        self.greenK0 = 0.0
+        self.greenLocal = 0.0
+        self.kOccX = np.zeros(N)
+        self.kOccY = np.zeros(N)
+        self.pairPlus = np.zeros(N)
+        self.pairMinus = np.zeros(N)
+        self.pairPlusMax = 0.0
+        self.pairMinusMax = 0.0
+        self.occDiffSq = 0.0
         self.meanPhi = np.zeros(self.OPDIM)
         self.normMeanPhi = 0.0
         self.phiRhoS_Gs = 0.0
@@ -757,6 +887,8 @@ class DetSDWOracle:
             ps = phi[k, site]
             self.meanPhi = self.meanPhi + ps
             self.associatedEnergy += self._adot(ps, ps)
+        if not self.pars.turnoffFermionMeasurements:
+            self.measureFermionic(k)
 
     def finishMeasurements(self):
         N, m = self.N, self.m
@@ -767,6 +899,18 @@ class DetSDWOracle:
             self.phiRhoS_Gc *= (0.5 * self.dtau)
             self.phiRhoS_Gs *= self.dtau
         self.associatedEnergy /= (2.0 * N * m)
+        if not self.pars.turnoffFermionMeasurements:            # detsdwopdim.cpp:923-1015
+            L = self.L
+            self.greenK0 /= float(m)
+            self.greenLocal /= float(m)
+            self.kOccX = 2.0 - self.kOccX / float(m * N)
+            self.kOccY = 2.0 - self.kOccY / float(m * N)
+            self.pairPlus = self.pairPlus / m
+            self.pairMinus = self.pairMinus / m
+            far = [(L // 2 + ox) + (L // 2 + oy) * L for oy in (-1, 0, 1) for ox in (-1, 0, 1)]   # coordsToSite(x, y)
+            self.pairPlusMax = sum(float(self.pairPlus[i]) for i in far) / 9.0
+            self.pairMinusMax = sum(float(self.pairMinus[i]) for i in far) / 9.0
+            self.occDiffSq /= float(m)
 
     # ------------------------------------------------------------------ global shift move (a21)
     def phiAction(self):
@@ -980,6 +1124,11 @@ class DetSDWOracle:
                     K[site, nb] -= h * ph
             ev, evec = np.linalg.eigh(K)
             props[band] = (evec * np.exp(-self.dtau * ev)) @ evec.conj().T
+            # propK_half, propK_half_inv (setupPropK, detsdwopdim.cpp:1282-1283)
+            self._propK_half = getattr(self, "_propK_half", {})
+            self._propK_half_inv = getattr(self, "_propK_half_inv", {})
+            self._propK_half[band] = (evec * np.exp(-0.5 * self.dtau * ev)) @ evec.conj().T
+            self._propK_half_inv[band] = (evec * np.exp(+0.5 * self.dtau * ev)) @ evec.conj().T
         self._propK = props
         return props
 

@@ -44,6 +44,13 @@ CASES = {
     "o2_L4_meas": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=2, measureSweeps=3, globalShift=1,
                                  globalUpdateInterval=2, sliceTrace=0)),
     "o3_L4_meas": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=1, measureSweeps=2, sliceTrace=0)),
+    # measurement sweeps incl. the fermionic observables (shiftGreenSymmetric, k-space occupation, pairing, ...)
+    "o2_L4_fmeas": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=1, measureSweeps=2, fermionMeas=1, sliceTrace=0)),
+    "o2_L4_fmeas_apbc_flux": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=1, measureSweeps=2, fermionMeas=1,
+                                            sliceTrace=0, bc="apbc-x", weakZflux=1)),
+    "o3_L4_fmeas": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=1, measureSweeps=2, fermionMeas=1, sliceTrace=0)),
+    "o1_L4_fmeas": dict(args=dict(opdim=1, L=4, beta=2, s=10, delaySteps=6, sweeps=1, measureSweeps=1, fermionMeas=1, sliceTrace=0,
+                                  checkerboard=0)),
     "o2_L6_seed": dict(args=dict(opdim=2, L=6, beta=3, s=10, delaySteps=8, sweeps=2, rngSeed=5555, simindex=3)),
     # checkerboard=false (CB_NONE): dense B = e^{-dtau V} e^{-dtau K}, inverse by arma::inv
     "o2_L4_dense": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, checkerboard=0)),

@@ -156,7 +156,7 @@ static ModelParamsDetSDW make_params(const std::map<std::string, std::string>& k
     p.wolffClusterUpdate = get<int>(kv, "wolffClusterUpdate", 0) != 0; p.specified.insert("wolffClusterUpdate");
     p.wolffClusterShiftUpdate = get<int>(kv, "wolffClusterShiftUpdate", 0) != 0; p.specified.insert("wolffClusterShiftUpdate");
     p.repeatWolffPerSweep = get<uint32_t>(kv, "repeatWolffPerSweep", 1);
-    p.turnoffFermionMeasurements = true; p.specified.insert("turnoffFermionMeasurements");
+    p.turnoffFermionMeasurements = get<int>(kv, "fermionMeas", 0) == 0; p.specified.insert("turnoffFermionMeasurements");
     p.phiFixed = get<int>(kv, "phiFixed", 0) != 0;
     return p;
 }
@@ -316,7 +316,19 @@ static int run(const std::map<std::string, std::string>& kv) {
             dump_scalar(tag + "_associatedEnergy", rep->associatedEnergy);
             dump_scalar(tag + "_phiRhoS_Gc", rep->phiRhoS_Gc);
             dump_scalar(tag + "_phiRhoS_Gs", rep->phiRhoS_Gs);
+            if (get<int>(kv, "fermionMeas", 0)) {     // measure() :545-899, finishMeasurements() :923-1017
+                dump_scalar(tag + "_greenK0", rep->greenK0);
+                dump_scalar(tag + "_greenLocal", rep->greenLocal);
+                dump(tag + "_kOccX", rep->kOccX);
+                dump(tag + "_kOccY", rep->kOccY);
+                dump(tag + "_pairPlus", rep->pairPlus);
+                dump(tag + "_pairMinus", rep->pairMinus);
+                dump_scalar(tag + "_pairPlusMax", rep->pairPlusMax);
+                dump_scalar(tag + "_pairMinusMax", rep->pairMinusMax);
+                dump_scalar(tag + "_occDiffSq", rep->occDiffSq);
+            }
         }
+        if (get<int>(kv, "fermionMeas", 0)) dump("final_shiftGreenSymmetric", rep->shiftGreenSymmetric());
     }
     dump_scalar("exchange_action", rep->get_exchange_action_contribution());
     // on-disk configuration stream (detsdwopdim.cpp:4991-5012): the reference appends to <dir>/configs-phi.binarystream

@@ -43,6 +43,7 @@ def oracle_params(args):
     kw["wolffClusterUpdate"] = bool(int(a.get("wolffClusterUpdate", 0)))
     kw["wolffClusterShiftUpdate"] = bool(int(a.get("wolffClusterShiftUpdate", 0)))
     kw["repeatWolffPerSweep"] = int(a.get("repeatWolffPerSweep", 1))
+    kw["turnoffFermionMeasurements"] = not bool(int(a.get("fermionMeas", 0)))
     kw["rngSeed"] = int(a.get("rngSeed", 1020304050))
     kw["simindex"] = int(a.get("simindex", 0))
     return SDWParams(**kw)

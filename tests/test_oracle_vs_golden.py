@@ -169,6 +169,28 @@ def test_measurement_sweeps(name):
     assert j > 2
 
 
+@pytest.mark.parametrize("name", ["o2_L4_fmeas", "o2_L4_fmeas_apbc_flux", "o3_L4_fmeas", "o1_L4_fmeas"])
+def test_fermionic_measurements(name):
+    """shiftGreenSymmetric (detsdwopdim.cpp:4507-4612) and the G-dependent observables of measure / finishMeasurements
+    (:545-899, :923-1015): greenK0, greenLocal, k-space occupation, pairing correlators, occDiffSq"""
+    g = load_golden(name)
+    o = DetSDWOracle(oracle_params(g["params"]))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        o.sweepThermalization()
+        i += 1
+    j = 1
+    while f"meas{j}_phi" in g:
+        o.sweep(True)
+        assert np.array_equal(o.phi[1:], np.transpose(g[f"meas{j}_phi"], (2, 0, 1))[1:])
+        for key in ("greenK0", "greenLocal", "pairPlusMax", "pairMinusMax", "occDiffSq"):
+            assert abs(getattr(o, key) - g[f"meas{j}_{key}"][0]) < TOL * max(1.0, abs(g[f"meas{j}_{key}"][0])), key
+        for key in ("kOccX", "kOccY", "pairPlus", "pairMinus"):
+            assert relerr(getattr(o, key), g[f"meas{j}_{key}"].ravel()) < TOL, key
+        j += 1
+    assert relerr(o.shiftGreenSymmetric(), g["final_shiftGreenSymmetric"]) < 1e-12
+
+
 def test_headline_size_checksums():
     """BASELINE config 3 (L=16, beta=10): the reference's G is pinned through sub-samples, its
     diagonal, Frobenius norm and singular values; the field trajectory must be identical."""
