@@ -61,7 +61,7 @@ class detsdw_params(C.Structure):
                 ("accRatio", C.c_double), ("cdwU", C.c_double),
                 ("stabilisation", C.c_int32), ("cb_none", C.c_int32),
                 ("wolffClusterUpdate", C.c_int32), ("wolffClusterShiftUpdate", C.c_int32),
-                ("repeatWolffPerSweep", C.c_int32), ("reserved3", C.c_int32)]
+                ("repeatWolffPerSweep", C.c_int32), ("fermionMeasurements", C.c_int32)]
 
 
 class detsdw_info(C.Structure):
@@ -80,7 +80,9 @@ class detsdw_info(C.Structure):
 
 class detsdw_observables(C.Structure):
     _fields_ = [("meanPhi", C.c_double * 3), ("normMeanPhi", C.c_double), ("associatedEnergy", C.c_double),
-                ("phiRhoS_Gc", C.c_double), ("phiRhoS_Gs", C.c_double), ("valid", C.c_int32), ("reserved", C.c_int32)]
+                ("phiRhoS_Gc", C.c_double), ("phiRhoS_Gs", C.c_double), ("valid", C.c_int32), ("fermionic_valid", C.c_int32),
+                ("greenK0", C.c_double), ("greenLocal", C.c_double), ("pairPlusMax", C.c_double), ("pairMinusMax", C.c_double),
+                ("occDiffSq", C.c_double)]
 
 
 class detsdw_control_data(C.Structure):
@@ -125,6 +127,11 @@ SYMBOLS = [
     ("dqmc_restore", C.c_int, [_P]),
     ("dqmc_exchange_action_host", C.c_int, [_P, _DP]),
     ("dqmc_set_exchange_parameter", C.c_int, [_P, C.c_double]),
+    ("dqmc_shift_green_symmetric_host", C.c_int, [_P, _P]),
+    ("dqmc_measure_reset", C.c_int, [_P]),
+    ("dqmc_measure_slice", C.c_int, [_P]),
+    ("dqmc_measure_accum_size", C.c_size_t, [_P]),
+    ("dqmc_measure_read_host", C.c_int, [_P, _DP]),
     ("dqmc_profile_enable", C.c_int, [_P, C.c_int]),
     ("dqmc_profile_read", C.c_int, [_P, C.POINTER(dqmc_profile)]),
     ("detsdw_create", C.c_int, [C.POINTER(detsdw_params), C.POINTER(_P)]),
@@ -137,6 +144,7 @@ SYMBOLS = [
     ("detsdw_sweep_thermalization", C.c_int, [_P]),
     ("detsdw_get_info", C.c_int, [_P, C.POINTER(detsdw_info)]),
     ("detsdw_get_observables", C.c_int, [_P, C.POINTER(detsdw_observables)]),
+    ("detsdw_get_observable_vector", C.c_int, [_P, C.c_int, _DP]),
     ("detsdw_get_phi", C.c_int, [_P, _DP]),
     ("detsdw_set_phi", C.c_int, [_P, _DP]),
     ("detsdw_get_green", C.c_int, [_P, _P]),

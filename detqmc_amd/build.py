@@ -20,6 +20,7 @@ SOURCES = [
     "kernels_svd.hip",
     "kernels_update.hip",
     "kernels_qr.hip",
+    "kernels_measure.hip",
     "dqmc_context.hip",
     os.path.join("host", "dsfmt19937.cpp"),
     os.path.join("host", "detsdw.cpp"),

@@ -49,6 +49,9 @@ struct dqmc_ctx {
     UdVSlot spare{}, tmpudv{};
     cplx *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *T4 = nullptr;
     cplx *propK[2] = {nullptr, nullptr}, *Tdense = nullptr;   // CB_NONE only: blockdiag e^{-+dtau K} (n_g x n_g), GEMM target
+    cplx *propKh[2] = {nullptr, nullptr};                    // CB_NONE only: e^{-+dtau K / 2} (propK_half, propK_half_inv)
+    double* macc = nullptr;                                   // fermionic measurement accumulators (kernels_measure.hip)
+    size_t macc_n = 0;
     SvdWork sw{};
     int stab = 0;                       // DQMC_STAB_SVD / DQMC_STAB_QR
     QrWork qw{};
@@ -182,7 +185,7 @@ static void herm4_exp(const hc H[4][4], double pref, hc out[4][4]) {
 }
 
 static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::vector<hc>& pmats,
-                         std::vector<double>& pabcd, std::vector<int>& neigh) {
+                         std::vector<double>& pabcd, std::vector<int>& neigh, bool all_half = false) {
     const int L = p.L, N = L * L, P = N / 4;
     neigh.assign(4 * N, 0);
     for (int site = 0; site < N; ++site) {
@@ -210,7 +213,7 @@ static void build_tables(const dqmc_params& p, std::vector<int>& psites, std::ve
                 int i = i2 * L + i1, j = neigh[0 * N + i], k = neigh[2 * N + i], l = neigh[0 * N + k];
                 const int corner[4] = {i, j, k, l};
                 for (int q = 0; q < 4; ++q) psites[(sub * 4 + q) * P + pidx] = corner[q];
-                const bool half = (sub == 1);
+                const bool half = all_half || (sub == 1);
                 for (int band = 0; band < 2; ++band)
                     for (int signIdx = 0; signIdx < 2; ++signIdx) {
                         const double sign = signIdx == 0 ? -1.0 : +1.0;
@@ -310,7 +313,7 @@ static void herm_exp_dense(int n, std::vector<hc>& A, double pref_minus, double 
 }
 
 static void build_dense_propK(const dqmc_params& p, const std::vector<int>& neigh, int MSF,
-                              std::vector<hc>& out_minus, std::vector<hc>& out_plus) {
+                              std::vector<hc>& out_minus, std::vector<hc>& out_plus, double tfac = 1.0) {
     const int L = p.L, N = L * L, ng = MSF * N;
     const double hopHor[2] = {p.txhor, p.tyhor}, hopVer[2] = {p.txver, p.tyver}, mu[2] = {p.mux, p.muy};
     const bool apbc_x = (p.bc == DQMC_BC_APBC_X || p.bc == DQMC_BC_APBC_XY);
@@ -335,7 +338,7 @@ static void build_dense_propK(const dqmc_params& p, const std::vector<int>& neig
             }
         }
         std::vector<hc> Em, Ep;
-        herm_exp_dense(N, K, -p.dtau, +p.dtau, Em, Ep);
+        herm_exp_dense(N, K, -p.dtau * tfac, +p.dtau * tfac, Em, Ep);
         for (int b = band; b < MSF; b += 2)
             for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) {
                 out_minus[(size_t)(b * N + j) * ng + (b * N + i)] = Em[(size_t)i * N + j];
@@ -402,7 +405,10 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     std::vector<hc> pmats;
     std::vector<double> pabcd;
     build_tables(*p, psites, pmats, pabcd, neigh);
-    int *d_psites, *d_neigh; cplx* d_pmats; double* d_pabcd;
+    std::vector<hc> pmats_h;
+    std::vector<double> pabcd_h;
+    { std::vector<int> ps2, nb2; build_tables(*p, ps2, pmats_h, pabcd_h, nb2, true); }
+    int *d_psites, *d_neigh; cplx *d_pmats, *d_pmats_h; double *d_pabcd, *d_pabcd_h;
     int rc;
 #define A_(x) if ((rc = (x))) { dqmc_destroy(c); return rc; }
     A_(salloc(c, &d_psites, psites.size()));
@@ -413,7 +419,12 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     HIPCHK(hipMemcpy(d_psites, psites.data(), psites.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_neigh, neigh.data(), neigh.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_pmats, pmats.data(), pmats.size() * sizeof(hc), hipMemcpyHostToDevice));
+    A_(salloc(c, &d_pmats_h, pmats_h.size()));
+    A_(salloc(c, &d_pabcd_h, pabcd_h.size()));
+    HIPCHK(hipMemcpy(d_pmats_h, pmats_h.data(), pmats_h.size() * sizeof(hc), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_pabcd_h, pabcd_h.data(), pabcd_h.size() * sizeof(double), hipMemcpyHostToDevice));
     hm.psites = d_psites; hm.neigh = d_neigh; hm.pmats = d_pmats; hm.pabcd = d_pabcd; hm.pm_real = p->weakZflux ? 0 : 1;
+    hm.pmats_h = d_pmats_h; hm.pabcd_h = d_pabcd_h;
     if (p->cb_none) {
         hm.dense = 1;
         hm.ov[0] = hm.ov[1] = hm.ovinv[0] = hm.ovinv[1] = 1.0;     // mu is part of K in setupPropK
@@ -423,6 +434,10 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
         A_(salloc(c, &c->propK[0], nn)); A_(salloc(c, &c->propK[1], nn)); A_(dalloc(c, &c->Tdense, nn));
         HIPCHK(hipMemcpy(c->propK[0], em.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->propK[1], ep.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+        build_dense_propK(*p, neigh, MSF, em, ep, 0.5);           // propK_half, propK_half_inv (detsdwopdim.cpp:1282-1283)
+        A_(salloc(c, &c->propKh[0], nn)); A_(salloc(c, &c->propKh[1], nn));
+        HIPCHK(hipMemcpy(c->propKh[0], em.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->propKh[1], ep.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
     }
 
     const size_t nphi = (size_t)(p->m + 1) * p->opdim * N, ncs = (size_t)(p->m + 1) * N;
@@ -474,6 +489,8 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     A_(dalloc(c, &c->uniforms, c->uni_cap));
     A_(dalloc(c, &c->us, 1));
     A_(dalloc(c, &c->scalar_out, 8));
+    c->macc_n = measure_accum_doubles(N, p->L);
+    A_(dalloc(c, &c->macc, c->macc_n));
     A_(arena_commit(c));                    // from here on the per-chain pointers are real (chain 0) addresses, zero filled
 #undef A_
     hm.phi = c->phi; hm.coshT = c->coshT; hm.sinhT = c->sinhT;
@@ -1024,6 +1041,54 @@ extern "C" int dqmc_restore(dqmc_ctx* c) {
     }
 #undef CP_
     c->currentTimeslice = c->m;
+    return DQMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fermionic measurements: shiftGreenSymmetric + per-slice accumulation on the device
+// ---------------------------------------------------------------------------------------------
+// T1 <- e^{-dtau K/2} G e^{+dtau K/2} (detsdwopdim.cpp:4507-4612)
+static void shift_green_dev(dqmc_ctx* c) {
+    const size_t n2 = (size_t)c->n_g * c->n_g;
+    launch_copy(c->lc, c->G, c->T1, n2);
+    if (!c->hm.dense) {
+        ProfScope ps(c, FAM_BMULT, 2);
+        launch_bmult(c->lc, nullptr, c->hm, DQMC_RIGHT, 1, 0, 1, 1, c->T1, c->n_g, /*shift=*/1);   // right: +sinh half steps
+        launch_bmult(c->lc, nullptr, c->hm, DQMC_LEFT, 0, 0, 1, 1, c->T1, c->n_g, /*shift=*/1);    // left:  -sinh half steps
+    } else {
+        gemm_dev(c, 0, 0, c->T1, c->propKh[1], c->Tdense, nullptr, 0, nullptr, nullptr, 0, 0, /*sharedB=*/1);
+        gemm_dev(c, 0, 0, c->propKh[0], c->Tdense, c->T1, nullptr, 0, nullptr, nullptr, 0, /*sharedA=*/1, 0);
+    }
+}
+extern "C" int dqmc_shift_green_symmetric_host(dqmc_ctx* c, dqmc_cplx* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    shift_green_dev(c);
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, selp(c, c->T1), (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+extern "C" int dqmc_measure_reset(dqmc_ctx* c) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
+    for (int b = 0; b < c->nb; ++b) HIPCHK(hipMemsetAsync(chainp(c, c->macc, b), 0, c->macc_n * sizeof(double), c->st));
+    return DQMC_OK;
+}
+extern "C" int dqmc_measure_slice(dqmc_ctx* c) {
+    if (!c) return fail(DQMC_EINVAL, "null ctx");
+    (void)hipSetDevice(c->p.device);
+    shift_green_dev(c);
+    { ProfScope ps(c, FAM_OTHER, 1); launch_measure_accum(c->lc, c->hm, c->T1, c->macc); }
+    HIPCHK(hipGetLastError());
+    return DQMC_OK;
+}
+extern "C" size_t dqmc_measure_accum_size(dqmc_ctx* c) { return c ? c->macc_n : 0; }
+extern "C" int dqmc_measure_read_host(dqmc_ctx* c, double* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpy(out, selp(c, c->macc), c->macc_n * sizeof(double), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 

@@ -59,6 +59,9 @@ struct DevModel {
     // (cb_assaad_applyBondFactorsLeft, detsdwopdim.cpp:1688-1756): [band][signIdx][sub][4][P]
     const double* pabcd;
     int pm_real;
+    // the same two tables with HALF steps for both subgroups (shiftGreenSymmetric, detsdwopdim.cpp:4507-4563)
+    const cplx* pmats_h;
+    const double* pabcd_h;
     // fields
     double* phi;       // [m+1][opdim][N]
     double* coshT;     // [m+1][N]
@@ -85,7 +88,7 @@ struct DevUpdateState {
 // ---- launchers (implemented in the kernels_*.hip files) ---------------------------------------
 // checkerboard chain: A <- prod B_k A etc. for k = kfirst, kfirst+kstep, ... (count slices)
 void launch_bmult(const Launch& lc, const DevModel* dm, const DevModel& hm, int side, int inverse,
-                  int kfirst, int kstep, int kcount, cplx* A, int lda);
+                  int kfirst, int kstep, int kcount, cplx* A, int lda, int shift = 0);   // shift: half-step hopping passes only
 
 // C = alpha-less complex GEMM on MFMA f64: C[MxN] (+)= op(A)[MxK] . diag(kscale) . op(B)[KxN]
 struct GemmArgs {
@@ -139,6 +142,11 @@ void launch_add_diag(const Launch& lc, cplx* A, const double* d, int n);
 void launch_copy(const Launch& lc, const cplx* A, cplx* B, size_t count);
 void launch_copy_bytes(const Launch& lc, const void* src, void* dst, size_t bytes);   // same buffer of every chain
 void launch_phi_sq_sum(const Launch& lc, const DevModel& hm, double* out);
+// fermionic observables of one time slice accumulated from the shifted Green's function gs (kernels_measure.hip)
+// acc layout (doubles): [0] sum Re gs, [1] Re tr gs, [2] occDiffSq sum, [3] slices, then pairPlus[N], pairMinus[N],
+// SX[(2L-1)^2] (re, im), SY[(2L-1)^2] (re, im)
+void launch_measure_accum(const Launch& lc, const DevModel& hm, const cplx* gs, double* acc);
+size_t measure_accum_doubles(int N, int L);
 
 // ---- QR / UDT building blocks (kernels_qr.hip) ------------------------------------------------
 struct SvdProfHooks;

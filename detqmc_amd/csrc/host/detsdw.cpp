@@ -148,6 +148,7 @@ void DetSDW::endLocalUpdates() {
 
 void DetSDW::updateInSlice(int k, bool thermalization) {
     check(dqmc_update_slice(ctx_, k, thermalization ? 1 : 0), "updateInSlice");
+    if (measuring_) check(dqmc_measure_slice(ctx_), "measure");     // updateInSliceAndMaybeMeasure (detmodel.h:1279-1285)
 }
 
 // detmodel.h:1333-1399
@@ -204,15 +205,76 @@ void DetSDW::sweep_skeleton(bool thermalization) {
 // updates of slice k (updateInSliceAndMaybeMeasure, detmodel.h:1279-1285, 1346-1352) -- no slice changes again within
 // the sweep, so they are accumulated afterwards from the final field, in the slice order of the sweep just done.
 void DetSDW::sweep(bool takeMeasurements) {
-    sweep_skeleton(false);
+    const bool fermionic = takeMeasurements && ch_[0].pars.fermionMeasurements;
+    if (fermionic) check(dqmc_measure_reset(ctx_), "initMeasurements");
+    measuring_ = fermionic;
+    try { sweep_skeleton(false); } catch (...) { measuring_ = false; throw; }
+    measuring_ = false;
     for (int b = 0; b < (int)ch_.size(); ++b) {
         if (takeMeasurements) {
             syncPhiFromDevice(b);
             measureBosonic(ch_[b], lastSweepDir_ == Down);
+            if (fermionic) finishFermionic(b);
         } else {
             ch_[b].obs.valid = 0;
+            ch_[b].obs.fermionic_valid = 0;
         }
     }
+}
+
+// finishMeasurements, fermionic part (detsdwopdim.cpp:923-1015) from the device accumulators of chain b
+void DetSDW::finishFermionic(int b) {
+    Chain& c = ch_[b];
+    select(b);
+    std::vector<double> acc(dqmc_measure_accum_size(ctx_));
+    check(dqmc_measure_read_host(ctx_, acc.data()), "dqmc_measure_read_host");
+    const int L = c.pars.L, N = N_, m = m_;
+    if ((int)acc[3] != m) throw GeneralError(DQMC_EINVAL, "measurement sweep did not visit every time slice");
+    detsdw_observables& o = c.obs;
+    o.greenK0 = acc[0] / double(m);
+    o.greenLocal = acc[1] / double(m);
+    o.occDiffSq = acc[2] / double(m);
+    c.pairPlus.assign(N, 0.0); c.pairMinus.assign(N, 0.0); c.kOccX.assign(N, 0.0); c.kOccY.assign(N, 0.0);
+    for (int i = 0; i < N; ++i) { c.pairPlus[i] = acc[4 + i] / m; c.pairMinus[i] = acc[4 + N + i] / m; }
+    // momentum-space occupation: Fourier sum over the (2L-1)^2 site-difference bins, k offset by half a step along
+    // antiperiodic directions (:616-659)
+    const int W = 2 * L - 1, nbins = W * W;
+    const double* S[2] = {&acc[4 + 2 * N], &acc[4 + 2 * N + 2 * (size_t)nbins]};
+    const std::string bc(c.pars.bc[0] ? c.pars.bc : "pbc");
+    const double offx = (bc == "apbc-x" || bc == "apbc-xy") ? 0.5 : 0.0, offy = (bc == "apbc-y" || bc == "apbc-xy") ? 0.5 : 0.0;
+    const double pi = M_PI;
+    for (int ksite = 0; ksite < N; ++ksite) {
+        const double ky = -pi + (double(ksite / L) + offy) * 2 * pi / double(L);
+        const double kx = -pi + (double(ksite % L) + offx) * 2 * pi / double(L);
+        double sx = 0.0, sy = 0.0;
+        for (int bin = 0; bin < nbins; ++bin) {
+            const int dx = bin % W - (L - 1), dy = bin / W - (L - 1);
+            const double arg = kx * dx + ky * dy, cs = std::cos(arg), sn = std::sin(arg);
+            sx += cs * S[0][2 * bin] - sn * S[0][2 * bin + 1];
+            sy += cs * S[1][2 * bin] - sn * S[1][2 * bin + 1];
+        }
+        c.kOccX[ksite] = 2.0 - sx / double(m * N);      // 2.0: spin included (:938-941)
+        c.kOccY[ksite] = 2.0 - sy / double(m * N);
+    }
+    // pairing correlations at maximum distance: the 3 x 3 sites around (L/2, L/2) (:986-1002)
+    double pp = 0.0, pm = 0.0;
+    for (int oy = -1; oy <= 1; ++oy)
+        for (int ox = -1; ox <= 1; ++ox) {
+            const int i = (L / 2 + oy) * L + (L / 2 + ox);
+            pp += c.pairPlus[i]; pm += c.pairMinus[i];
+        }
+    o.pairPlusMax = pp / 9.0;
+    o.pairMinusMax = pm / 9.0;
+    o.fermionic_valid = 1;
+}
+
+void DetSDW::getObservableVector(int which, double* out, int b) const {
+    const Chain& c = ch_[b];
+    if (!c.obs.fermionic_valid) throw GeneralError(DQMC_EINVAL, "no fermionic measurement has been taken");
+    const std::vector<double>* v = which == DETSDW_OBS_KOCCX ? &c.kOccX : which == DETSDW_OBS_KOCCY ? &c.kOccY
+                                 : which == DETSDW_OBS_PAIRPLUS ? &c.pairPlus : which == DETSDW_OBS_PAIRMINUS ? &c.pairMinus : nullptr;
+    if (!v) throw ParameterWrong("unknown observable vector");
+    std::memcpy(out, v->data(), v->size() * sizeof(double));
 }
 
 // initMeasurements / measure / finishMeasurements, bosonic part (detsdwopdim.cpp:441-456, :509-545, :903-921)
@@ -248,7 +310,7 @@ void DetSDW::measureBosonic(Chain& c, bool descending) {
     }
     detsdw_observables& o = c.obs;
     std::memset(&o, 0, sizeof(o));
-    double nrm2 = 0.0;
+    double nrm2 = 0.0;   // (fermionic fields are filled in afterwards by finishFermionic)
     for (int d = 0; d < opdim_; ++d) { o.meanPhi[d] = meanPhi[d] / double(N_ * m_); nrm2 += o.meanPhi[d] * o.meanPhi[d]; }
     o.normMeanPhi = std::sqrt(nrm2);
     if (opdim_ == 2) { o.phiRhoS_Gc = Gc * (0.5 * c.pars.dtau); o.phiRhoS_Gs = Gs * c.pars.dtau; }
@@ -564,6 +626,9 @@ extern "C" int detsdw_sweep_thermalization(detsdw_replica* r) { GUARD(r->impl->s
 extern "C" int detsdw_get_info(detsdw_replica* r, detsdw_info* out) { GUARD(r->impl->getInfo(*out, r->sel)) }
 extern "C" int detsdw_get_observables(detsdw_replica* r, detsdw_observables* out) {
     GUARD(r->impl->getObservables(*out, r->sel))
+}
+extern "C" int detsdw_get_observable_vector(detsdw_replica* r, int which, double* out) {
+    GUARD(r->impl->getObservableVector(which, out, r->sel))
 }
 extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { GUARD(r->impl->getPhi(phi, r->sel)) }
 extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { GUARD(r->impl->setPhi(phi, r->sel)) }

@@ -47,6 +47,7 @@ public:
 
     void getInfo(detsdw_info& out, int b = 0);
     void getObservables(detsdw_observables& out, int b = 0) const { out = ch_[b].obs; }
+    void getObservableVector(int which, double* out, int b = 0) const;
     void getPhi(double* phi, int b = 0);
     void setPhi(const double* phi, int b = 0);
     void getGreen(dqmc_cplx* g, int b = 0);
@@ -67,6 +68,7 @@ private:
         double addedWolffClusterSize = 0.0;
         double phiDelta = 0.5, lastAccRatio = 0.0;
         detsdw_observables obs{};
+        std::vector<double> kOccX, kOccY, pairPlus, pairMinus;
         Chain(const detsdw_params& p) : pars(p), rng(p.rngSeed, (uint32_t)p.simindex + 1u) {}   // detqmc.h:181
     };
     std::vector<Chain> ch_;
@@ -82,6 +84,8 @@ private:
     void setupUdVStorage_and_calculateGreen();
     void sweep_skeleton(bool thermalization);
     void measureBosonic(Chain& c, bool descending);
+    void finishFermionic(int b);
+    bool measuring_ = false;          // measure(k) after the updates of slice k (updateInSliceAndMaybeMeasure)
     void sweepDown(bool thermalization);
     void sweepUp(bool thermalization);
     void updateInSlice(int k, bool thermalization);

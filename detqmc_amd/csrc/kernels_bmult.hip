@@ -58,7 +58,7 @@ __device__ __forceinline__ void build_V(cplx (&V)[MSF][MSF], double sign, double
 
 template<int MSF, bool RIGHT, bool INV>
 __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restrict__ A, int lda, int nvec,
-                                                      int kfirst, int kstep, int kcount, size_t cs) {
+                                                      int kfirst, int kstep, int kcount, int shift, size_t cs) {
     extern __shared__ cplx sm[];
     dm = chain_model(dm, cs); CHAIN(A);
     const int N = dm.N, ng = dm.ng, P = dm.P;
@@ -94,11 +94,16 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
         const int k = kfirst + kc * kstep;
         for (int stage = 0; stage < 2; ++stage) {
             const bool do_passes = (stage == 0) == PASSES_FIRST;
+            if (shift && !do_passes) continue;           // shiftGreenSymmetric: hopping half steps only, no e^{-+dtau V}
             if (do_passes) {
                 if (dm.dense) continue;      // CB_NONE: dense e^{+-dtau K} applied by a GEMM outside this kernel
                 // e^{+-dtau K1/2} e^{+-dtau K0} e^{+-dtau K1/2}: sub 1 (half), sub 0 (full), sub 1 (half)
-                for (int pass = 0; pass < 3; ++pass) {
-                    const int sub = (pass == 1) ? 0 : 1;
+                // shift (shiftGreenSymmetric, detsdwopdim.cpp:4527-4541): e^{+-dtau K1/2} then e^{+-dtau K0/2}, half-step tables
+                const double* abcd_tab = shift ? dm.pabcd_h : dm.pabcd;
+                const cplx* mat_tab = shift ? dm.pmats_h : dm.pmats;
+                const int npass = shift ? 2 : 3;
+                for (int pass = 0; pass < npass; ++pass) {
+                    const int sub = shift ? (pass == 0 ? 1 : 0) : ((pass == 1) ? 0 : 1);
                     const int items = nv * MSF * P;
                     for (int idx = tid; idx < items; idx += nth) {
                         int p, b, v;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
                             // rows (a b c d)(b a d c)(c d a b)(d c b a): symmetric, so left and right agree
                             double co[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) co[q] = dm.pabcd[(tbl * 4 + q) * P + p];
+                            for (int q = 0; q < 4; ++q) co[q] = abcd_tab[(tbl * 4 + q) * P + p];
 #pragma unroll
                             for (int a = 0; a < 4; ++a) {
                                 cplx acc = make_double2(0.0, 0.0);
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
                                 y[a] = acc;
                             }
                         } else {
-                            const cplx* mat = dm.pmats + tbl * 16 * P + p;
+                            const cplx* mat = mat_tab + tbl * 16 * P + p;
 #pragma unroll
                             for (int a = 0; a < 4; ++a) {
                                 cplx acc = make_double2(0.0, 0.0);
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
 }
 
 void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, int side, int inverse,
-                  int kfirst, int kstep, int kcount, cplx* A, int lda) {
+                  int kfirst, int kstep, int kcount, cplx* A, int lda, int shift) {
     const int ng = hm.ng;
     const int max_fit = (int)(65536 / ((size_t)ng * sizeof(cplx))) - (side == DQMC_LEFT ? 0 : 1);   // keep <= 64 KiB of LDS
     static const int env_l = getenv("DQMC_BMULT_NVEC_L") ? atoi(getenv("DQMC_BMULT_NVEC_L")) : 0;   // developer knobs
@@ -217,7 +222,7 @@ void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, 
     const size_t lds = (size_t)(side == DQMC_LEFT ? nvec : nvec + 1) * ng * sizeof(cplx);
 #define LAUNCH(MSFV, R, I)                                                                              \
     hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I>), dim3(grid, 1, lc.nb), dim3(256), lds, lc.st, hm, A, lda, nvec, \
-                       kfirst, kstep, kcount, lc.cs)
+                       kfirst, kstep, kcount, shift, lc.cs)
     if (hm.MSF == 2) {
         if (side == DQMC_LEFT) { if (!inverse) LAUNCH(2, false, false); else LAUNCH(2, false, true); }
         else                   { if (!inverse) LAUNCH(2, true, false);  else LAUNCH(2, true, true); }

@@ -53,6 +53,7 @@ class SDWParams:
     wolffClusterUpdate: bool = False
     wolffClusterShiftUpdate: bool = False
     repeatWolffPerSweep: int = 1
+    fermionMeasurements: bool = False    # sweep(True) also takes the G-dependent observables (reference default: on)
     globalUpdateInterval: int = 100
     phi2bosons: bool = False
     cdwU: float = 0.0
@@ -99,6 +100,11 @@ class KernelContext:
             self.close()
         except Exception:
             pass
+
+    def shiftGreenSymmetric(self):
+        g = np.zeros((self.ng, self.ng), dtype=np.complex128, order="F")
+        check(self.lib.dqmc_shift_green_symmetric_host(self.h, g.ctypes.data))
+        return g
 
     def select_chain(self, b):
         """host-buffer calls (fields, G, sv, UdV, uniforms, update state, ...) refer to chain b from now on"""
@@ -268,7 +274,7 @@ def _host_params(pars: SDWParams):
         mu=pars.mu, mux=pars.mux or 0.0, muy=pars.muy or 0.0, accRatio=pars.accRatio, cdwU=pars.cdwU,
         stabilisation=STABILISATION[pars.stabilisation], cb_none=int(not pars.checkerboard),
         wolffClusterUpdate=int(pars.wolffClusterUpdate), wolffClusterShiftUpdate=int(pars.wolffClusterShiftUpdate),
-        repeatWolffPerSweep=int(pars.repeatWolffPerSweep))
+        repeatWolffPerSweep=int(pars.repeatWolffPerSweep), fermionMeasurements=int(pars.fermionMeasurements))
 
 
 class DetSDW:
@@ -334,6 +340,14 @@ class DetSDW:
         o = _lib.detsdw_observables()
         check(self.lib.detsdw_get_observables(self.h, C.byref(o)), host=True)
         return o
+
+    def observable_vector(self, name):
+        """'kOccX', 'kOccY', 'pairPlus', 'pairMinus' of the last sweep(True) with fermionMeasurements"""
+        self._sel()
+        out = np.zeros(self.info.N)
+        which = {"kOccX": 0, "kOccY": 1, "pairPlus": 2, "pairMinus": 3}[name]
+        check(self.lib.detsdw_get_observable_vector(self.h, which, out.ctypes.data_as(_lib._DP)), host=True)
+        return out
 
     @property
     def phi(self):

@@ -54,7 +54,8 @@ typedef struct detsdw_params {
     int32_t wolffClusterUpdate;       /* attemptWolffClusterUpdate every globalUpdateInterval sweeps (detsdwopdim.cpp:3488-3562) */
     int32_t wolffClusterShiftUpdate;  /* combined cluster + global shift (:3647-3751); excludes the two individual moves */
     int32_t repeatWolffPerSweep;      /* cluster flips per attempt, 0 is read as 1 */
-    int32_t reserved3;
+    int32_t fermionMeasurements;      /* 1: sweep(takeMeasurements) also takes the G-dependent observables (the reference's
+                                         default, i.e. turnoffFermionMeasurements = false); 0: bosonic observables only */
 } detsdw_params;
 
 typedef struct detsdw_info {
@@ -92,8 +93,12 @@ typedef struct detsdw_observables {
     double associatedEnergy;
     double phiRhoS_Gc, phiRhoS_Gs;      /* opdim == 2 only */
     int32_t valid;                      /* 1 after a sweep with takeMeasurements */
-    int32_t reserved;
+    int32_t fermionic_valid;            /* 1 if the fields below and the vectors of detsdw_get_observable_vector were taken */
+    double greenK0, greenLocal;         /* src/detsdwopdim.cpp:565-588, :926-927 */
+    double pairPlusMax, pairMinusMax;   /* :986-1002 */
+    double occDiffSq;                   /* :866-897, :1013 */
 } detsdw_observables;
+enum { DETSDW_OBS_KOCCX = 0, DETSDW_OBS_KOCCY = 1, DETSDW_OBS_PAIRPLUS = 2, DETSDW_OBS_PAIRMINUS = 3 };
 
 /* createReplica (src/detsdwopdim.cpp:49-84) + DetSDW ctor (:158-361): checks parameters, seeds the
  * RNG with (rngSeed, simindex + 1) (src/detqmc.h:181), draws the random field, builds UdV storage and
@@ -116,6 +121,8 @@ int detsdw_sweep_thermalization(detsdw_replica* r);
 
 int detsdw_get_info(detsdw_replica* r, detsdw_info* out);
 int detsdw_get_observables(detsdw_replica* r, detsdw_observables* out);
+/* N-vectors of the last measurement sweep: kOccX, kOccY (site index = k-vector, :616-659, :937-941), pairPlus, pairMinus */
+int detsdw_get_observable_vector(detsdw_replica* r, int which, double* out);
 /* phi in the reference layout (N, OPDIM, m+1) column-major */
 int detsdw_get_phi(detsdw_replica* r, double* phi);
 int detsdw_set_phi(detsdw_replica* r, const double* phi);      /* also rebuilds UdV storage and G */

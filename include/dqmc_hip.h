@@ -165,6 +165,20 @@ int dqmc_backup(dqmc_ctx* ctx);
 int dqmc_restore(dqmc_ctx* ctx);
 /* 1/2 dtau sum phi^2 (get_exchange_action_contribution, detsdwopdim.cpp:5205-5216) */
 int dqmc_exchange_action_host(dqmc_ctx* ctx, double* out);
+
+/* ---- fermionic measurements --------------------------------------------------
+ * shiftGreenSymmetric (src/detsdwopdim.cpp:4507-4612): e^{-dtau K/2} G e^{+dtau K/2} of the selected chain */
+int dqmc_shift_green_symmetric_host(dqmc_ctx* ctx, dqmc_cplx* out);
+/* initMeasurements / measure(k), G-dependent part (src/detsdwopdim.cpp:458-505, :545-899), all chains: the slice's
+ * contributions are accumulated on the device.  Accumulator layout (doubles, dqmc_measure_accum_size of them):
+ * [0] greenK0 sum, [1] greenLocal sum, [2] occDiffSq sum, [3] slices measured, pairPlus[N], pairMinus[N],
+ * S_X[(2L-1)^2] and S_Y[(2L-1)^2] as (re, im): S_band(dx, dy) = sum over site pairs with r_i - r_j = (dx, dy) of
+ * g_band,up(i,j) + g_band,down(i,j), bin index (dy + L-1) (2L-1) + (dx + L-1); the momentum-space occupation is
+ * their Fourier sum (finishMeasurements does it on the host). */
+int dqmc_measure_reset(dqmc_ctx* ctx);
+int dqmc_measure_slice(dqmc_ctx* ctx);
+size_t dqmc_measure_accum_size(dqmc_ctx* ctx);
+int dqmc_measure_read_host(dqmc_ctx* ctx, double* out);
 /* set_exchange_parameter_value (detsdwopdim.cpp:5195-5197): r only enters the bosonic action */
 int dqmc_set_exchange_parameter(dqmc_ctx* ctx, double r);
 

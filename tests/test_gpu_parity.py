@@ -36,7 +36,7 @@ def _sdw_params(a, **over):
               mux=op.mux, muy=op.muy, accRatio=op.accRatio, delaySteps=op.delaySteps, bc=op.bc,
               weakZflux=op.weakZflux, globalShift=op.globalShift, globalUpdateInterval=op.globalUpdateInterval,
               wolffClusterUpdate=op.wolffClusterUpdate, wolffClusterShiftUpdate=op.wolffClusterShiftUpdate,
-              repeatWolffPerSweep=op.repeatWolffPerSweep,
+              repeatWolffPerSweep=op.repeatWolffPerSweep, fermionMeasurements=not op.turnoffFermionMeasurements,
               rngSeed=op.rngSeed, simindex=op.simindex, checkerboard=op.checkerboard)
     kw.update(over)
     return SDWParams(**kw)
@@ -706,3 +706,61 @@ def test_measurement_sweeps_vs_reference(name, stab):
         j += 1
     assert j > 2
     rep.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# fermionic measurements on the device: shiftGreenSymmetric + G-dependent observables
+# ------------------------------------------------------------------------------------------------
+FMEAS = ["o2_L4_fmeas", "o2_L4_fmeas_apbc_flux", "o3_L4_fmeas", "o1_L4_fmeas"]
+
+
+@pytest.mark.parametrize("stab", ["svd", "qr"])
+@pytest.mark.parametrize("name", FMEAS)
+def test_fermionic_measurement_sweeps_vs_reference(name, stab):
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    rep = DetSDW(_sdw_params(g["params"], stabilisation=stab))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        i += 1
+    j = 1
+    while f"meas{j}_phi" in g:
+        rep.sweep(True)
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"meas{j}_phi")[1:]), f"measurement sweep {j}: trajectory diverged"
+        o = rep.observables
+        assert o.valid and o.fermionic_valid
+        assert o.normMeanPhi == g[f"meas{j}_normMeanPhi"][0]
+        for key in ("greenK0", "greenLocal", "pairPlusMax", "pairMinusMax", "occDiffSq"):
+            want = g[f"meas{j}_{key}"][0]
+            assert abs(getattr(o, key) - want) < TOL * max(1.0, abs(want)), (key, getattr(o, key), want)
+        for key in ("kOccX", "kOccY", "pairPlus", "pairMinus"):
+            assert relerr(rep.observable_vector(key), g[f"meas{j}_{key}"].ravel()) < TOL, key
+        j += 1
+    assert j > 1
+    # shiftGreenSymmetric of the final state
+    assert relerr(rep.kernel_context.shiftGreenSymmetric(), g["final_shiftGreenSymmetric"]) < TOL
+    rep.close()
+
+
+def test_fermionic_measurements_in_a_batch():
+    """every chain of a batch measures like its single-replica twin"""
+    import dataclasses
+    from detqmc_amd import DetSDW, DetSDWBatch
+    g = load_golden("o2_L4_fmeas")
+    p0 = _sdw_params(g["params"], stabilisation="qr")
+    plist = [p0, dataclasses.replace(p0, simindex=3, r=-0.7)]
+    batch = DetSDWBatch(plist)
+    single = DetSDW(plist[1])
+    for _ in range(2):
+        batch.sweep(True)
+        single.sweep(True)
+    o0 = batch.chain(0).observables
+    assert abs(o0.greenK0 - g["meas2_greenK0"][0]) < 1  # chain 0 started measuring one sweep earlier than the fixture: sanity only
+    ob, os_ = batch.chain(1).observables, single.observables
+    for key in ("greenK0", "greenLocal", "pairPlusMax", "pairMinusMax", "occDiffSq", "normMeanPhi"):
+        assert getattr(ob, key) == getattr(os_, key), key
+    for key in ("kOccX", "kOccY", "pairPlus", "pairMinus"):
+        assert np.array_equal(batch.chain(1).observable_vector(key), single.observable_vector(key))
+    single.close()
+    batch.close()
