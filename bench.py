@@ -274,14 +274,40 @@ def main():
                         "one Jacobi round reads and writes every column of A and V once")
                 roofs.append(r)
             else:
-                # QR + formation of Q: every panel step streams the trailing matrix twice (read, write)
-                np_ = (n + 15) // 16
-                qr_bytes = 2 * sum(2 * 16.0 * (n - 16 * p) * (n - 16 * p) for p in range(np_))
+                # k_qr_apply_reg reads and writes the columns it is given once per launch; the launch sequence of
+                # run_qr (kernels_qr.hip): groups of 4 panels, look-ahead launches for the group's own columns
+                def qr_apply_traffic(nn):
+                    tot, p, npan = 0.0, 0, (nn + 15) // 16
+                    while p < npan:
+                        j0 = p * 16
+                        left = nn - j0
+                        if nn <= 512 and left > 64:
+                            for rows, ncols in ((left, 16), (left, 32), (left - 32, 16), (left, left - 64)):
+                                tot += 2 * 16.0 * rows * ncols
+                            p += 4
+                        elif nn <= 512 and left > 32:
+                            tot += 2 * 16.0 * left * 16 + 2 * 16.0 * left * (left - 32)
+                            p += 2
+                        else:
+                            nbp = min(16, left)
+                            if left - nbp > 0:
+                                tot += 2 * 16.0 * left * (left - nbp)
+                            p += 1
+                    p = npan - 1
+                    while p >= 0:                       # formation of Q, reflectors in reverse order
+                        cnt = 1
+                        if nn <= 512 and min(16, nn - p * 16) == 16:
+                            cnt = 4 if p >= 3 else (2 if p >= 1 else 1)
+                        lo = p - (cnt - 1)
+                        tot += 2 * 16.0 * (nn - lo * 16) ** 2
+                        p -= cnt
+                    return tot
+                qr_bytes = qr_apply_traffic(n)
                 calls = max(prof["qr_calls"], 1)
                 napply = max(prof["decomp_rounds"], 1)
-                roofs.append(hbm("qr_apply", "k_qr_apply", prof["decomp_round_ms"], napply, qr_bytes * calls / napply,
-                                 "block reflector applied to the trailing matrix / to Q: reads and writes it once; bytes = average over the "
-                                 "panels of a factorisation"))
+                roofs.append(hbm("qr_apply", "k_qr_apply_reg", prof["decomp_round_ms"], napply, qr_bytes * calls / napply,
+                                 "block reflectors of up to 4 panels applied to the trailing matrix / to Q while the columns stay in "
+                                 "registers: one read + one write per launch; bytes = average over the launches of a factorisation"))
                 rest_ms = max(prof["decomp"][0] - prof["decomp_round_ms"], 0.0)
                 rest_l = max(prof["decomp"][1] - napply, 1)
                 roofs.append(hbm("qr_rest", "k_qr_panel, triangular solve, pivoting glue", rest_ms, rest_l, 0.0,
