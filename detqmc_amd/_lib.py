@@ -150,6 +150,8 @@ SYMBOLS = [
     ("detsdw_get_green", C.c_int, [_P, _P]),
     ("detsdw_get_green_inv_sv", C.c_int, [_P, _DP]),
     ("detsdw_save_configuration_stream_binary", C.c_int, [_P, C.c_char_p]),
+    ("detsdw_save_state", C.c_int, [_P, C.c_char_p]),
+    ("detsdw_load_state", C.c_int, [_P, C.c_char_p]),
     ("detsdw_rng_rand01", C.c_double, [_P]),
     ("detsdw_ctx", _P, [_P]),
     ("detsdw_get_exchange_parameter_value", C.c_double, [_P]),

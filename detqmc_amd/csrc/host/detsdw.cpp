@@ -585,6 +585,66 @@ void DetSDW::saveConfigurationStreamBinary(const std::string& directory, int b) 
     ok &= std::fclose(f) == 0;
     if (!ok) throw GeneralError(DQMC_EINVAL, "write error on " + path);
 }
+// ---- checkpoint / resume --------------------------------------------------------------------------------------
+namespace {
+const char kMagic[8] = {'D', 'Q', 'M', 'C', 'K', 'P', 'T', '1'};
+struct FileCloser { std::FILE* f; ~FileCloser() { if (f) std::fclose(f); } };
+void wr(std::FILE* f, const void* p, size_t n) { if (std::fwrite(p, 1, n, f) != n) throw GeneralError(DQMC_EINVAL, "checkpoint: write error"); }
+void rd(std::FILE* f, void* p, size_t n) { if (std::fread(p, 1, n, f) != n) throw GeneralError(DQMC_EINVAL, "checkpoint: truncated file"); }
+}  // namespace
+
+void DetSDW::saveState(const std::string& path) {
+    FileCloser fc{std::fopen(path.c_str(), "wb")};
+    if (!fc.f) throw GeneralError(DQMC_EINVAL, "Could not open file " + path + " for writing");
+    const int32_t hdr[4] = {(int32_t)ch_.size(), (int32_t)sizeof(detsdw_params), performedSweeps_, (int32_t)lastSweepDir_};
+    wr(fc.f, kMagic, 8); wr(fc.f, hdr, sizeof(hdr));
+    for (int b = 0; b < (int)ch_.size(); ++b) {
+        Chain& c = ch_[b];
+        syncPhiFromDevice(b);
+        detsdw_control_data cd;
+        get_control_data(cd, b);
+        const std::vector<uint64_t> rng = c.rng.serialize();
+        const uint64_t nr = rng.size(), np = c.phi.size();
+        wr(fc.f, &c.pars, sizeof(c.pars)); wr(fc.f, &cd, sizeof(cd));
+        wr(fc.f, &nr, 8); wr(fc.f, rng.data(), nr * 8);
+        wr(fc.f, &np, 8); wr(fc.f, c.phi.data(), np * 8);
+    }
+}
+
+void DetSDW::loadState(const std::string& path) {
+    FileCloser fc{std::fopen(path.c_str(), "rb")};
+    if (!fc.f) throw GeneralError(DQMC_EINVAL, "Could not open file " + path + " for reading");
+    char magic[8]; int32_t hdr[4];
+    rd(fc.f, magic, 8); rd(fc.f, hdr, sizeof(hdr));
+    if (std::memcmp(magic, kMagic, 8) != 0) throw GeneralError(DQMC_EINVAL, "checkpoint: not a detqmc_amd state file");
+    if (hdr[0] != (int32_t)ch_.size() || hdr[1] != (int32_t)sizeof(detsdw_params))
+        throw GeneralError(DQMC_EINVAL, "checkpoint: written for a different number of replicas / library version");
+    for (int b = 0; b < (int)ch_.size(); ++b) {
+        Chain& c = ch_[b];
+        detsdw_params p; detsdw_control_data cd;
+        rd(fc.f, &p, sizeof(p)); rd(fc.f, &cd, sizeof(cd));
+        detsdw_params a = p, q = c.pars;
+        a.r = q.r = 0.0; a.device = q.device = 0;               // r is restored from the file; the device may differ
+        if (std::memcmp(&a, &q, sizeof(a)) != 0) throw GeneralError(DQMC_EINVAL, "checkpoint: parameters differ from this replica's");
+        uint64_t nr = 0, np = 0;
+        rd(fc.f, &nr, 8);
+        if (nr < DSFMT19937::state_words() + 3 || nr > (1u << 26)) throw GeneralError(DQMC_EINVAL, "checkpoint: bad RNG record");
+        std::vector<uint64_t> rng(nr);
+        rd(fc.f, rng.data(), nr * 8);
+        rd(fc.f, &np, 8);
+        if (np != c.phi.size()) throw GeneralError(DQMC_EINVAL, "checkpoint: field size mismatch");
+        rd(fc.f, c.phi.data(), np * 8);
+        c.rng.deserialize(rng);
+        select(b);
+        c.pars.r = p.r;
+        check(dqmc_set_exchange_parameter(ctx_, p.r), "dqmc_set_exchange_parameter");
+        check(dqmc_set_fields_host(ctx_, c.phi.data()), "dqmc_set_fields_host");
+        set_control_data(cd, b);
+    }
+    performedSweeps_ = hdr[2];
+    setupUdVStorage_and_calculateGreen();         // like the reference's resume: G(beta) from scratch, next sweep goes down
+}
+
 void DetSDW::getGreen(dqmc_cplx* g, int b) { select(b); check(dqmc_get_green_host(ctx_, g), "dqmc_get_green_host"); }
 void DetSDW::getGreenInvSv(double* sv, int b) { select(b); check(dqmc_get_sv_host(ctx_, sv), "dqmc_get_sv_host"); }
 
@@ -634,6 +694,14 @@ extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { GUARD(r->impl->g
 extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { GUARD(r->impl->setPhi(phi, r->sel)) }
 extern "C" int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g) { GUARD(r->impl->getGreen(g, r->sel)) }
 extern "C" int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv) { GUARD(r->impl->getGreenInvSv(sv, r->sel)) }
+extern "C" int detsdw_save_state(detsdw_replica* r, const char* path) {
+    if (!path) { g_host_err = "null path"; return DQMC_EINVAL; }
+    GUARD(r->impl->saveState(path))
+}
+extern "C" int detsdw_load_state(detsdw_replica* r, const char* path) {
+    if (!path) { g_host_err = "null path"; return DQMC_EINVAL; }
+    GUARD(r->impl->loadState(path))
+}
 extern "C" int detsdw_save_configuration_stream_binary(detsdw_replica* r, const char* directory) {
     GUARD(r->impl->saveConfigurationStreamBinary(directory ? directory : ".", r->sel))
 }

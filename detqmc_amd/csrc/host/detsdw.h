@@ -53,6 +53,8 @@ public:
     void getGreen(dqmc_cplx* g, int b = 0);
     void getGreenInvSv(double* sv, int b = 0);
     void saveConfigurationStreamBinary(const std::string& directory, int b = 0);
+    void saveState(const std::string& path);
+    void loadState(const std::string& path);
     double rand01(int b = 0) { return ch_[b].rng.rand01(); }
     dqmc_ctx* ctx() { return ctx_; }
 

@@ -81,6 +81,23 @@ void RngStream::consume(size_t n) {
     if (pos_ >= buf_.size()) { buf_.clear(); pos_ = 0; }
 }
 
+std::vector<uint64_t> RngStream::serialize() const {
+    std::vector<uint64_t> b(DSFMT19937::state_words() + 3 + (buf_.size() - pos_));
+    gen_.get_state(b.data());
+    size_t o = DSFMT19937::state_words();
+    b[o++] = drawn_; b[o++] = mySeed_; b[o++] = buf_.size() - pos_;
+    for (size_t i = pos_; i < buf_.size(); ++i) { uint64_t u; std::memcpy(&u, &buf_[i], 8); b[o++] = u; }
+    return b;
+}
+void RngStream::deserialize(const std::vector<uint64_t>& b) {
+    gen_.set_state(b.data());
+    size_t o = DSFMT19937::state_words();
+    drawn_ = b[o++]; mySeed_ = (uint32_t)b[o++];
+    const size_t nbuf = (size_t)b[o++];
+    buf_.assign(nbuf, 0.0); pos_ = 0;
+    for (size_t i = 0; i < nbuf; ++i) std::memcpy(&buf_[i], &b[o++], 8);
+}
+
 void RngStream::randPointOnCircle(double& x, double& y) {
     const double phi = randRange(0., 2. * M_PI);
     x = std::cos(phi);

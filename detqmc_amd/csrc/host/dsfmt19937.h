@@ -17,8 +17,12 @@ public:
     void init(uint32_t seed);
     // uniform in (0,1): dsfmt_genrand_open_open
     double genrand_open_open();
+    // raw generator state (checkpoints)
+    static constexpr size_t state_words() { return (N_ + 1) * 2 + 1; }
+    void get_state(uint64_t* out) const { for (int i = 0; i < (N_ + 1) * 2; ++i) out[i] = st_[i]; out[(N_ + 1) * 2] = (uint64_t)idx_; }
+    void set_state(const uint64_t* in) { for (int i = 0; i < (N_ + 1) * 2; ++i) st_[i] = in[i]; idx_ = (int)in[(N_ + 1) * 2]; }
 private:
-    static const int N_ = 191;
+    static constexpr int N_ = 191;
     uint64_t st_[(N_ + 1) * 2];
     int idx_;
     void gen_rand_all();
@@ -38,6 +42,9 @@ public:
     void consume(size_t n);
     uint64_t drawn() const { return drawn_; }
     uint32_t mySeed() const { return mySeed_; }
+    // exact stream position for checkpoints (the reference serialises the dSFMT state string, rngwrapper.h:100-116)
+    std::vector<uint64_t> serialize() const;
+    void deserialize(const std::vector<uint64_t>& blob);
 private:
     DSFMT19937 gen_;
     std::vector<double> buf_;

@@ -378,6 +378,13 @@ class DetSDW:
         check(self.lib.detsdw_get_green_inv_sv(self.h, sv.ctypes.data_as(_lib._DP)), host=True)
         return sv
 
+    def save_state(self, path):
+        """checkpoint of the whole replica object (all chains if this is a view of a batch)"""
+        check(self.lib.detsdw_save_state(self.h, str(path).encode()), host=True)
+
+    def load_state(self, path):
+        check(self.lib.detsdw_load_state(self.h, str(path).encode()), host=True)
+
     def saveConfigurationStreamBinary(self, directory="."):
         """appends to <directory>/configs-phi.binarystream (reference format, src/detsdwopdim.cpp:4991-5012)"""
         self._sel()
@@ -447,6 +454,12 @@ class DetSDWBatch:
 
     def sweepThermalization(self):
         check(self.lib.detsdw_sweep_thermalization(self.h), host=True)
+
+    def save_state(self, path):
+        check(self.lib.detsdw_save_state(self.h, str(path).encode()), host=True)
+
+    def load_state(self, path):
+        check(self.lib.detsdw_load_state(self.h, str(path).encode()), host=True)
 
     @property
     def kernel_context(self):

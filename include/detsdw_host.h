@@ -136,6 +136,14 @@ dqmc_ctx* detsdw_ctx(detsdw_replica* r);
  * format its evaluation tools (sdwcorr, deteval) read */
 int detsdw_save_configuration_stream_binary(detsdw_replica* r, const char* directory);
 
+/* Checkpoint / resume: field configurations, RNG stream positions, step-size adaptation state and update statistics of
+ * every chain (what the reference keeps in simulation.state, src/detsdwopdim.h:1127-1148, src/rngwrapper.h:100-116; own
+ * binary format).  detsdw_load_state needs a replica created with the same parameters; it rebuilds UdV storage and
+ * G(beta) like the reference's resume does, i.e. the next sweep is a down sweep -- a checkpoint written after an even
+ * number of sweeps continues exactly the uninterrupted Markov chain. */
+int detsdw_save_state(detsdw_replica* r, const char* path);
+int detsdw_load_state(detsdw_replica* r, const char* path);
+
 /* replica-exchange surface (src/detsdwopdim.h:116-153, src/detsdwopdim.cpp:5185-5247) */
 double detsdw_get_exchange_parameter_value(detsdw_replica* r);
 int detsdw_set_exchange_parameter_value(detsdw_replica* r, double value);

@@ -764,3 +764,46 @@ def test_fermionic_measurements_in_a_batch():
         assert np.array_equal(batch.chain(1).observable_vector(key), single.observable_vector(key))
     single.close()
     batch.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint / resume
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("batched", [False, True])
+def test_checkpoint_resume_continues_the_same_chain(tmp_path, batched):
+    """state saved after an even number of sweeps; a fresh replica that loads it walks exactly the chain of the
+    uninterrupted run (fields, step size, update statistics, RNG position), here with global moves every 2 sweeps"""
+    import dataclasses
+    from detqmc_amd import DetSDW, DetSDWBatch, DqmcError
+    g = load_golden("o2_L4_wolff")
+    p0 = _sdw_params(g["params"], stabilisation="qr", globalUpdateInterval=2)
+    plist = [p0, dataclasses.replace(p0, simindex=4, r=-0.8)] if batched else [p0]
+    make = (lambda: DetSDWBatch(plist)) if batched else (lambda: DetSDW(p0))
+    chains = (lambda rep: rep.chains) if batched else (lambda rep: [rep])
+    a = make()
+    for _ in range(4):
+        a.sweepThermalization()
+    ck = tmp_path / "state.ckpt"
+    a.save_state(ck)
+    for _ in range(4):
+        a.sweepThermalization()
+    b = make()
+    b.load_state(ck)
+    assert chains(b)[0].info.performedSweeps == 4
+    for _ in range(4):
+        b.sweepThermalization()
+    for ca, cb in zip(chains(a), chains(b)):
+        assert np.array_equal(ca.phi, cb.phi)
+        ia, ib = ca.info, cb.info
+        assert ia.phiDelta == ib.phiDelta and ia.rngDrawn == ib.rngDrawn
+        assert ia.acceptedGlobalShifts == ib.acceptedGlobalShifts and ia.acceptedWolffClusterUpdates == ib.acceptedWolffClusterUpdates
+        assert ia.addedWolffClusterSize == ib.addedWolffClusterSize
+        assert relerr(cb.g, ca.g) < TOL
+        assert ca.rand01() == cb.rand01()
+    # a replica with other parameters refuses the file
+    other = DetSDW(dataclasses.replace(p0, u=p0.u + 0.5))
+    with pytest.raises(DqmcError):
+        other.load_state(ck)
+    other.close()
+    a.close()
+    b.close()
