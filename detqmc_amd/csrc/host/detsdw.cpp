@@ -243,13 +243,24 @@ void DetSDW::finishFermionic(int b) {
     const std::string bc(c.pars.bc[0] ? c.pars.bc : "pbc");
     const double offx = (bc == "apbc-x" || bc == "apbc-xy") ? 0.5 : 0.0, offy = (bc == "apbc-y" || bc == "apbc-xy") ? 0.5 : 0.0;
     const double pi = M_PI;
+    // e^{i (kx dx + ky dy)} = e^{i kx dx} e^{i ky dy}: two small tables instead of a cos/sin per (k, bin)
+    std::vector<double> ex((size_t)L * W * 2), ey((size_t)L * W * 2);
+    for (int kk = 0; kk < L; ++kk) {
+        const double kx = -pi + (double(kk) + offx) * 2 * pi / double(L), ky = -pi + (double(kk) + offy) * 2 * pi / double(L);
+        for (int d = 0; d < W; ++d) {
+            const int dd = d - (L - 1);
+            ex[((size_t)kk * W + d) * 2] = std::cos(kx * dd); ex[((size_t)kk * W + d) * 2 + 1] = std::sin(kx * dd);
+            ey[((size_t)kk * W + d) * 2] = std::cos(ky * dd); ey[((size_t)kk * W + d) * 2 + 1] = std::sin(ky * dd);
+        }
+    }
     for (int ksite = 0; ksite < N; ++ksite) {
-        const double ky = -pi + (double(ksite / L) + offy) * 2 * pi / double(L);
-        const double kx = -pi + (double(ksite % L) + offx) * 2 * pi / double(L);
+        const double* tx = &ex[(size_t)(ksite % L) * W * 2];
+        const double* ty = &ey[(size_t)(ksite / L) * W * 2];
         double sx = 0.0, sy = 0.0;
         for (int bin = 0; bin < nbins; ++bin) {
-            const int dx = bin % W - (L - 1), dy = bin / W - (L - 1);
-            const double arg = kx * dx + ky * dy, cs = std::cos(arg), sn = std::sin(arg);
+            const int ix = bin % W, iy = bin / W;
+            const double cs = tx[2 * ix] * ty[2 * iy] - tx[2 * ix + 1] * ty[2 * iy + 1];
+            const double sn = tx[2 * ix] * ty[2 * iy + 1] + tx[2 * ix + 1] * ty[2 * iy];
             sx += cs * S[0][2 * bin] - sn * S[0][2 * bin + 1];
             sy += cs * S[1][2 * bin] - sn * S[1][2 * bin + 1];
         }

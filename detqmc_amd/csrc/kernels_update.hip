@@ -24,6 +24,7 @@
 // The decision kernel is ONE wavefront: the chain of decisions is strictly sequential, all
 // cross-lane traffic is wave shuffles / a tiny LDS scratch, and no workgroup barrier is ever needed.
 #include "dqmc_internal.h"
+#include <mutex>
 
 __device__ __forceinline__ cplx u_cfma(cplx a, cplx b, cplx c) {
     c.x = fma(a.x, b.x, c.x); c.x = fma(-a.y, b.y, c.x);
@@ -647,7 +648,13 @@ void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevMod
     const int WD = hm.MSF * hm.D;
     size_t lds = ((size_t)WD * (WD + 1) + 6 * (size_t)hm.MSF * WD) * sizeof(cplx) + (size_t)hm.opdim * hm.N * sizeof(double);
     if (lds > 48 * 1024) {     // deep delay blocks: raise the dynamic LDS limit of the instantiation to what is needed
-        static size_t raised[4] = {0, 0, 0, 0};
+        // the attribute belongs to (function, device); several contexts / host threads may get here at once
+        static std::mutex mu;
+        static size_t raised_tab[64][4] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        size_t* raised = raised_tab[dev & 63];
         if (lds > raised[hm.opdim]) {
             const void* f = hm.opdim == 1 ? (const void*)k_update_decide<1> : hm.opdim == 2 ? (const void*)k_update_decide<2>
                                                                                            : (const void*)k_update_decide<3>;
