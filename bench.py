@@ -181,17 +181,27 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
     dist = None
     torch = None
+    # DQMC_BENCH_BACKEND=gloo + DQMC_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank control flow on a one-GPU box
+    # (all ranks drive device 0, the ranks themselves stay off the GPU); the real runs use nccl (= RCCL)
+    backend = os.environ.get("DQMC_BENCH_BACKEND", "nccl")
+    if os.environ.get("DQMC_BENCH_ONE_DEVICE"):
+        local = 0
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     def fence():
         if dist is not None:
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
 
     R = 1 if a.inprocess else max(1, a.workers)
     B = max(1, a.batch)
@@ -235,7 +245,7 @@ def main():
     for p in procs:
         p.wait()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
