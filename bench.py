@@ -329,6 +329,18 @@ def main():
             roofs.append(hbm("flush", "k_flush (G += X Gr)", *prof["flush"], 2 * 16.0 * n * n,
                              "read-modify-write of G once per delayed-update block that accepted an update; the launches of the "
                              "other blocks exit at once", nblocks))
+            # HBM bytes of k_flush from the PMC counters (collected separately, profiles/r01_pmc_flush_*.json: FETCH_SIZE and
+            # WRITE_SIZE passes, FETCH doubled as MI355X_MICROARCH.md prescribes), per launch that had work, if the file
+            # was taken with this run's chains per launch and delaySteps
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_flush_b%d_d%d.json" % (B, D))
+            if os.path.exists(pmc):
+                try:
+                    for r_ in roofs:
+                        if r_["family"] == "flush":
+                            r_["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch_with_work"]
+                            r_["traffic_note"] = "per launch with work, rocprofv3 --pmc, " + os.path.basename(pmc)
+                except Exception:
+                    pass
             gms, gl = prof["gemm"]
             tf = prof["gemm_flops"] / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
             roofs.append({"family": "gemm", "kernel": "k_zgemm<2,2>", "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF,
