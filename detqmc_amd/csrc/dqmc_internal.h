@@ -103,6 +103,7 @@ struct GemmArgs {
     const double* rowscale;     // optional epilogue: acc *= rowscale[i] * colscale[j]
     const double* colscale;
     int accumulate;             // C += instead of C =
+    int negate;                 // the product enters with a minus sign (C -= A B with accumulate)
     int sharedA, sharedB;       // operand is one matrix for all chains (not shifted by the chain stride)
 };
 void launch_gemm(const Launch& lc, const GemmArgs& a);

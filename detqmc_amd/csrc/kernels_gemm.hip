@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
                 if (gi < g.M && gj < g.N) {
                     double re = acc_re[a][b][r], im = acc_im[a][b][r];
                     if (g.rowscale) { double sc = g.rowscale[gi] * g.colscale[gj]; re *= sc; im *= sc; }
+                    if (g.negate) { re = -re; im = -im; }
                     size_t off = (size_t)gj * g.ldc + gi;
                     if (g.accumulate) { cplx c = g.C[off]; re += c.x; im += c.y; }
                     g.C[off] = make_double2(re, im);

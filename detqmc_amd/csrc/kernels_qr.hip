@@ -630,11 +630,12 @@ int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const 
     for (int j0 = 0; j0 < n; j0 += TRSM_NB) {
         const int nb = (n - j0 < TRSM_NB) ? (n - j0) : TRSM_NB;
         if (j0 > 0) {
-            // C_J += Y_{<J} (-R_{<J,J})
-            hipLaunchKernelGGL(k_negate_copy_block, dim3((j0 * nb + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st,
-                               R + (size_t)j0 * n, n, j0, nb, w.Rneg, n, lc.cs);
-            gemm_small(lc, 0, 0, C, n, w.Rneg, n, C + (size_t)j0 * n, n, n, nb, j0, 1);
-            launches += 2;
+            // C_J -= Y_{<J} R_{<J,J}
+            GemmArgs g = GemmArgs();
+            g.A = C; g.lda = n; g.opA = 0; g.B = R + (size_t)j0 * n; g.ldb = n; g.opB = 0; g.C = C + (size_t)j0 * n; g.ldc = n;
+            g.M = n; g.N = nb; g.K = j0; g.Kmul = 1; g.accumulate = 1; g.negate = 1;
+            launch_gemm(lc, g);
+            launches += 1;
         }
         hipLaunchKernelGGL(k_trsm_block, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, C, n, R, n, n, j0, nb, lc.cs);
         ++launches;
