@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     constexpr int NIT = (NITEMS + 63) / 64;
     static_assert(O_GCC % 2 == 0, "complex items must be 16-byte aligned in LDS");
     __shared__ __attribute__((aligned(16))) double scand[NIT * 64];
+    __shared__ __attribute__((aligned(16))) double sdec[4 * MSF * MSF + 2];   // wave 0 -> all: delta, G[c,c], exp(-dS), uniform
 
     auto neighbours = [&](int s, int (&nbr)[4]) {
         // neighbortable.h:34-36 (XPLUS, XMINUS, YPLUS, YMINUS), computed: a table look-up would put a dependent
@@ -342,35 +343,21 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         // ---- C: start the loads of the NEXT candidate now; they complete while this decision is computed ----
         const bool have_next = (site + 1 < N);
         if (have_next && !(dm.dbg & 1)) fetch(pre, pu, pv, site + 1, site, cur + OPDIM, nI);
-        // ---- every thread picks up the candidate's scalars (broadcast LDS reads) ----
+        // ---- the waves split the work between the two barriers: wave 0 does the scalar Metropolis arithmetic of this
+        //      proposal (D) and hands delta, exp(-dS), the acceptance uniform and G[c,c] to the others through LDS; waves
+        //      1-3 meanwhile form p and q (E).  Neither waits for the other before barrier 2. ----
         // uniforms: skip the one the previous decision consumed for its acceptance test
         const int uoff = (prev_site >= 0 && prev_used_uniform) ? 1 : 0;
-        int nbr[4];
-        neighbours(site, nbr);
-        double oldphi[OPDIM], newphi[OPDIM], snb[OPDIM], tnb[OPDIM];
+        double newphi[OPDIM], coshN = 0.0, sinhN = 0.0;
 #pragma unroll
-        for (int d = 0; d < OPDIM; ++d) {
-            oldphi[d] = sphi[d * N + site];
-            double low = -phiDelta, high = phiDelta;
-            newphi[d] = propose_component(oldphi[d], low, high, scand[O_UNI + uoff + d]);
-            // XPLUS, XMINUS, YPLUS, YMINUS in the order of the reference's neighbour loop (:4208-4214)
-            snb[d] = ((0.0 + sphi[d * N + nbr[0]]) + sphi[d * N + nbr[1]]) + sphi[d * N + nbr[2]] + sphi[d * N + nbr[3]];
-            tnb[d] = scand[O_TL + d] + scand[O_TE + d];
-        }
-        const double uacc = scand[O_UNI + uoff + OPDIM];
-        const double coshO = scand[O_CH], sinhO = scand[O_SH];
-        cplx Gcc[MSF][MSF];
-#pragma unroll
-        for (int a = 0; a < MSF; ++a)
-#pragma unroll
-            for (int b = 0; b < MSF; ++b) Gcc[a][b] = *(const cplx*)&scand[O_GCC + 2 * (a * MSF + b)];
+        for (int d = 0; d < OPDIM; ++d) newphi[d] = 0.0;
         cur += OPDIM;
         TICK(2);
-        // ---- E: p = W v and, speculatively (needed only on acceptance), q = u W.  Work item = one dot product
-        //      split over a quad of lanes; items [0, nI MSF) are p(i, b), items [nI MSF, 2 nI MSF) are q(a, i). ----
-        {
+        if (tid >= 64) {
+            // ---- E: p = W v and, speculatively (needed only on acceptance), q = u W.  Work item = one dot product
+            //      split over a quad of lanes; items [0, nI MSF) are p(i, b), items [nI MSF, 2 nI MSF) are q(a, i). ----
             const int nitems = (dm.dbg & 2) ? 0 : 2 * nI * MSF;
-            for (int t = tid; t < 4 * nitems; t += 256) {
+            for (int t = tid - 64; t < 4 * nitems; t += 192) {
                 int item = t >> 2, part = t & 3;
                 cplx acc = make_double2(0.0, 0.0);
                 cplx* dst;
@@ -381,7 +368,10 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                     dst = sp + i * MSF + b;
                 } else {
                     int it2 = item - nI * MSF;
-                    int a = it2 / nI, i = it2 - a * nI;
+                    int a = 0;
+#pragma unroll
+                    for (int q = 1; q < MSF; ++q) a += (it2 >= q * nI) ? 1 : 0;
+                    const int i = it2 - a * nI;
                     for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(su[a * WD + i2], W[i2 * WS + i], acc);
                     dst = sq + a * WD + i;
                 }
@@ -389,70 +379,100 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 acc.x = u_dpp_add<0x4E, 0xf>(acc.x); acc.y = u_dpp_add<0x4E, 0xf>(acc.y);
                 if (part == 0) *dst = acc;
             }
-        }
-        TICK(3);
-        // ---- D: bosonic action (deltaSPhi, :4186-4239) and delta (get_delta_forsite, :3179-3289) ----
-        double dsphi;
-        {
-            double oldSq = 0.0, newSq = 0.0;
+        } else {
+            // ---- D (wave 0): the candidate's scalars (broadcast LDS reads), bosonic action (deltaSPhi, :4186-4239)
+            //      and delta (get_delta_forsite, :3179-3289) ----
+            int nbr[4];
+            neighbours(site, nbr);
+            double oldphi[OPDIM], snb[OPDIM], tnb[OPDIM];
 #pragma unroll
-            for (int d = 0; d < OPDIM; ++d) { oldSq += oldphi[d] * oldphi[d]; newSq += newphi[d] * newphi[d]; }
-            double phiSqDiff = newSq - oldSq;
-            if (dm.phi2bosons) {
-                dsphi = dm.dtau * 0.5 * dm.r * phiSqDiff;
-            } else {
-                double phiPow4Diff = newSq * newSq - oldSq * oldSq;
-                double dotTime = 0.0, dotSpace = 0.0;
-#pragma unroll
-                for (int d = 0; d < OPDIM; ++d) {
-                    double diff = newphi[d] - oldphi[d];
-                    dotTime += tnb[d] * diff;
-                    dotSpace += snb[d] * diff;
-                }
-                double delta1 = (1.0 / (dm.c * dm.c * dm.dtau)) * (phiSqDiff - dotTime);
-                double delta2 = 0.5 * dm.dtau * (4.0 * phiSqDiff - 2.0 * dotSpace);
-                double delta3 = dm.dtau * (0.5 * dm.r * phiSqDiff + 0.25 * dm.u * phiPow4Diff);
-                dsphi = delta1 + delta2 + delta3;
+            for (int d = 0; d < OPDIM; ++d) {
+                oldphi[d] = sphi[d * N + site];
+                double low = -phiDelta, high = phiDelta;
+                newphi[d] = propose_component(oldphi[d], low, high, scand[O_UNI + uoff + d]);
+                // XPLUS, XMINUS, YPLUS, YMINUS in the order of the reference's neighbour loop (:4208-4214)
+                snb[d] = ((0.0 + sphi[d * N + nbr[0]]) + sphi[d * N + nbr[1]]) + sphi[d * N + nbr[2]] + sphi[d * N + nbr[3]];
+                tnb[d] = scand[O_TL + d] + scand[O_TE + d];
             }
-        }
-        double probSPhi, coshN, sinhN;
-        {
-            double nn = 0.0;
+            const double coshO = scand[O_CH], sinhO = scand[O_SH];
+            double dsphi;
+            {
+                double oldSq = 0.0, newSq = 0.0;
 #pragma unroll
-            for (int d = 0; d < OPDIM; ++d) nn += newphi[d] * newphi[d];
-            double nrm = sqrt(nn);
-            double arg = dm.lambda * dm.dtau * nrm;
-            // the wave evaluates ONE exp sequence: lane 0 on -dS, the other lanes on arg
-            double ex = (dm.dbg & 4) ? 1.0 + (lane == 0 ? -dsphi : arg) : exp(lane == 0 ? -dsphi : arg);
-            int lo = __builtin_amdgcn_readlane(__double2loint(ex), 0), hi = __builtin_amdgcn_readlane(__double2hiint(ex), 0);
-            probSPhi = __hiloint2double(hi, lo);
-            lo = __builtin_amdgcn_readlane(__double2loint(ex), 1); hi = __builtin_amdgcn_readlane(__double2hiint(ex), 1);
-            double ea = __hiloint2double(hi, lo), iea = 1.0 / ea;
-            coshN = 0.5 * (ea + iea);
-            // sinh(a)/|phi|: for small a the difference e^a - e^-a cancels, use the series there
-            double sh = (arg > 0.25) ? 0.5 * (ea - iea)
-                                     : arg * (1.0 + arg * arg * (1.0 / 6.0 + arg * arg * (1.0 / 120.0 + arg * arg *
-                                              (1.0 / 5040.0 + arg * arg * (1.0 / 362880.0 + arg * arg * (1.0 / 39916800.0))))));
-            sinhN = sh / nrm;
-        }
-        cplx delta[MSF][MSF];
-        {
+                for (int d = 0; d < OPDIM; ++d) { oldSq += oldphi[d] * oldphi[d]; newSq += newphi[d] * newphi[d]; }
+                double phiSqDiff = newSq - oldSq;
+                if (dm.phi2bosons) {
+                    dsphi = dm.dtau * 0.5 * dm.r * phiSqDiff;
+                } else {
+                    double phiPow4Diff = newSq * newSq - oldSq * oldSq;
+                    double dotTime = 0.0, dotSpace = 0.0;
+#pragma unroll
+                    for (int d = 0; d < OPDIM; ++d) {
+                        double diff = newphi[d] - oldphi[d];
+                        dotTime += tnb[d] * diff;
+                        dotSpace += snb[d] * diff;
+                    }
+                    double delta1 = (1.0 / (dm.c * dm.c * dm.dtau)) * (phiSqDiff - dotTime);
+                    double delta2 = 0.5 * dm.dtau * (4.0 * phiSqDiff - 2.0 * dotSpace);
+                    double delta3 = dm.dtau * (0.5 * dm.r * phiSqDiff + 0.25 * dm.u * phiPow4Diff);
+                    dsphi = delta1 + delta2 + delta3;
+                }
+            }
+            double probSPhi;
+            {
+                double nn = 0.0;
+#pragma unroll
+                for (int d = 0; d < OPDIM; ++d) nn += newphi[d] * newphi[d];
+                double nrm = sqrt(nn);
+                double arg = dm.lambda * dm.dtau * nrm;
+                // the wave evaluates ONE exp sequence: lane 0 on -dS, the other lanes on arg
+                double ex = (dm.dbg & 4) ? 1.0 + (lane == 0 ? -dsphi : arg) : exp(lane == 0 ? -dsphi : arg);
+                int lo = __builtin_amdgcn_readlane(__double2loint(ex), 0), hi = __builtin_amdgcn_readlane(__double2hiint(ex), 0);
+                probSPhi = __hiloint2double(hi, lo);
+                lo = __builtin_amdgcn_readlane(__double2loint(ex), 1); hi = __builtin_amdgcn_readlane(__double2hiint(ex), 1);
+                double ea = __hiloint2double(hi, lo), iea = 1.0 / ea;
+                coshN = 0.5 * (ea + iea);
+                // sinh(a)/|phi|: for small a the difference e^a - e^-a cancels, use the series there
+                double sh = (arg > 0.25) ? 0.5 * (ea - iea)
+                                         : arg * (1.0 + arg * arg * (1.0 / 6.0 + arg * arg * (1.0 / 120.0 + arg * arg *
+                                                  (1.0 / 5040.0 + arg * arg * (1.0 / 362880.0 + arg * arg * (1.0 / 39916800.0))))));
+                sinhN = sh / nrm;
+            }
             cplx evOld[MSF][MSF], emvNew[MSF][MSF];
             ev_matrix<MSF>(evOld, +1.0, oldphi, OPDIM, coshO, sinhO);
             ev_matrix<MSF>(emvNew, -1.0, newphi, OPDIM, coshN, sinhN);
+            if (tid < MSF * MSF) {             // lane (a, b) publishes delta[a][b] and G[c,c][a][b]
+                cplx dsel = make_double2(0.0, 0.0);
 #pragma unroll
-            for (int a = 0; a < MSF; ++a)
+                for (int a = 0; a < MSF; ++a)
 #pragma unroll
-                for (int b = 0; b < MSF; ++b) {
-                    cplx acc = make_double2(a == b ? -1.0 : 0.0, 0.0);
+                    for (int b = 0; b < MSF; ++b) {
+                        cplx acc = make_double2(a == b ? -1.0 : 0.0, 0.0);
 #pragma unroll
-                    for (int q = 0; q < MSF; ++q) acc = u_cfma(emvNew[a][q], evOld[q][b], acc);
-                    delta[a][b] = acc;
-                }
+                        for (int q = 0; q < MSF; ++q) acc = u_cfma(emvNew[a][q], evOld[q][b], acc);
+                        if (tid == a * MSF + b) dsel = acc;
+                    }
+                *(cplx*)&sdec[2 * tid] = dsel;
+                *(cplx*)&sdec[2 * MSF * MSF + 2 * tid] = *(const cplx*)&scand[O_GCC + 2 * tid];
+            }
+            if (tid == 0) {
+                sdec[4 * MSF * MSF] = probSPhi;
+                sdec[4 * MSF * MSF + 1] = scand[O_UNI + uoff + OPDIM];
+            }
         }
         TICK(4);
         __syncthreads();                              // barrier 2 of 2: p, q visible
         TICK(5);
+        // ---- every thread picks up what wave 0 published ----
+        cplx delta[MSF][MSF], Gcc[MSF][MSF];
+#pragma unroll
+        for (int a = 0; a < MSF; ++a)
+#pragma unroll
+            for (int b = 0; b < MSF; ++b) {
+                delta[a][b] = *(const cplx*)&sdec[2 * (a * MSF + b)];
+                Gcc[a][b] = *(const cplx*)&sdec[2 * MSF * MSF + 2 * (a * MSF + b)];
+            }
+        const double probSPhi = sdec[4 * MSF * MSF], uacc = sdec[4 * MSF * MSF + 1];
         // ---- G: S = Gcc + u p ----
         cplx S[MSF][MSF];
         if (MSF == 2) {
