@@ -109,14 +109,19 @@ __device__ __forceinline__ cplx small_det_inv(const cplx (&Min)[MSF][MSF], cplx 
             double v = A[r][c].x * A[r][c].x + A[r][c].y * A[r][c].y;
             if (v > best) { best = v; piv = r; }
         }
-        if (piv != c) {
+        // row swap with compile-time indices only (a run-time row index would push the matrices into scratch memory)
+#pragma unroll
+        for (int r = c + 1; r < MSF; ++r) {
+            const bool sw = (piv == r);
 #pragma unroll
             for (int j = 0; j < MSF; ++j) {
-                cplx t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t;
-                t = Inv[c][j]; Inv[c][j] = Inv[piv][j]; Inv[piv][j] = t;
+                cplx t = A[c][j], u = A[r][j];
+                A[c][j] = sw ? u : t; A[r][j] = sw ? t : u;
+                t = Inv[c][j]; u = Inv[r][j];
+                Inv[c][j] = sw ? u : t; Inv[r][j] = sw ? t : u;
             }
-            det = make_double2(-det.x, -det.y);
         }
+        if (piv != c) det = make_double2(-det.x, -det.y);
         cplx pv = A[c][c];
         det = u_cmul(det, pv);
         double dn = pv.x * pv.x + pv.y * pv.y;
