@@ -51,6 +51,11 @@ CASES = {
     "o3_L4_fmeas": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=1, measureSweeps=2, fermionMeas=1, sliceTrace=0)),
     "o1_L4_fmeas": dict(args=dict(opdim=1, L=4, beta=2, s=10, delaySteps=6, sweeps=1, measureSweeps=1, fermionMeas=1, sliceTrace=0,
                                   checkerboard=0)),
+    # headline size, longer: 6 sweeps with global shift moves every other sweep; fields as SHA-256, G as checksums
+    "o2_L16_b10_long": dict(args=dict(opdim=2, L=16, beta=10, s=10, delaySteps=16, sweeps=6, sliceTrace=0, globalShift=1,
+                                      globalUpdateInterval=2),
+                            drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi", "init_udv"),
+                            subsample=32, hash_fields=True),
     "o2_L6_seed": dict(args=dict(opdim=2, L=6, beta=3, s=10, delaySteps=8, sweeps=2, rngSeed=5555, simindex=3)),
     # checkerboard=false (CB_NONE): dense B = e^{-dtau V} e^{-dtau K}, inverse by arma::inv
     "o2_L4_dense": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, checkerboard=0)),
@@ -97,6 +102,12 @@ def run_case(name, spec):
                 arrays[nm + "_fro"] = np.array([np.linalg.norm(a)])
                 a = a[::ss, ::ss].copy()
                 nm = nm + f"_sub{ss}"
+            if spec.get("hash_fields") and dt != "c16" and a.ndim == 3 and nm.endswith("_phi"):
+                # long trajectories at the headline size: keep a SHA-256 of the field (raw bytes of the (N, OPDIM, m+1)
+                # column-major cube) instead of 400 KB per sweep
+                import hashlib
+                arrays[nm + "_sha256"] = np.frombuffer(hashlib.sha256(np.asfortranarray(a).tobytes(order="F")).digest(), dtype=np.uint8).copy()
+                continue
             arrays[nm] = np.ascontiguousarray(a)
         stream = os.path.join(td, "configs-phi.binarystream")
         if os.path.exists(stream):

@@ -807,3 +807,39 @@ def test_checkpoint_resume_continues_the_same_chain(tmp_path, batched):
     other.close()
     a.close()
     b.close()
+
+
+def test_headline_size_long_trajectory_batched_vs_reference():
+    """6 sweeps at L = 16, beta = 10 with global shift moves every other sweep, run the way bench.py runs (batched
+    replicas, QR stabilisation, delaySteps 32): chain 0 must reproduce the reference's field after EVERY sweep
+    (SHA-256 of the raw cube), its Green's function checksums and its global-move statistics."""
+    import dataclasses
+    import hashlib
+    from detqmc_amd import DetSDWBatch
+    g = load_golden("o2_L16_b10_long")
+    p0 = _sdw_params(g["params"], stabilisation="qr", delaySteps=32)
+    batch = DetSDWBatch([p0, dataclasses.replace(p0, simindex=11)])
+    c0 = batch.chain(0)
+
+    def sha(phi_kNd):
+        cube = np.asfortranarray(np.transpose(phi_kNd, (1, 2, 0)))          # (N, OPDIM, m+1) column-major, as dumped
+        return np.frombuffer(hashlib.sha256(cube.tobytes(order="F")).digest(), dtype=np.uint8)
+
+    assert g["init_phi_sha256"].size == 32
+    i = 1
+    while f"sweep{i}_phi_sha256" in g:
+        batch.sweepThermalization()
+        # the whole cube incl. the unused slice 0, which the global shift moves displace like every other slice
+        assert np.array_equal(sha(c0.phi), g[f"sweep{i}_phi_sha256"]), f"sweep {i}: field differs from the reference"
+        G = c0.g
+        assert relerr(G[::32, ::32], g[f"sweep{i}_g_sub32"]) < TOL
+        assert relerr(np.diag(G), g[f"sweep{i}_g_diag"]) < TOL
+        inf = c0.info
+        assert inf.phiDelta == g[f"sweep{i}_phiDelta"][0]
+        assert inf.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert inf.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+        i += 1
+    assert i == 7
+    nxt = np.array([c0.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"])
+    batch.close()
