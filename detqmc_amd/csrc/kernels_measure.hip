@@ -115,29 +115,44 @@ __global__ __launch_bounds__(256) void k_measure_accum(DevModel dm, const cplx* 
             acc[4 + N + i] += minus.x;
         }
     } else {
-        // S_band(dx, dy) bins for the momentum-space occupation (:616-659)
+        // S_band(dx, dy) bins for the momentum-space occupation (:616-659): 8 lanes per bin, each takes every 8th site,
+        // partial sums combined in a fixed order by DPP row shifts (lane 7 of the group ends up with the total)
         const int W = 2 * L - 1, nbins = W * W;
         const int idx = (role - 3) * 256 + tid;
-        if (idx >= 2 * nbins) return;
-        const int band = idx / nbins, bin = idx - band * nbins;
+        const int binlin = idx >> 3, part = idx & 7;
+        const bool valid = binlin < 2 * nbins;
+        const int band = valid ? binlin / nbins : 0, bin = valid ? binlin - band * nbins : 0;
         const int dx = bin % W - (L - 1), dy = bin / W - (L - 1);
         cplx s = make_double2(0.0, 0.0);
-        for (int i = 0; i < N; ++i) {
-            const int ix = i % L, iy = i / L;
-            const int jx = ix - dx, jy = iy - dy;
-            if (jx < 0 || jx >= L || jy < 0 || jy >= L) continue;
-            const int j = jy * L + jx;
-            s = m_add(s, m_add(gl(i, band, UP, j, band, UP), gl(i, band, DN, j, band, DN)));
+        if (valid)
+            for (int i = part; i < N; i += 8) {
+                const int ix = i % L, iy = i / L;
+                const int jx = ix - dx, jy = iy - dy;
+                if (jx < 0 || jx >= L || jy < 0 || jy >= L) continue;
+                const int j = jy * L + jx;
+                s = m_add(s, m_add(gl(i, band, UP, j, band, UP), gl(i, band, DN, j, band, DN)));
+            }
+        auto shr_add = [](double v, int ctrl_sel) {
+            int lo = __double2loint(v), hi = __double2hiint(v), lo2, hi2;
+            if (ctrl_sel == 1) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false); }
+            else if (ctrl_sel == 2) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, false); }
+            else { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, false); }
+            return v + __hiloint2double(hi2, lo2);
+        };
+        s.x = shr_add(s.x, 1); s.y = shr_add(s.y, 1);      // row_shr:1, 2, 4: lane l holds the sum of lanes l-7 .. l
+        s.x = shr_add(s.x, 2); s.y = shr_add(s.y, 2);
+        s.x = shr_add(s.x, 4); s.y = shr_add(s.y, 4);
+        if (valid && part == 7) {
+            double* S = acc + 4 + 2 * N + (size_t)band * 2 * nbins;
+            S[2 * bin] += s.x;
+            S[2 * bin + 1] += s.y;
         }
-        double* S = acc + 4 + 2 * N + (size_t)band * 2 * nbins;
-        S[2 * bin] += s.x;
-        S[2 * bin + 1] += s.y;
     }
 }
 
 void launch_measure_accum(const Launch& lc, const DevModel& hm, const cplx* gs, double* acc) {
     const int nbins = (2 * hm.L - 1) * (2 * hm.L - 1);
-    const dim3 grid(3 + (2 * nbins + 255) / 256, 1, lc.nb);
+    const dim3 grid(3 + (2 * nbins * 8 + 255) / 256, 1, lc.nb);
     if (hm.opdim == 1) hipLaunchKernelGGL((k_measure_accum<1>), grid, dim3(256), 0, lc.st, hm, gs, acc, lc.cs);
     else if (hm.opdim == 2) hipLaunchKernelGGL((k_measure_accum<2>), grid, dim3(256), 0, lc.st, hm, gs, acc, lc.cs);
     else hipLaunchKernelGGL((k_measure_accum<3>), grid, dim3(256), 0, lc.st, hm, gs, acc, lc.cs);
