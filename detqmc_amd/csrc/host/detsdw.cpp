@@ -17,6 +17,23 @@ void DetSDW::check(int rc, const char* what) {
     if (rc != DQMC_OK) throw GeneralError(rc, std::string(what) + ": " + dqmc_last_error());
 }
 
+// field-wise comparison of two normalised parameter sets (struct padding is not the caller's business); everything but
+// the exchange parameter r, the device and -- unless seeds_too -- the RNG stream identity
+static bool same_model(const detsdw_params& a, const detsdw_params& b, bool seeds_too) {
+    const bool ints = a.opdim == b.opdim && a.L == b.L && a.m == b.m && a.s == b.s && a.delaySteps == b.delaySteps &&
+                      a.globalShift == b.globalShift && a.globalUpdateInterval == b.globalUpdateInterval &&
+                      a.weakZflux == b.weakZflux && a.phi2bosons == b.phi2bosons && a.has_mux_muy == b.has_mux_muy &&
+                      a.updateMethod == b.updateMethod && a.stabilisation == b.stabilisation && a.cb_none == b.cb_none &&
+                      a.wolffClusterUpdate == b.wolffClusterUpdate && a.wolffClusterShiftUpdate == b.wolffClusterShiftUpdate &&
+                      a.repeatWolffPerSweep == b.repeatWolffPerSweep && a.fermionMeasurements == b.fermionMeasurements;
+    const bool reals = a.beta == b.beta && a.dtau == b.dtau && a.c == b.c && a.u == b.u && a.lambda == b.lambda &&
+                       a.txhor == b.txhor && a.txver == b.txver && a.tyhor == b.tyhor && a.tyver == b.tyver &&
+                       a.mu == b.mu && a.mux == b.mux && a.muy == b.muy && a.accRatio == b.accRatio && a.cdwU == b.cdwU;
+    const bool bc = std::strncmp(a.bc[0] ? a.bc : "pbc", b.bc[0] ? b.bc : "pbc", sizeof(a.bc)) == 0;
+    const bool seeds = !seeds_too || (a.rngSeed == b.rngSeed && a.simindex == b.simindex);
+    return ints && reals && bc && seeds;
+}
+
 void DetSDW::select(int b) {
     if (b < 0 || b >= (int)ch_.size()) throw ParameterWrong("chain index out of range");
     check(dqmc_select_chain(ctx_, b), "dqmc_select_chain");
@@ -74,9 +91,7 @@ DetSDW::DetSDW(const detsdw_params* in, int nchains) {
         if (b > 0) {
             // the chains of a batch are the replicas of ONE parallel-tempering ensemble: same lattice, same
             // temperature and couplings; they may differ in r (the exchange parameter) and in the RNG stream
-            detsdw_params a = ch_[0].pars, q = p;
-            a.r = q.r = 0.0; a.rngSeed = q.rngSeed = 0; a.simindex = q.simindex = 0;
-            if (std::memcmp(&a, &q, sizeof(a)) != 0)
+            if (!same_model(ch_[0].pars, p, /*seeds_too=*/false))
                 throw ParameterWrong("replicas of one batch may differ only in r, rngSeed and simindex");
         }
         ch_.emplace_back(p);
@@ -634,9 +649,8 @@ void DetSDW::loadState(const std::string& path) {
         Chain& c = ch_[b];
         detsdw_params p; detsdw_control_data cd;
         rd(fc.f, &p, sizeof(p)); rd(fc.f, &cd, sizeof(cd));
-        detsdw_params a = p, q = c.pars;
-        a.r = q.r = 0.0; a.device = q.device = 0;               // r is restored from the file; the device may differ
-        if (std::memcmp(&a, &q, sizeof(a)) != 0) throw GeneralError(DQMC_EINVAL, "checkpoint: parameters differ from this replica's");
+        // r is restored from the file; the device may differ
+        if (!same_model(p, c.pars, /*seeds_too=*/true)) throw GeneralError(DQMC_EINVAL, "checkpoint: parameters differ from this replica's");
         uint64_t nr = 0, np = 0;
         rd(fc.f, &nr, 8);
         if (nr < DSFMT19937::state_words() + 3 || nr > (1u << 26)) throw GeneralError(DQMC_EINVAL, "checkpoint: bad RNG record");
