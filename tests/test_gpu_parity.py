@@ -843,3 +843,16 @@ def test_headline_size_long_trajectory_batched_vs_reference():
     nxt = np.array([c0.rand01() for _ in range(4)])
     assert np.array_equal(nxt, g["rng_next"])
     batch.close()
+
+
+def test_o3_deepest_delay_blocks_vs_reference():
+    """O(3) with MSF * delaySteps = 64 (the largest W the decision kernel holds: > 64 KiB of dynamic LDS, raised per
+    instantiation) against the fixture the reference produced with delaySteps = 12"""
+    from detqmc_amd import DetSDW
+    g = load_golden("o3_L6")
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr", delaySteps=16))
+    for i in (1, 2):
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}"
+        _check_subsampled(rep.g, g, f"sweep{i}", 4)
+    rep.close()
