@@ -682,6 +682,9 @@ using detqmc::DetSDW;
 struct detsdw_replica { DetSDW* impl; int sel; };   // sel: chain the per-replica calls refer to
 static thread_local std::string g_host_err;
 
+#define RGUARD(...)                                                                          \
+    if (!r) { g_host_err = "null replica handle"; return DQMC_EINVAL; }                      \
+    GUARD(__VA_ARGS__)
 #define GUARD(...)                                                          \
     try { __VA_ARGS__; return DQMC_OK; }                                            \
     catch (const detqmc::GeneralError& e) { g_host_err = e.what(); return e.code; } \
@@ -706,40 +709,40 @@ extern "C" int detsdw_select_chain(detsdw_replica* r, int chain) {
     return DQMC_OK;
 }
 extern "C" void detsdw_destroy(detsdw_replica* r) { if (r) { delete r->impl; delete r; } }
-extern "C" int detsdw_sweep(detsdw_replica* r, int tm) { GUARD(r->impl->sweep(tm != 0)) }
-extern "C" int detsdw_sweep_thermalization(detsdw_replica* r) { GUARD(r->impl->sweepThermalization()) }
-extern "C" int detsdw_get_info(detsdw_replica* r, detsdw_info* out) { GUARD(r->impl->getInfo(*out, r->sel)) }
+extern "C" int detsdw_sweep(detsdw_replica* r, int tm) { RGUARD(r->impl->sweep(tm != 0)) }
+extern "C" int detsdw_sweep_thermalization(detsdw_replica* r) { RGUARD(r->impl->sweepThermalization()) }
+extern "C" int detsdw_get_info(detsdw_replica* r, detsdw_info* out) { RGUARD(r->impl->getInfo(*out, r->sel)) }
 extern "C" int detsdw_get_observables(detsdw_replica* r, detsdw_observables* out) {
-    GUARD(r->impl->getObservables(*out, r->sel))
+    RGUARD(r->impl->getObservables(*out, r->sel))
 }
 extern "C" int detsdw_get_observable_vector(detsdw_replica* r, int which, double* out) {
-    GUARD(r->impl->getObservableVector(which, out, r->sel))
+    RGUARD(r->impl->getObservableVector(which, out, r->sel))
 }
-extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { GUARD(r->impl->getPhi(phi, r->sel)) }
-extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { GUARD(r->impl->setPhi(phi, r->sel)) }
-extern "C" int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g) { GUARD(r->impl->getGreen(g, r->sel)) }
-extern "C" int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv) { GUARD(r->impl->getGreenInvSv(sv, r->sel)) }
+extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { RGUARD(r->impl->getPhi(phi, r->sel)) }
+extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { RGUARD(r->impl->setPhi(phi, r->sel)) }
+extern "C" int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g) { RGUARD(r->impl->getGreen(g, r->sel)) }
+extern "C" int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv) { RGUARD(r->impl->getGreenInvSv(sv, r->sel)) }
 extern "C" int detsdw_save_state(detsdw_replica* r, const char* path) {
     if (!path) { g_host_err = "null path"; return DQMC_EINVAL; }
-    GUARD(r->impl->saveState(path))
+    RGUARD(r->impl->saveState(path))
 }
 extern "C" int detsdw_load_state(detsdw_replica* r, const char* path) {
     if (!path) { g_host_err = "null path"; return DQMC_EINVAL; }
-    GUARD(r->impl->loadState(path))
+    RGUARD(r->impl->loadState(path))
 }
 extern "C" int detsdw_save_configuration_stream_binary(detsdw_replica* r, const char* directory) {
-    GUARD(r->impl->saveConfigurationStreamBinary(directory ? directory : ".", r->sel))
+    RGUARD(r->impl->saveConfigurationStreamBinary(directory ? directory : ".", r->sel))
 }
-extern "C" double detsdw_rng_rand01(detsdw_replica* r) { return r->impl->rand01(r->sel); }
+extern "C" double detsdw_rng_rand01(detsdw_replica* r) { return r ? r->impl->rand01(r->sel) : -1.0; }
 extern "C" dqmc_ctx* detsdw_ctx(detsdw_replica* r) { return r ? r->impl->ctx() : nullptr; }
-extern "C" double detsdw_get_exchange_parameter_value(detsdw_replica* r) { return r->impl->get_exchange_parameter_value(r->sel); }
-extern "C" int detsdw_set_exchange_parameter_value(detsdw_replica* r, double v) { GUARD(r->impl->set_exchange_parameter_value(v, r->sel)) }
-extern "C" const char* detsdw_get_exchange_parameter_name(detsdw_replica* r) { return r->impl->get_exchange_parameter_name(); }
+extern "C" double detsdw_get_exchange_parameter_value(detsdw_replica* r) { return r ? r->impl->get_exchange_parameter_value(r->sel) : 0.0; }
+extern "C" int detsdw_set_exchange_parameter_value(detsdw_replica* r, double v) { RGUARD(r->impl->set_exchange_parameter_value(v, r->sel)) }
+extern "C" const char* detsdw_get_exchange_parameter_name(detsdw_replica* r) { return r ? r->impl->get_exchange_parameter_name() : ""; }
 extern "C" int detsdw_get_exchange_action_contribution(detsdw_replica* r, double* out) {
-    GUARD(*out = r->impl->get_exchange_action_contribution(r->sel))
+    RGUARD(*out = r->impl->get_exchange_action_contribution(r->sel))
 }
-extern "C" int detsdw_get_control_data(detsdw_replica* r, detsdw_control_data* out) { GUARD(r->impl->get_control_data(*out, r->sel)) }
-extern "C" int detsdw_set_control_data(detsdw_replica* r, const detsdw_control_data* in) { GUARD(r->impl->set_control_data(*in, r->sel)) }
+extern "C" int detsdw_get_control_data(detsdw_replica* r, detsdw_control_data* out) { RGUARD(r->impl->get_control_data(*out, r->sel)) }
+extern "C" int detsdw_set_control_data(detsdw_replica* r, const detsdw_control_data* in) { RGUARD(r->impl->set_control_data(*in, r->sel)) }
 // detsdwopdim.cpp:5251-5264 (Hukushima & Nemoto 1996)
 extern "C" double detsdw_replica_exchange_probability(double par1, double action1, double par2, double action2) {
     const double delta = (par1 - par2) * (action2 - action1);

@@ -86,3 +86,14 @@ def test_product_does_not_import_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "detsdw_oracle" not in txt and "dsfmt_oracle" not in txt, f
                 assert "oracle/" not in txt.replace("oracle/_ref", ""), f
+
+
+def test_null_replica_handle_is_rejected(lib):
+    import ctypes as C
+    from detqmc_amd._lib import detsdw_info
+    info = detsdw_info()
+    assert lib.detsdw_get_info(None, C.byref(info)) == -1
+    assert lib.detsdw_sweep(None, 0) == -1
+    assert lib.detsdw_save_state(None, b"/tmp/x") == -1
+    assert b"null" in lib.detsdw_last_error()
+    assert lib.detsdw_num_chains(None) == 0
