@@ -378,7 +378,8 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     if (p->stabilisation != DQMC_STAB_SVD && p->stabilisation != DQMC_STAB_QR) return fail(DQMC_EINVAL, "stabilisation");
     if (!(p->dtau > 0)) return fail(DQMC_EINVAL, "dtau");
     const int ng = MSF * N;
-    if (ng > 2304) return fail(DQMC_EINVAL, "n_g > 2304 not supported by the Jacobi kernel instantiations");
+    if (p->stabilisation == DQMC_STAB_SVD && ng > 2304) return fail(DQMC_EINVAL, "n_g > 2304 not supported by the Jacobi kernel instantiations");
+    if (ng > 4096) return fail(DQMC_EINVAL, "n_g > 4096 not supported by the QR panel kernel instantiations");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DQMC_ENODEV, "no HIP device available");
@@ -474,7 +475,6 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     }
     c->stab = p->stabilisation;
     if (c->stab == DQMC_STAB_QR) {
-        if (ng > 1024) { dqmc_destroy(c); return fail(DQMC_EINVAL, "QR stabilisation supports n_g <= 1024 on this build"); }
         const int np = (ng + 15) / 16;
         A_(dalloc(c, &c->qw.V, n2)); A_(dalloc(c, &c->qw.T, (size_t)np * 2 * 256));
         A_(dalloc(c, &c->qw.W, (size_t)16 * ng)); A_(dalloc(c, &c->qw.W2, (size_t)16 * ng)); A_(dalloc(c, &c->qw.Rneg, (size_t)32 * ng));

@@ -67,22 +67,35 @@ __device__ __forceinline__ void q_wave_sum32(double (&val)[32], int lane) {
 __device__ __forceinline__ cplx q_cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // One column step of the panel factorisation (C = column index inside the panel, compile time).
-template<int RPT, int C>
+template<int C>
 struct QrPanelStep {
     template<class S> __device__ static __forceinline__ void run(S& s) {
         s.template column<C>();
-        QrPanelStep<RPT, C + 1>::run(s);
+        QrPanelStep<C + 1>::run(s);
     }
 };
-template<int RPT>
-struct QrPanelStep<RPT, QR_NB> {
+template<>
+struct QrPanelStep<QR_NB> {
     template<class S> __device__ static __forceinline__ void run(S&) {}
 };
 
-template<int RPT>
+// sum of one scratch entry over the NW waves of the workgroup (pairwise, the same order for every thread)
+template<int NW>
+__device__ __forceinline__ double q_xwave(const double (*r)[2 * QR_NB], int idx) {
+    double s = (r[0][idx] + r[1][idx]) + (r[2][idx] + r[3][idx]);
+#pragma unroll
+    for (int w = 4; w < NW; w += 4) s += (r[w][idx] + r[w + 1][idx]) + (r[w + 2][idx] + r[w + 3][idx]);
+    return s;
+}
+
+// NT threads per workgroup: 256 (rows <= 1024) or 512 (rows <= 2560) with the panel in registers, 1024 for rows <= 4096
+// (128 registers per lane there: the compiler spills part of the panel to scratch -- matrices that large spend their
+// time in the trailing update, not here)
+template<int RPT, int NT>
 struct QrPanelState {
-    cplx a[RPT][QR_NB];          // rows tid + r*256 (relative to the panel's first row) of the panel
-    double (*red)[4][2 * QR_NB]; // [parity][wave][...] cross-wave scratch
+    static constexpr int NW = NT / 64;
+    cplx a[RPT][QR_NB];          // rows tid + r*NT (relative to the panel's first row) of the panel
+    double (*red)[NW][2 * QR_NB]; // [parity][wave][...] cross-wave scratch
     cplx* sT;                    // [NB][NB] compact-WY factor, column major in LDS
     cplx* sTau;                  // [NB]
     double* sBeta;               // [NB]  diagonal of R
@@ -96,14 +109,14 @@ struct QrPanelState {
         double part = 0.0;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            int row = tid + r * 256;
+            int row = tid + r * NT;
             if (row > C && row < rows) part += a[r][C].x * a[r][C].x + a[r][C].y * a[r][C].y;
         }
         part = q_wave_total(part);
         if (tid == C) *sAlpha = a[0][C];            // row C lives in thread C, r = 0 (NB <= 256)
         if (lane == 0) red[0][wave][0] = part;
         __syncthreads();
-        const double xnorm2 = (red[0][0][0] + red[0][1][0]) + (red[0][2][0] + red[0][3][0]);
+        const double xnorm2 = q_xwave<NW>(red[0], 0);
         const cplx alpha = *sAlpha;
         // zlarfg: beta = -sign(Re alpha) sqrt(|alpha|^2 + xnorm^2), tau = (beta - alpha)/beta, v = x/(alpha - beta)
         cplx tau = make_double2(0.0, 0.0), scal = make_double2(0.0, 0.0);
@@ -119,7 +132,7 @@ struct QrPanelState {
         // ---- v in place (zeros above row C, one at row C) ----
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            int row = tid + r * 256;
+            int row = tid + r * NT;
             if (row > C) a[r][C] = q_cmul(a[r][C], scal);
         }
         // the thread owning row C keeps R[C][C] = beta aside; its v entry is 1
@@ -130,7 +143,7 @@ struct QrPanelState {
         for (int c = 0; c < 32; ++c) val[c] = 0.0;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            int row = tid + r * 256;
+            int row = tid + r * NT;
             if (row >= C && row < rows) {
                 cplx v = (row == C) ? vpiv : a[r][C];
 #pragma unroll
@@ -156,14 +169,13 @@ struct QrPanelState {
 #pragma unroll
         for (int c = 0; c < QR_NB; ++c) {
             if (c == C) { w[c] = make_double2(0.0, 0.0); continue; }
-            w[c] = make_double2((red[1][0][2 * c] + red[1][1][2 * c]) + (red[1][2][2 * c] + red[1][3][2 * c]),
-                                (red[1][0][2 * c + 1] + red[1][1][2 * c + 1]) + (red[1][2][2 * c + 1] + red[1][3][2 * c + 1]));
+            w[c] = make_double2(q_xwave<NW>(red[1], 2 * c), q_xwave<NW>(red[1], 2 * c + 1));
         }
         // ---- apply H^H = I - conj(tau) v v^H to the rest of the panel ----
         const cplx ctau = make_double2(tau.x, -tau.y);
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            int row = tid + r * 256;
+            int row = tid + r * NT;
             if (row >= C && row < rows) {
                 cplx v = (row == C) ? vpiv : a[r][C];
                 cplx tv = q_cmul(ctau, v);
@@ -204,34 +216,34 @@ struct QrPanelState {
 // Factor the panel A[j0:n, j0:j0+NB]:  R (upper part) goes back into A, the reflectors into Vp (unit lower
 // trapezoidal, zeros above the diagonal, same position as in A), T into Tp[NB*NB] (column major) and
 // -T into Tn[NB*NB].
-template<int RPT>
-__global__ __launch_bounds__(256) void k_qr_panel(cplx* __restrict__ A, int lda, int n, int j0,
-                                                   cplx* __restrict__ Vp, cplx* __restrict__ Tp, cplx* __restrict__ Tn, size_t cs) {
-    __shared__ double red[2][4][2 * QR_NB];
+template<int RPT, int NT>
+__global__ __launch_bounds__(NT) void k_qr_panel(cplx* __restrict__ A, int lda, int n, int j0,
+                                                  cplx* __restrict__ Vp, cplx* __restrict__ Tp, cplx* __restrict__ Tn, size_t cs) {
+    __shared__ double red[2][NT / 64][2 * QR_NB];
     CHAIN(A); CHAIN(Vp); CHAIN(Tp); CHAIN(Tn);
     __shared__ cplx sT[QR_NB * QR_NB];
     __shared__ cplx sTau[QR_NB];
     __shared__ double sBeta[QR_NB];
     __shared__ cplx sAlpha;
-    QrPanelState<RPT> s;
+    QrPanelState<RPT, NT> s;
     s.red = red; s.sT = sT; s.sTau = sTau; s.sBeta = sBeta; s.sAlpha = &sAlpha;
     s.tid = threadIdx.x; s.lane = threadIdx.x & 63; s.wave = threadIdx.x >> 6;
     s.rows = n - j0;
     s.ncols = (n - j0 < QR_NB) ? (n - j0) : QR_NB;
-    for (int i = threadIdx.x; i < QR_NB * QR_NB; i += 256) sT[i] = make_double2(0.0, 0.0);
+    for (int i = threadIdx.x; i < QR_NB * QR_NB; i += NT) sT[i] = make_double2(0.0, 0.0);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-        int row = s.tid + r * 256;
+        int row = s.tid + r * NT;
 #pragma unroll
         for (int c = 0; c < QR_NB; ++c)
             s.a[r][c] = (row < s.rows && c < s.ncols) ? A[(size_t)(j0 + c) * lda + (j0 + row)] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    QrPanelStep<RPT, 0>::run(s);
+    QrPanelStep<0>::run(s);
     // ---- write back ----
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-        int row = s.tid + r * 256;
+        int row = s.tid + r * NT;
         if (row < s.rows) {
 #pragma unroll
             for (int c = 0; c < QR_NB; ++c) {
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(256) void k_qr_panel(cplx* __restrict__ A, int lda,
             }
         }
     }
-    for (int i = threadIdx.x; i < QR_NB * QR_NB; i += 256) {
+    for (int i = threadIdx.x; i < QR_NB * QR_NB; i += NT) {
         cplx t = sT[i];
         Tp[i] = t;
         Tn[i] = make_double2(-t.x, -t.y);
@@ -489,13 +501,26 @@ static void gemm_small(const Launch& lc, int opA, int opB, const cplx* A, int ld
 
 static void launch_panel(const Launch& lc, cplx* A, int n, int j0, cplx* V, cplx* Tp, cplx* Tn) {
     const int rows = n - j0;
+    if (rows > 2560) {                                   // 1024 threads, 3 or 4 rows each (n <= 4096 enforced by the caller)
+        if (rows <= 3072) hipLaunchKernelGGL((k_qr_panel<3, 1024>), dim3(1, 1, lc.nb), dim3(1024), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs);
+        else              hipLaunchKernelGGL((k_qr_panel<4, 1024>), dim3(1, 1, lc.nb), dim3(1024), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs);
+        return;
+    }
+    if (rows > 1024) {                                   // 512 threads, 3..5 rows each: still (mostly) register resident
+        switch ((rows + 511) / 512) {
+            case 3: hipLaunchKernelGGL((k_qr_panel<3, 512>), dim3(1, 1, lc.nb), dim3(512), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+            case 4: hipLaunchKernelGGL((k_qr_panel<4, 512>), dim3(1, 1, lc.nb), dim3(512), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+            default: hipLaunchKernelGGL((k_qr_panel<5, 512>), dim3(1, 1, lc.nb), dim3(512), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+        }
+        return;
+    }
     const int rpt = (rows + 255) / 256;
     switch (rpt) {
-        case 1: hipLaunchKernelGGL((k_qr_panel<1>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
-        case 2: hipLaunchKernelGGL((k_qr_panel<2>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
-        case 3: hipLaunchKernelGGL((k_qr_panel<3>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
-        case 4: hipLaunchKernelGGL((k_qr_panel<4>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
-        default: break;     // n <= 1024 enforced by the caller
+        case 1: hipLaunchKernelGGL((k_qr_panel<1, 256>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+        case 2: hipLaunchKernelGGL((k_qr_panel<2, 256>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+        case 3: hipLaunchKernelGGL((k_qr_panel<3, 256>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+        case 4: hipLaunchKernelGGL((k_qr_panel<4, 256>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, V, Tp, Tn, lc.cs); break;
+        default: break;
     }
 }
 

@@ -9,7 +9,8 @@ L = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 beta = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
 nsw = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 opdim = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-kw = dict(opdim=opdim, L=L, beta=beta, s=10, delaySteps=16, globalShift=True, globalUpdateInterval=2)
+flux = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False          # BASELINE config 5: O(3) L = 24 with magnetic flux
+kw = dict(opdim=opdim, L=L, beta=beta, s=10, delaySteps=16, globalShift=True, globalUpdateInterval=2, weakZflux=flux)
 a = DetSDW(SDWParams(stabilisation="svd", **kw))
 b = DetSDW(SDWParams(stabilisation="qr", **kw))
 ga, gb = a.g, b.g

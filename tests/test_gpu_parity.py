@@ -375,7 +375,9 @@ def test_headline_size_vs_reference_checksums():
 # ------------------------------------------------------------------------------------------------
 # QR ("UDT") stabilisation mode: different factorisation, same Green's functions and same Markov chain
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("L,opdim", [(4, 2), (6, 2), (8, 2), (4, 3), (16, 2), (12, 3), (16, 3)])   # n_g up to 1024: all panel depths
+# n_g up to 1024: all register-resident panel depths; 1296 and 2304 (O(3) L = 24, BASELINE config 5): 512-thread panels;
+# 2704: 1024-thread panels
+@pytest.mark.parametrize("L,opdim", [(4, 2), (6, 2), (8, 2), (4, 3), (16, 2), (12, 3), (16, 3), (18, 3), (24, 3), (26, 3)])
 def test_qr_udt_decompose(L, opdim):
     from detqmc_amd import KernelContext
     ctx = KernelContext(opdim, L, 20, 10, 0.1, delaySteps=4, stabilisation="qr")
@@ -387,6 +389,8 @@ def test_qr_udt_decompose(L, opdim):
         assert relerr(U.conj().T @ U, np.eye(n)) < 1e-12, "Q must be unitary"
         assert np.all(d > 0)
         assert relerr((U * d[None, :]) @ Vt.conj().T, M) < 1e-12
+        if n > 1300:
+            continue                                  # the LAPACK cross-checks below take too long on the host
         # T = V_t^H is a row-scaled, column-permuted triangular factor: well conditioned
         assert np.linalg.cond(Vt) < 1e6
         # |det M| is carried by d alone
