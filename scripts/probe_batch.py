@@ -9,7 +9,7 @@ nsw = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 stab = sys.argv[4] if len(sys.argv) > 4 else "qr"
 Bs = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [1, 4, 8, 16]
 prof = len(sys.argv) > 6 and sys.argv[6] == "prof"
-p0 = SDWParams(opdim=2, L=L, beta=beta, s=10, delaySteps=int(os.environ.get("DQMC_DELAY_STEPS", "16")), stabilisation=stab)
+p0 = SDWParams(opdim=int(os.environ.get("DQMC_OPDIM", "2")), L=L, beta=beta, s=10, delaySteps=int(os.environ.get("DQMC_DELAY_STEPS", "16")), stabilisation=stab)
 for B in Bs:
     t0 = time.time()
     batch = DetSDWBatch([dataclasses.replace(p0, simindex=b, r=p0.r + 0.01 * b) for b in range(B)])
