@@ -56,6 +56,8 @@ struct dqmc_ctx {
     int stab = 0;                       // DQMC_STAB_SVD / DQMC_STAB_QR
     QrWork qw{};
     int* qr_perm = nullptr;
+    int* qr_perm_inv = nullptr;      // inverse of qr_perm and 1/d of the last lazy UDT (triangular chaining product)
+    double* qr_dinv = nullptr;
     double *rmax_inv = nullptr, *rmin = nullptr, *lmax_inv = nullptr, *lmin = nullptr;
     UdVSlot eye{};
     uint64_t qr_calls = 0;
@@ -478,7 +480,7 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
         const int np = (ng + 15) / 16;
         A_(dalloc(c, &c->qw.V, n2)); A_(dalloc(c, &c->qw.T, (size_t)np * 2 * 256));
         A_(dalloc(c, &c->qw.W, (size_t)16 * ng)); A_(dalloc(c, &c->qw.W2, (size_t)16 * ng)); A_(dalloc(c, &c->qw.Rneg, (size_t)32 * ng));
-        A_(dalloc(c, &c->qr_perm, (size_t)ng));
+        A_(dalloc(c, &c->qr_perm, (size_t)ng)); A_(dalloc(c, &c->qr_perm_inv, (size_t)ng)); A_(dalloc(c, &c->qr_dinv, (size_t)ng));
         A_(dalloc(c, &c->rmax_inv, (size_t)ng)); A_(dalloc(c, &c->rmin, (size_t)ng));
         A_(dalloc(c, &c->lmax_inv, (size_t)ng)); A_(dalloc(c, &c->lmin, (size_t)ng));
     }
@@ -660,7 +662,9 @@ static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
 // ---------------------------------------------------------------------------------------------
 enum { KIND_R = 0, KIND_L = 1 };
 
-static int udt_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, int kind, UdVSlot out) {
+// lazy != 0: the non-unitary factor T^H = (D^-1 R P^T)^H is not formed; R stays in sw.A, 1/d and the inverse permutation
+// go to qr_dinv / qr_perm_inv for the triangular chaining product of decompose_chained
+static int udt_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, int kind, UdVSlot out, int lazy = 0) {
     const int n = c->n_g;
     const int transpose = (kind == KIND_L);
     ProfScope ps(c, FAM_JACOBI, 0);
@@ -672,7 +676,8 @@ static int udt_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
     c->qw.apply_hooks = qr_hooks(c, hk);
     int launches = run_qr(c->lc, n, c->sw.A, Q, c->qw);
     launch_udt_diag(c->lc, c->sw.A, n, out.d);
-    launch_udt_tmat(c->lc, c->sw.A, out.d, c->qr_perm, n, Tt);
+    if (lazy) launch_udt_lazy(c->lc, out.d, c->qr_perm, n, c->qr_dinv, c->qr_perm_inv);
+    else launch_udt_tmat(c->lc, c->sw.A, out.d, c->qr_perm, n, Tt);
     c->fam_launches[FAM_JACOBI] += launches + 5;
     c->qr_calls += 1;
     return DQMC_OK;
@@ -699,15 +704,16 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
         launch_udt_init(c->lc, c->T2, n, nullptr, nullptr, c->qr_perm, 0, c->sw.A, n);
         SvdProfHooks hk;
         c->qw.apply_hooks = qr_hooks(c, hk);
-        int launches = run_qr(c->lc, n, c->sw.A, c->T1, c->qw);          // sw.A = R factor, T1 = Q
+        int launches = run_qr(c->lc, n, c->sw.A, nullptr, c->qw);        // sw.A = R factor, Q stays in reflector form
         launch_permute_scale_cols(c->lc, L.Vt, c->lmax_inv, c->qr_perm, n, c->T3);
         launches += run_trsm_right_upper(c->lc, n, c->sw.A, c->T3, c->qw);   // T3 = (V_l Dlmax^-1 P) R^-1
         launch_logdet_vector(c->lc, c->sw.A, c->rmax_inv, c->lmax_inv, n, c->sv);
-        c->fam_launches[FAM_JACOBI] += launches + 5;
+        launch_udt_init(c->lc, R.U, n, c->rmax_inv, nullptr, nullptr, 1, c->T1, n);   // T1 = Drmax^-1 U_r^H
+        launches += run_qr_apply_q(c->lc, n, c->T1, c->qw, 1);            // T1 = Q^H Drmax^-1 U_r^H: Q is never formed
+        c->fam_launches[FAM_JACOBI] += launches + 6;
         c->qr_calls += 1;
     }
-    gemm_dev(c, 0, 0, R.U, c->T1, c->T4, c->rmax_inv, 0);                  // T4 = U_r Drmax^-1 Q
-    gemm_dev(c, 0, 1, c->T3, c->T4, c->G);                                 // G = T3 T4^H
+    gemm_dev(c, 0, 0, c->T3, c->T1, c->G);                                 // G = T3 T1
     return DQMC_OK;
 }
 
@@ -716,6 +722,34 @@ static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
 static int decompose(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, int kind, UdVSlot out) {
     if (c->stab == DQMC_STAB_QR) return udt_dev(c, M, colscale, rowscale, kind, out);
     return udv_dev(c, M, colscale, rowscale, out);
+}
+
+// Decomposition of a chain step whose non-unitary factor is chained with the previous one (detmodel.h:987, :1143):
+// out gets the unitary factor, the scales, and Aold * (new non-unitary factor).  QR mode: that factor is
+// P R^H D^-1, so the product is a column gather of Aold times a LOWER TRIANGULAR matrix -- half the multiply-adds,
+// and the factor itself is never written.
+static int decompose_chained(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, int kind, UdVSlot out,
+                             const cplx* Aold) {
+    cplx* dest = (kind == KIND_R) ? out.Vt : out.U;
+    if (c->stab == DQMC_STAB_QR) {
+        int rc = udt_dev(c, M, colscale, rowscale, kind, out, 1);
+        if (rc) return rc;
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = Aold; g.lda = c->n_g; g.opA = 0; g.a_kgather = c->qr_perm_inv;
+        g.B = c->sw.A; g.ldb = c->n_g; g.opB = 1; g.b_lower = 1;
+        g.C = dest; g.ldc = c->n_g; g.M = g.N = g.K = c->n_g; g.Kmul = 1; g.colscale = c->qr_dinv;
+        c->gemm_flops += 4.0 * (double)g.M * g.N * g.K * c->nb;
+        ProfScope ps(c, FAM_GEMM, 1);
+        launch_gemm(c->lc, g);
+        return DQMC_OK;
+    }
+    UdVSlot t = out;
+    if (kind == KIND_R) t.Vt = c->tmpudv.Vt; else t.U = c->tmpudv.U;
+    int rc = decompose(c, M, colscale, rowscale, kind, t);
+    if (rc) return rc;
+    gemm_dev(c, 0, 0, Aold, (kind == KIND_R) ? c->tmpudv.Vt : c->tmpudv.U, dest);
+    return DQMC_OK;
 }
 
 // greenFromUdV (detmodel.h:769-818)
@@ -770,9 +804,7 @@ extern "C" int dqmc_udv_setup(dqmc_ctx* c) {
         const int k_l = s * l, k_lp1 = (l < n - 1) ? s * (l + 1) : m;
         launch_copy(c->lc, c->storage[l].U, c->T1, (size_t)ng * ng);
         bmult_dev(c, DQMC_LEFT, 0, k_lp1, k_l, c->T1);
-        UdVSlot t = c->storage[l + 1]; t.Vt = c->tmpudv.Vt;
-        if ((rc = decompose(c, c->T1, c->storage[l].d, nullptr, KIND_R, t))) return rc;
-        gemm_dev(c, 0, 0, c->storage[l].Vt, c->tmpudv.Vt, c->storage[l + 1].Vt);
+        if ((rc = decompose_chained(c, c->T1, c->storage[l].d, nullptr, KIND_R, c->storage[l + 1], c->storage[l].Vt))) return rc;
     }
     if ((rc = green_from_eye(c, c->storage[n], KIND_R))) return rc;
     c->currentTimeslice = m;
@@ -801,9 +833,7 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
             const UdVSlot& st = c->storage[l];
             { ProfScope ps(c, FAM_OTHER, 1); launch_conj_transpose(c->lc, st.Vt, c->T1, ng); }
             bmult_dev(c, DQMC_RIGHT, 0, k_l, k_lm1, c->T1);
-            UdVSlot t = L; t.U = c->tmpudv.U;
-            if ((rc = decompose(c, c->T1, nullptr, st.d, KIND_L, t))) return rc;
-            gemm_dev(c, 0, 0, st.U, c->tmpudv.U, L.U);
+            if ((rc = decompose_chained(c, c->T1, nullptr, st.d, KIND_L, L, st.U))) return rc;
         } else {
             { ProfScope ps(c, FAM_OTHER, 1); launch_set_identity(c->lc, c->T1, ng); }
             bmult_dev(c, DQMC_RIGHT, 0, k_l, k_lm1, c->T1);
@@ -824,9 +854,7 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
         UdVSlot T = c->spare;
         launch_copy(c->lc, st.U, c->T1, (size_t)ng * ng);
         bmult_dev(c, DQMC_LEFT, 0, k_lp1, k_l, c->T1);
-        UdVSlot t = T; t.Vt = c->tmpudv.Vt;
-        if ((rc = decompose(c, c->T1, st.d, nullptr, KIND_R, t))) return rc;
-        gemm_dev(c, 0, 0, st.Vt, c->tmpudv.Vt, T.Vt);
+        if ((rc = decompose_chained(c, c->T1, st.d, nullptr, KIND_R, T, st.Vt))) return rc;
         if (k_lp1 != m) rc = green_from_udv(c, c->storage[l + 1], T);
         else rc = green_from_eye(c, T, KIND_R);
         if (rc) return rc;

@@ -105,6 +105,8 @@ struct GemmArgs {
     int accumulate;             // C += instead of C =
     int negate;                 // the product enters with a minus sign (C -= A B with accumulate)
     int sharedA, sharedB;       // operand is one matrix for all chains (not shifted by the chain stride)
+    const int* a_kgather;       // opA == 0 only: column k of op(A) is column a_kgather[k] of A
+    int b_lower;                // op(B) is lower triangular (entries with k < j are zero): the k loop of a column tile starts at its first column
 };
 void launch_gemm(const Launch& lc, const GemmArgs& a);
 // G += X Gr, K = min(Kmax, *Kdev * Kmul): the delayed-update flush as a register-only read-modify-write stream
@@ -152,11 +154,13 @@ size_t measure_accum_doubles(int N, int L);
 // ---- QR / UDT building blocks (kernels_qr.hip) ------------------------------------------------
 struct SvdProfHooks;
 struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; const SvdProfHooks* apply_hooks; };   // hooks: optional timing of the k_qr_apply launches
-int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit
+int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit (Q == nullptr: reflectors only)
+int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans);       // C <- Q C or Q^H C with the reflectors of the last run_qr
 int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w);   // C <- C R^-1
 void launch_udt_init(const Launch& lc, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,
                      int transpose, cplx* W, int n);
 void launch_udt_diag(const Launch& lc, const cplx* R, int n, double* d);
+void launch_udt_lazy(const Launch& lc, const double* d, const int* perm, int n, double* dinv, int* perm_inv);   // 1/d and the inverse permutation
 void launch_udt_tmat(const Launch& lc, const cplx* R, const double* d, const int* perm, int n, cplx* Tt);
 void launch_permute_scale_cols(const Launch& lc, const cplx* X, const double* cs, const int* perm, int n, cplx* Y);
 void launch_split_scales(const Launch& lc, const double* d, int n, double* dmax_inv, double* dmin);

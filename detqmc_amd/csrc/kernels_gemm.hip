@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
     if (!g.sharedB) g.B = chain_ptr_i(g.B, cs, chain);
     g.C = chain_ptr_i(g.C, cs, chain); g.Kdev = chain_ptr_i(g.Kdev, cs, chain); g.kscale = chain_ptr_i(g.kscale, cs, chain);
     g.rowscale = chain_ptr_i(g.rowscale, cs, chain); g.colscale = chain_ptr_i(g.colscale, cs, chain);
+    g.a_kgather = chain_ptr_i(g.a_kgather, cs, chain);
 
     int K = g.K;
     if (g.Kdev) { int kd = (*g.Kdev) * g.Kmul; K = kd < K ? kd : K; }
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
             cplx v = make_double2(0.0, 0.0);
             const int gi = i0 + i, gk = k0 + k;
             if (gi < g.M && gk < K) {
-                if (g.opA == 0) v = g.A[(size_t)gk * g.lda + gi];
+                if (g.opA == 0) v = g.A[(size_t)(g.a_kgather ? g.a_kgather[gk] : gk) * g.lda + gi];
                 else { cplx t = g.A[(size_t)gi * g.lda + gk]; v = make_double2(t.x, -t.y); }
                 if (g.kscale) {
                     double sc = g.kscale[gk];
@@ -100,9 +101,10 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
         }
     };
 
-    if (K > 0) { gload(0); sstore(0); }
+    const int kbeg = g.b_lower ? (j0 / BK) * BK : 0;      // triangular op(B): rows above the tile's first column are zero
+    if (K > kbeg) { gload(kbeg); sstore(0); }
     __syncthreads();
-    for (int k0 = 0, buf = 0; k0 < K; k0 += BK, buf ^= 1) {
+    for (int k0 = kbeg, buf = 0; k0 < K; k0 += BK, buf ^= 1) {
         const bool more = k0 + BK < K;
         if (more) gload(k0 + BK);
 #pragma unroll
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
                 if (gi < g.M && gj < g.N) {
                     double re = acc_re[a][b][r], im = acc_im[a][b][r];
                     if (g.rowscale) { double sc = g.rowscale[gi] * g.colscale[gj]; re *= sc; im *= sc; }
+                    else if (g.colscale) { double sc = g.colscale[gj]; re *= sc; im *= sc; }
                     if (g.negate) { re = -re; im = -im; }
                     size_t off = (size_t)gj * g.ldc + gi;
                     if (g.accumulate) { cplx c = g.C[off]; re += c.x; im += c.y; }

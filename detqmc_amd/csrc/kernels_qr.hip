@@ -588,6 +588,7 @@ int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
         }
     }
     // ---- Q = H_0 H_1 ... applied to the identity, block reflectors in reverse order (zungqr): C <- (I - V T V^H) C ----
+    if (!Q) return launches;                                      // the caller applies Q itself (run_qr_apply_q)
     launch_set_identity(lc, Q, n);
     ++launches;
     for (int p = np - 1; p >= 0;) {
@@ -596,6 +597,58 @@ int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
         const int lo = p - (cnt - 1);                             // H_p first, ..., H_lo last; rows / columns from block lo
         apply(false, Q, lo, lo * QR_NB, n - lo * QR_NB, p, -1, cnt);
         p -= cnt;
+    }
+    return launches;
+}
+
+// C <- Q C (trans == 0) or C <- Q^H C (trans != 0) for a dense n x n matrix C, Q from the reflectors the last run_qr left
+// in w (zunmqr, left): n^3 multiply-adds, against 2/3 n^3 for forming Q plus n^3 for the product with it.
+int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans) {
+    int launches = 0;
+    const int np = (n + QR_NB - 1) / QR_NB;
+    const bool reg = n <= 512;
+    auto nbof = [&](int p) { return (n - p * QR_NB < QR_NB) ? (n - p * QR_NB) : QR_NB; };
+    // one launch: the reflectors of panels first, first + step, ... (cnt of them, in that order), rows from block lo
+    auto group = [&](int first, int step, int cnt, int lo) {
+        const int rows = n - lo * QR_NB;
+        cplx* Cs = C + lo * QR_NB;                                 // rows from block lo, all columns
+        const dim3 grid((n + QR_NB - 1) / QR_NB, 1, lc.nb);
+        if (w.apply_hooks) w.apply_hooks->begin(w.apply_hooks->user);
+        if (reg) {
+            QrRefs r;
+            r.n = cnt;
+            for (int i = 0; i < QR_MAXREF; ++i) { r.V[i] = nullptr; r.Tn[i] = nullptr; r.nb[i] = 0; }
+            for (int i = 0; i < cnt; ++i) {
+                const int q = first + i * step;
+                r.V[i] = w.V + (size_t)(q * QR_NB) * n + lo * QR_NB;
+                r.Tn[i] = w.T + (size_t)q * 2 * QR_NB * QR_NB + QR_NB * QR_NB;
+                r.nb[i] = nbof(q);
+            }
+            if (trans) hipLaunchKernelGGL((k_qr_apply_reg<true>), grid, dim3(256), 0, lc.st, r, n, Cs, n, rows, n, lc.cs);
+            else       hipLaunchKernelGGL((k_qr_apply_reg<false>), grid, dim3(256), 0, lc.st, r, n, Cs, n, rows, n, lc.cs);
+        } else {
+            const cplx* Vq = w.V + (size_t)(first * QR_NB) * n + lo * QR_NB;
+            const cplx* Tq = w.T + (size_t)first * 2 * QR_NB * QR_NB + QR_NB * QR_NB;
+            if (trans) hipLaunchKernelGGL((k_qr_apply<true>), grid, dim3(256), 0, lc.st, Vq, n, Tq, Cs, n, rows, n, nbof(first), lc.cs);
+            else       hipLaunchKernelGGL((k_qr_apply<false>), grid, dim3(256), 0, lc.st, Vq, n, Tq, Cs, n, rows, n, nbof(first), lc.cs);
+        }
+        if (w.apply_hooks) w.apply_hooks->end(w.apply_hooks->user, 1);
+        ++launches;
+    };
+    if (trans) {                                                   // Q^H = H_{np-1}^H ... H_0^H: ascending, as in the factorisation
+        for (int p = 0; p < np;) {
+            int cnt = 1;
+            if (reg) { cnt = (np - p >= 4) ? 4 : ((np - p >= 2) ? 2 : 1); if (nbof(p + cnt - 1) != QR_NB) cnt = 1; }
+            group(p, 1, cnt, p);
+            p += cnt;
+        }
+    } else {                                                       // Q = H_0 ... H_{np-1}: descending, as when forming Q
+        for (int p = np - 1; p >= 0;) {
+            int cnt = 1;
+            if (reg && nbof(p) == QR_NB) cnt = (p >= 3) ? 4 : (p >= 1 ? 2 : 1);
+            group(p, -1, cnt, p - (cnt - 1));
+            p -= cnt;
+        }
     }
     return launches;
 }
@@ -671,7 +724,7 @@ int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const 
 // ---------------------------------------------------------------------------------------------
 // glue for the UDT decomposition  Ms P = Q R  ->  (Q, d, T^H) resp. (T^H, d, Q)
 // ---------------------------------------------------------------------------------------------
-// W[:, perm[j]] = Ms[:, j] (or Ms^H when T != 0), Ms = diag(rowscale) M diag(colscale)
+// W[:, perm[j]] = Ms[:, j] (or Ms^H when T != 0), Ms = diag(rowscale) M diag(colscale); perm == nullptr: identity
 __global__ void k_udt_init(const cplx* __restrict__ M, int ldm, const double* colscale, const double* rowscale,
                            const int* __restrict__ perm, int transpose, cplx* __restrict__ W, int n, size_t cs) {
     CHAIN(M); CHAIN(colscale); CHAIN(rowscale); CHAIN(perm); CHAIN(W);
@@ -683,7 +736,7 @@ __global__ void k_udt_init(const cplx* __restrict__ M, int ldm, const double* co
         double sc = 1.0;
         if (colscale) sc *= colscale[mj];
         if (rowscale) sc *= rowscale[mi];
-        W[(size_t)perm[j] * n + i] = make_double2(v.x * sc, transpose ? -v.y * sc : v.y * sc);
+        W[(size_t)(perm ? perm[j] : j) * n + i] = make_double2(v.x * sc, transpose ? -v.y * sc : v.y * sc);
     }
 }
 
@@ -692,6 +745,13 @@ __global__ void k_udt_diag(const cplx* __restrict__ R, int n, double* d, size_t 
     CHAIN(R); CHAIN(d);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) { cplx r = R[(size_t)k * n + k]; d[k] = sqrt(r.x * r.x + r.y * r.y); }
+}
+
+// what the triangular product A (D^-1 R P^T)^H needs instead of the explicit factor: 1/d and the inverse permutation
+__global__ void k_udt_lazy(const double* __restrict__ d, const int* __restrict__ perm, int n, double* dinv, int* perm_inv, size_t cs) {
+    CHAIN(d); CHAIN(perm); CHAIN(dinv); CHAIN(perm_inv);
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { dinv[k] = 1.0 / d[k]; perm_inv[perm[k]] = k; }
 }
 
 // Tt[j, k] = conj(R[k, perm[j]]) / d[k]   (= (D^-1 R P^T)^H); zero where R is zero
@@ -754,6 +814,9 @@ void launch_udt_init(const Launch& lc, const cplx* M, int ldm, const double* cs,
 }
 void launch_udt_diag(const Launch& lc, const cplx* R, int n, double* d) {
     hipLaunchKernelGGL(k_udt_diag, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, R, n, d, lc.cs);
+}
+void launch_udt_lazy(const Launch& lc, const double* d, const int* perm, int n, double* dinv, int* perm_inv) {
+    hipLaunchKernelGGL(k_udt_lazy, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, d, perm, n, dinv, perm_inv, lc.cs);
 }
 void launch_udt_tmat(const Launch& lc, const cplx* R, const double* d, const int* perm, int n, cplx* Tt) {
     hipLaunchKernelGGL(k_udt_tmat, dim3(1024, 1, lc.nb), dim3(256), 0, lc.st, R, d, perm, n, Tt, lc.cs);
