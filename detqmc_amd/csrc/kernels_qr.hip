@@ -382,27 +382,38 @@ __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, i
 // (m = row = l4 + 4 r, n = column) -- so C is read once and written once instead of read twice, and pass 1 needs no
 // LDS staging or barrier per chunk.  V comes from global memory (all workgroups of a chain read the same panel: L2).
 #define QR_MAXREF 4
+// keeps loads on their side (compiler level: memory clobber; scheduler level: sched_barrier): the double buffers below are
+// otherwise undone by hoisting every load of a pass to its top (32 quads of registers -> spills)
+#define QR_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// makes the base pointer of the next loads depend on an accumulator of the MFMAs before it: the loads cannot be hoisted
+// above those MFMAs, and the MFMAs after it cannot move above the loads
+#define QR_TIE(acc, ptr) asm volatile("" : "+v"(acc), "+v"(ptr))
 struct QrRefs { const cplx* V[QR_MAXREF]; const cplx* Tn[QR_MAXREF]; int nb[QR_MAXREF]; int n; };
-template<bool TRANS_T>
-__global__ __launch_bounds__(256) void k_qr_apply_reg(QrRefs refs, int ldv, cplx* __restrict__ C, int ldc, int rows, int ncols, size_t cs) {
+// NCH = ceil(rows / 64) is a template parameter and every load has a clamped, always valid address: the unrolled code is
+// straight-line, so the compiler issues the loads of a pass in batches instead of one guarded load + s_waitcnt vmcnt(0)
+// per element (what the bounds-checked version compiled to: waves were parked half of their cycles).
+template<bool TRANS_T, int NCH>
+__global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, cplx* __restrict__ C, int ldc, int rows, int ncols, size_t cs) {
     __shared__ cplx sW[QR_NB][QR_NB + 1];      // W, then W2, as [k][j]
     __shared__ cplx sT[QR_NB][QR_NB + 1];      // -T as [i][k]
     __shared__ cplx sPart[4][QR_NB][QR_NB + 1];
     CHAIN(C);
+    constexpr int RW = 16 * NCH;                    // rows per wave
+    constexpr int NE = 4 * NCH;                     // elements per lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int c0 = blockIdx.x * QR_NB;
     const int nc = min(QR_NB, ncols - c0);
-    const int RW = ((rows + 63) / 64) * 16;        // rows per wave, a multiple of 16 (<= 128)
-    const int ne = RW / 4;                          // elements per lane (<= 32)
     const int slab = wave * RW;
-    cplx* Ccol = C + (size_t)(c0 + l15) * ldc;
+    const int rlast = rows - 1;
     const bool cok = l15 < nc;
-    cplx creg[32];
+    cplx* Ccol = C + (size_t)(c0 + (cok ? l15 : 0)) * ldc;
+    cplx creg[NE];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int row = slab + 4 * e + l4;
-        creg[e] = (e < ne && cok && row < rows) ? Ccol[row] : make_double2(0.0, 0.0);
+        const cplx t = Ccol[min(row, rlast)];
+        creg[e] = (cok && row < rows) ? t : make_double2(0.0, 0.0);
     }
     // Up to four block reflectors are applied one after the other while C stays in registers (the later ones are the
     // next panels', whose rows above their own first row are zero in V): the trailing matrix is then read and written
@@ -412,23 +423,53 @@ __global__ __launch_bounds__(256) void k_qr_apply_reg(QrRefs refs, int ldv, cplx
         const cplx* Vp = chain_ptr(refs.V[rf], cs);
         const cplx* Tn = chain_ptr(refs.Tn[rf], cs);
         const int nb = refs.nb[rf];
+        // per-iteration copies of the bounds the compiler cannot see through: otherwise the 32 clamped row indices and
+        // 32 lane masks of the passes are hoisted out of this loop and kept alive across it (spills at NCH = 8)
+        int rl = rlast, rw = rows;
+        asm volatile("" : "+v"(rl), "+s"(rw));
         __syncthreads();                            // sT / sW / sPart of the previous reflector are no longer read
-        sT[wi][wj] = (wi < nb && wj < nb) ? Tn[wj * QR_NB + wi] : make_double2(0.0, 0.0);
-        const cplx* Vcol = Vp + (size_t)l15 * ldv;
+        {
+            const cplx t = Tn[wj * QR_NB + wi];     // the panel kernel writes all 256 entries (zeros beyond its columns)
+            sT[wi][wj] = (wi < nb && wj < nb) ? t : make_double2(0.0, 0.0);
+        }
         const bool vok = l15 < nb;
-        // ---- pass 1: W = V^H C over this wave's slab ----
+        const cplx* Vcol = Vp + (size_t)(vok ? l15 : 0) * ldv;
+        // ---- pass 1: W = V^H C over this wave's slab; V in chunks of CH elements, the next chunk's loads in flight while
+        //      the matrix cores work on the current one (explicit double buffer: left alone the compiler keeps ONE
+        //      register quad for v and waits for every load right after issuing it) ----
         q_v4d w_re = (q_v4d)(0.0), w_im = (q_v4d)(0.0);
+        constexpr int CH = (NE < 8 || NCH >= 7) ? 4 : 8;     // NCH >= 7: C alone takes half of the register file
+        cplx va[CH], vb[CH];
+        auto loadv = [&](const cplx* base, int e0, cplx (&dst)[CH]) {
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            if (e < ne) {
-                const int row = slab + 4 * e + l4;
-                const cplx v = (vok && row < rows) ? Vcol[row] : make_double2(0.0, 0.0);     // A(m = i, k) = conj(v)
-                const cplx x = creg[e];                                                       // B(k, n = j)
+            for (int i = 0; i < CH; ++i) {
+                if (e0 + i >= NE) continue;                                                   // NE need not be a multiple of CH
+                const int row = slab + 4 * (e0 + i) + l4;
+                const cplx t = base[min(row, rl)];
+                dst[i] = (vok && row < rw) ? t : make_double2(0.0, 0.0);                      // A(m = i, k) = conj(v)
+            }
+        };
+        auto mac = [&](int e0, const cplx (&src)[CH]) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (e0 + i >= NE) continue;
+                const cplx v = src[i];
+                const cplx x = creg[e0 + i];                                                  // B(k, n = j)
                 w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.x, w_re, 0, 0, 0);
                 w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.y, w_re, 0, 0, 0);
                 w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.y, w_im, 0, 0, 0);
                 w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, x.x, w_im, 0, 0, 0);
             }
+        };
+        const cplx* vbase = Vcol;
+        loadv(vbase, 0, va);
+        if (CH < NE) loadv(vbase, CH, vb);
+#pragma unroll
+        for (int c = 0; c < NE; c += 2 * CH) {
+            mac(c, va);
+            if (c + 2 * CH < NE) { QR_TIE(w_re, vbase); loadv(vbase, c + 2 * CH, va); }
+            if (c + CH < NE) mac(c + CH, vb);
+            if (c + 3 * CH < NE) { QR_TIE(w_re, vbase); loadv(vbase, c + 3 * CH, vb); }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) sPart[wave][l4 + 4 * r][l15] = make_double2(w_re[r], w_im[r]);   // D[m = l4 + 4r][n = l15]
@@ -456,35 +497,66 @@ __global__ __launch_bounds__(256) void k_qr_apply_reg(QrRefs refs, int ldv, cplx
         cplx w2[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) w2[ks] = sW[ks * 4 + l4][l15];           // B(k, n = column)
+        cplx vfa[4], vfb[4];
+        auto loadvf = [&](const cplx* base, int t, cplx (&dst)[4]) {
+            const int vrow = slab + 16 * t + l15;                                // A(m = row, k)
+            const int vr = min(vrow, rl);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if (4 * t < ne) {
-                const int vrow = slab + 16 * t + l15;                            // A(m = row, k)
-                cplx vf[4];
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = ks * 4 + l4;
+                const cplx tv = base[(size_t)min(k, nb - 1) * ldv + vr];
+                dst[ks] = (vrow < rw && k < nb) ? tv : make_double2(0.0, 0.0);
+            }
+        };
+        q_v4d d_re, d_im;
+        auto upd = [&](int t, const cplx (&vf)[4]) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int k = ks * 4 + l4;
-                    vf[ks] = (vrow < rows && k < nb) ? Vp[(size_t)k * ldv + vrow] : make_double2(0.0, 0.0);
-                }
-                q_v4d d_re, d_im;
+            for (int r = 0; r < 4; ++r) { d_re[r] = creg[4 * t + r].x; d_im[r] = creg[4 * t + r].y; }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { d_re[r] = creg[4 * t + r].x; d_im[r] = creg[4 * t + r].y; }
+            for (int ks = 0; ks < 4; ++ks) {
+                d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].x, d_re, 0, 0, 0);
+                d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-vf[ks].y, w2[ks].y, d_re, 0, 0, 0);
+                d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].y, d_im, 0, 0, 0);
+                d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].y, w2[ks].x, d_im, 0, 0, 0);
+            }
+        };
+        auto put = [&](int t) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].x, d_re, 0, 0, 0);
-                    d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-vf[ks].y, w2[ks].y, d_re, 0, 0, 0);
-                    d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].y, d_im, 0, 0, 0);
-                    d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].y, w2[ks].x, d_im, 0, 0, 0);
-                }
+            for (int r = 0; r < 4; ++r) creg[4 * t + r] = make_double2(d_re[r], d_im[r]);   // D[m = l4 + 4r][n = l15]
+        };
+        const cplx* pbase = Vp;
+        loadvf(pbase, 0, vfa);
+        if (NCH > 1) loadvf(pbase, 1, vfb);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) creg[4 * t + r] = make_double2(d_re[r], d_im[r]);   // D[m = l4 + 4r][n = l15]
+        for (int t = 0; t < NCH; t += 2) {
+            upd(t, vfa);
+            if (t + 2 < NCH) { QR_TIE(d_re, pbase); loadvf(pbase, t + 2, vfa); }
+            put(t);
+            if (t + 1 < NCH) {
+                upd(t + 1, vfb);
+                if (t + 3 < NCH) { QR_TIE(d_re, pbase); loadvf(pbase, t + 3, vfb); }
+                put(t + 1);
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int row = slab + 4 * e + l4;
-        if (e < ne && cok && row < rows) Ccol[row] = creg[e];
+        if (cok && row < rows) Ccol[row] = creg[e];
+    }
+}
+
+template<bool TRANS_T>
+static void launch_apply_reg(const Launch& lc, dim3 grid, const QrRefs& r, int ldv, cplx* C, int ldc, int rows, int ncols) {
+    switch ((rows + 63) / 64) {
+        case 1: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 1>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
+        case 2: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 2>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
+        case 3: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 3>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
+        case 4: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 4>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
+        case 5: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 5>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
+        case 6: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 6>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
+        case 7: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 7>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
+        default: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 8>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
     }
 }
 
@@ -544,8 +616,8 @@ int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
             r.n = count;
             for (int i = 0; i < QR_MAXREF; ++i) { r.V[i] = nullptr; r.Tn[i] = nullptr; r.nb[i] = 0; }
             for (int i = 0; i < count; ++i) { const int p = p0 + i * step; r.V[i] = Vat(p, rb); r.Tn[i] = Tneg(p); r.nb[i] = nbof(p); }
-            if (transT) hipLaunchKernelGGL((k_qr_apply_reg<true>), grid, dim3(256), 0, lc.st, r, n, C, n, rows, ncols, lc.cs);
-            else        hipLaunchKernelGGL((k_qr_apply_reg<false>), grid, dim3(256), 0, lc.st, r, n, C, n, rows, ncols, lc.cs);
+            if (transT) launch_apply_reg<true>(lc, grid, r, n, C, n, rows, ncols);
+            else        launch_apply_reg<false>(lc, grid, r, n, C, n, rows, ncols);
         } else {
             if (transT) hipLaunchKernelGGL((k_qr_apply<true>), grid, dim3(256), 0, lc.st, Vat(p0, rb), n, Tneg(p0), C, n, rows, ncols, nbof(p0), lc.cs);
             else        hipLaunchKernelGGL((k_qr_apply<false>), grid, dim3(256), 0, lc.st, Vat(p0, rb), n, Tneg(p0), C, n, rows, ncols, nbof(p0), lc.cs);
@@ -624,8 +696,8 @@ int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans)
                 r.Tn[i] = w.T + (size_t)q * 2 * QR_NB * QR_NB + QR_NB * QR_NB;
                 r.nb[i] = nbof(q);
             }
-            if (trans) hipLaunchKernelGGL((k_qr_apply_reg<true>), grid, dim3(256), 0, lc.st, r, n, Cs, n, rows, n, lc.cs);
-            else       hipLaunchKernelGGL((k_qr_apply_reg<false>), grid, dim3(256), 0, lc.st, r, n, Cs, n, rows, n, lc.cs);
+            if (trans) launch_apply_reg<true>(lc, grid, r, n, Cs, n, rows, n);
+            else       launch_apply_reg<false>(lc, grid, r, n, Cs, n, rows, n);
         } else {
             const cplx* Vq = w.V + (size_t)(first * QR_NB) * n + lo * QR_NB;
             const cplx* Tq = w.T + (size_t)first * 2 * QR_NB * QR_NB + QR_NB * QR_NB;
