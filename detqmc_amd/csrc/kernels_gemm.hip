@@ -50,38 +50,69 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
         for (int b = 0; b < TN; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); }
 
     cplx ra[NA], rb[NB_];
-    // global -> registers: op(A) tile element (i, k), op(B) tile element (k, j)
+    // global -> registers: op(A) tile element (i, k), op(B) tile element (k, j).  Every load has a clamped, always valid
+    // address and the bounds are applied afterwards by a select: guarded loads compile to one exec-masked branch +
+    // s_waitcnt vmcnt(0) per element, which serialises the eight loads of a tile instead of keeping them in flight
+    // behind the MFMAs of the previous tile.
+    const int Mm1 = g.M - 1, Nm1 = g.N - 1;
     auto gload = [&](int k0) {
+        const int Km1 = K - 1;
+        int ka[NA];
+        bool oka[NA];
+        if (g.opA == 0) {
+            int ia[NA], ca[NA];
 #pragma unroll
-        for (int e = 0; e < NA; ++e) {
-            const int idx = tid + e * 256;
-            int i, k;
-            if (g.opA == 0) { i = idx % BM; k = idx / BM; } else { k = idx % BK; i = idx / BK; }
-            cplx v = make_double2(0.0, 0.0);
-            const int gi = i0 + i, gk = k0 + k;
-            if (gi < g.M && gk < K) {
-                if (g.opA == 0) v = g.A[(size_t)(g.a_kgather ? g.a_kgather[gk] : gk) * g.lda + gi];
-                else { cplx t = g.A[(size_t)gi * g.lda + gk]; v = make_double2(t.x, -t.y); }
-                if (g.kscale) {
-                    double sc = g.kscale[gk];
-                    if (g.kscale_invert) sc = 1.0 / sc;
-                    v.x *= sc; v.y *= sc;
-                }
+            for (int e = 0; e < NA; ++e) {
+                const int idx = tid + e * 256;
+                const int gi = i0 + idx % BM, gk = k0 + idx / BM;
+                oka[e] = gi < g.M && gk < K;
+                ia[e] = min(gi, Mm1); ka[e] = min(gk, Km1); ca[e] = ka[e];
             }
-            ra[e] = v;
+            if (g.a_kgather) {
+#pragma unroll
+                for (int e = 0; e < NA; ++e) ca[e] = g.a_kgather[ka[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < NA; ++e) ra[e] = g.A[(size_t)ca[e] * g.lda + ia[e]];
+        } else {
+#pragma unroll
+            for (int e = 0; e < NA; ++e) {
+                const int idx = tid + e * 256;
+                const int gk = k0 + idx % BK, gi = i0 + idx / BK;
+                oka[e] = gi < g.M && gk < K;
+                ka[e] = min(gk, Km1);
+                const cplx t = g.A[(size_t)min(gi, Mm1) * g.lda + ka[e]];
+                ra[e] = make_double2(t.x, -t.y);
+            }
+        }
+        if (g.kscale) {
+            double sc[NA];
+#pragma unroll
+            for (int e = 0; e < NA; ++e) sc[e] = g.kscale[ka[e]];
+#pragma unroll
+            for (int e = 0; e < NA; ++e) {
+                const double f = g.kscale_invert ? 1.0 / sc[e] : sc[e];
+                ra[e].x *= f; ra[e].y *= f;
+            }
         }
 #pragma unroll
-        for (int e = 0; e < NB_; ++e) {
-            const int idx = tid + e * 256;
-            int j, k;
-            if (g.opB == 0) { k = idx % BK; j = idx / BK; } else { j = idx % BN; k = idx / BN; }
-            cplx v = make_double2(0.0, 0.0);
-            const int gj = j0 + j, gk = k0 + k;
-            if (gj < g.N && gk < K) {
-                if (g.opB == 0) v = g.B[(size_t)gj * g.ldb + gk];
-                else { cplx t = g.B[(size_t)gk * g.ldb + gj]; v = make_double2(t.x, -t.y); }
+        for (int e = 0; e < NA; ++e) if (!oka[e]) ra[e] = make_double2(0.0, 0.0);
+        if (g.opB == 0) {
+#pragma unroll
+            for (int e = 0; e < NB_; ++e) {
+                const int idx = tid + e * 256;
+                const int gk = k0 + idx % BK, gj = j0 + idx / BK;
+                const cplx t = g.B[(size_t)min(gj, Nm1) * g.ldb + min(gk, Km1)];
+                rb[e] = (gj < g.N && gk < K) ? t : make_double2(0.0, 0.0);
             }
-            rb[e] = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < NB_; ++e) {
+                const int idx = tid + e * 256;
+                const int gj = j0 + idx % BN, gk = k0 + idx / BN;
+                const cplx t = g.B[(size_t)min(gk, Km1) * g.ldb + min(gj, Nm1)];
+                rb[e] = (gj < g.N && gk < K) ? make_double2(t.x, -t.y) : make_double2(0.0, 0.0);
+            }
         }
     };
     auto sstore = [&](int buf) {
@@ -133,21 +164,28 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < TN; ++b) {
+            const int gi = i0 + wm * 16 * TM + a * 16 + l15;
+            const int gic = min(gi, Mm1);
+            cplx cold[4];
+            if (g.accumulate) {                                    // the four loads together, bounds by select (see gload)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int gi = i0 + wm * 16 * TM + a * 16 + l15;
-                int gj = j0 + wn * 16 * TN + b * 16 + l4 + 4 * r;
-                if (gi < g.M && gj < g.N) {
-                    double re = acc_re[a][b][r], im = acc_im[a][b][r];
-                    if (g.rowscale) { double sc = g.rowscale[gi] * g.colscale[gj]; re *= sc; im *= sc; }
-                    else if (g.colscale) { double sc = g.colscale[gj]; re *= sc; im *= sc; }
-                    if (g.negate) { re = -re; im = -im; }
-                    size_t off = (size_t)gj * g.ldc + gi;
-                    if (g.accumulate) { cplx c = g.C[off]; re += c.x; im += c.y; }
-                    g.C[off] = make_double2(re, im);
+                for (int r = 0; r < 4; ++r) {
+                    const int gj = j0 + wn * 16 * TN + b * 16 + l4 + 4 * r;
+                    cold[r] = g.C[(size_t)min(gj, Nm1) * g.ldc + gic];
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gj = j0 + wn * 16 * TN + b * 16 + l4 + 4 * r;
+                double re = acc_re[a][b][r], im = acc_im[a][b][r];
+                if (g.rowscale) { double sc = g.rowscale[gic] * g.colscale[min(gj, Nm1)]; re *= sc; im *= sc; }
+                else if (g.colscale) { double sc = g.colscale[min(gj, Nm1)]; re *= sc; im *= sc; }
+                if (g.negate) { re = -re; im = -im; }
+                if (g.accumulate) { re += cold[r].x; im += cold[r].y; }
+                if (gi < g.M && gj < g.N) g.C[(size_t)gj * g.ldc + gi] = make_double2(re, im);
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,12 +222,14 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int gi = i0 + a * 16 + l15;
-            af[a] = (gk < K && gi < n) ? X[(size_t)gk * ldx + gi] : make_double2(0.0, 0.0);
+            const cplx t = X[(size_t)min(gk, K - 1) * ldx + min(gi, n - 1)];      // clamped address + select: no branch, no wait
+            af[a] = (gk < K && gi < n) ? t : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int gj = j0 + b * 16 + l15;
-            bf[b] = (gk < K && gj < n) ? Gr[(size_t)gj * ldg + gk] : make_double2(0.0, 0.0);
+            const cplx t = Gr[(size_t)min(gj, n - 1) * ldg + min(gk, K - 1)];
+            bf[b] = (gk < K && gj < n) ? t : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -212,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gj = j0 + b * 16 + l4 + 4 * r;
-                c[r] = (gi < n && gj < n) ? G[(size_t)gj * ldc + gi] : make_double2(0.0, 0.0);
+                c[r] = G[(size_t)min(gj, n - 1) * ldc + min(gi, n - 1)];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
