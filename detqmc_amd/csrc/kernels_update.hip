@@ -716,13 +716,23 @@ __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpd
     const int r0 = blockIdx.x * 32;
     // ---- Gr[i, r] = G[I_i, r] - delta ----
     {
+        // all (<= 8) row-gather loads of a thread in flight together: clamped indices, bounds applied at the store
         const int r = r0 + (tid & 31);
-        if (r < ng)
-            for (int i = tid >> 5; i < nI; i += 8) {
-                cplx h = G[(size_t)r * ng + sI[i]];
-                if (r == sI[i]) h.x -= 1.0;
-                Gr[(size_t)r * WD + i] = h;
-            }
+        const int rc = min(r, ng - 1);
+        constexpr int NIT = DQMC_MAX_WDIM / 8;
+        cplx h[NIT];
+        int si[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            si[it] = sI[min((tid >> 5) + 8 * it, nI - 1)];
+            h[it] = G[(size_t)rc * ng + si[it]];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = (tid >> 5) + 8 * it;
+            if (r == si[it]) h[it].x -= 1.0;
+            if (r < ng && i < nI) Gr[(size_t)r * WD + i] = h[it];
+        }
     }
     // ---- X tile: rows r0 .. r0 + 31, columns 16 wave .. 16 wave + 15 ----
     const int c0 = wave * 16;
@@ -736,12 +746,17 @@ __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpd
         const int gk = k0 + l4;
         const bool kok = gk < nI;
         // first MFMA operand (m = column of X, k): W[k][c0 + l15];  second (k, n = row): G[r0 + a 16 + l15, I_k]
-        const cplx w = (kok && c0 + l15 < nI) ? Wg[(size_t)(c0 + l15) * WD + gk] : make_double2(0.0, 0.0);
-        const size_t col = kok ? (size_t)sI[gk] * ng : 0;
+        const int gkc = min(gk, nI - 1);
+        const cplx wl = Wg[(size_t)min(c0 + l15, nI - 1) * WD + gkc];          // clamped address + select: no branch, no wait per load
+        const cplx w = (kok && c0 + l15 < nI) ? wl : make_double2(0.0, 0.0);
+        const size_t col = (size_t)sI[gkc] * ng;
+        cplx gl[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) gl[a] = G[col + min(r0 + a * 16 + l15, ng - 1)];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int r = r0 + a * 16 + l15;
-            const cplx g = (kok && r < ng) ? G[col + r] : make_double2(0.0, 0.0);
+            const cplx g = (kok && r < ng) ? gl[a] : make_double2(0.0, 0.0);
             acc_re[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, g.x, acc_re[a], 0, 0, 0);
             acc_re[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w.y, g.y, acc_re[a], 0, 0, 0);
             acc_im[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, g.x, acc_im[a], 0, 0, 0);
