@@ -36,7 +36,7 @@ WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=int(os.envi
                 stabilisation=os.environ.get("DQMC_STABILISATION", "qr"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
-DEFAULT_BATCH = 64             # chains per kernel context (lockstep batch); 4 x 64 chains = 61 GB of the 288 GB HBM
+DEFAULT_BATCH = 128            # chains per kernel context (lockstep batch); 4 x 128 chains = 123 GB of the 288 GB HBM
 DEFAULT_WORKERS = 4            # contexts per GPU: the latency-bound kernels of one overlap the streaming kernels of the others
 
 
