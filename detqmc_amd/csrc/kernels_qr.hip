@@ -235,8 +235,11 @@ __global__ __launch_bounds__(NT) void k_qr_panel(cplx* __restrict__ A, int lda, 
     for (int r = 0; r < RPT; ++r) {
         int row = s.tid + r * NT;
 #pragma unroll
-        for (int c = 0; c < QR_NB; ++c)
-            s.a[r][c] = (row < s.rows && c < s.ncols) ? A[(size_t)(j0 + c) * lda + (j0 + row)] : make_double2(0.0, 0.0);
+        for (int c = 0; c < QR_NB; ++c) {
+            // clamped address + select (a guarded load costs an exec-masked branch and an s_waitcnt vmcnt(0) each)
+            const cplx t = A[(size_t)(j0 + min(c, s.ncols - 1)) * lda + (j0 + min(row, s.rows - 1))];
+            s.a[r][c] = (row < s.rows && c < s.ncols) ? t : make_double2(0.0, 0.0);
+        }
     }
     __syncthreads();
     QrPanelStep<0>::run(s);
@@ -305,8 +308,12 @@ __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, i
         for (int idx = tid; idx < 64 * QR_NB; idx += 256) {
             int rr = idx & 63, cc = idx >> 6;
             int row = r0 + rr;
-            sV[rr][cc] = (row < rows && cc < nb) ? Vp[(size_t)cc * ldv + row] : make_double2(0.0, 0.0);
-            sC[rr][cc] = (row < rows && cc < nc) ? C[(size_t)(c0 + cc) * ldc + row] : make_double2(0.0, 0.0);
+            // clamped addresses + select: guarded loads are issued one at a time (branch + s_waitcnt vmcnt(0) each)
+            const int rowc = min(row, rows - 1);
+            const cplx tv = Vp[(size_t)min(cc, nb - 1) * ldv + rowc];
+            const cplx tc = C[(size_t)(c0 + min(cc, nc - 1)) * ldc + rowc];
+            sV[rr][cc] = (row < rows && cc < nb) ? tv : make_double2(0.0, 0.0);
+            sC[rr][cc] = (row < rows && cc < nc) ? tc : make_double2(0.0, 0.0);
         }
         __syncthreads();
 #pragma unroll
@@ -353,12 +360,13 @@ __global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, i
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int k = ks * 4 + l4;
-            vf[ks] = (rok && k < nb) ? Vp[(size_t)k * ldv + row] : make_double2(0.0, 0.0);   // B(k, n = row)
+            const cplx tv = Vp[(size_t)min(k, nb - 1) * ldv + min(row, rows - 1)];
+            vf[ks] = (rok && k < nb) ? tv : make_double2(0.0, 0.0);                          // B(k, n = row)
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = l4 + 4 * r;
-            cv[r] = (rok && j < nc) ? C[(size_t)(c0 + j) * ldc + row] : make_double2(0.0, 0.0);
+            cv[r] = C[(size_t)(c0 + min(j, nc - 1)) * ldc + min(row, rows - 1)];             // only stored back where rok && j < nc
         }
         q_v4d d_re = (q_v4d)(0.0), d_im = (q_v4d)(0.0);
 #pragma unroll

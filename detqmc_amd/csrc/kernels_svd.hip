@@ -231,13 +231,11 @@ __global__ __launch_bounds__(256) void k_jacobi_round(cplx* __restrict__ A, cplx
         int row = tid + r * 256;
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) {
-            if (row < n) {
-                body.a[r][c] = A[(size_t)cols[c] * n + row];
-                body.v[r][c] = V[(size_t)cols[c] * n + row];
-            } else {
-                body.a[r][c] = make_double2(0.0, 0.0);
-                body.v[r][c] = make_double2(0.0, 0.0);
-            }
+            // clamped address + select: a guarded load costs an exec-masked branch and an s_waitcnt vmcnt(0) each
+            const cplx ta = A[(size_t)cols[c] * n + min(row, n - 1)];
+            const cplx tv = V[(size_t)cols[c] * n + min(row, n - 1)];
+            body.a[r][c] = (row < n) ? ta : make_double2(0.0, 0.0);
+            body.v[r][c] = (row < n) ? tv : make_double2(0.0, 0.0);
         }
     }
     body.init_norms();
