@@ -215,22 +215,28 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); }
-#pragma unroll 2
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int gk = k0 + l4;
-        cplx af[2], bf[2];
+    // operand fragments of k-step k0 (clamped addresses + select: no branch, no wait per load); the fragments of step
+    // k0 + 4 are requested before the MFMAs of step k0 are issued
+    auto loadab = [&](int k0, cplx (&a_)[2], cplx (&b_)[2]) {
+        const int gk = k0 + l4, gkc = min(gk, K - 1);
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int gi = i0 + a * 16 + l15;
-            const cplx t = X[(size_t)min(gk, K - 1) * ldx + min(gi, n - 1)];      // clamped address + select: no branch, no wait
-            af[a] = (gk < K && gi < n) ? t : make_double2(0.0, 0.0);
+            const cplx t = X[(size_t)gkc * ldx + min(gi, n - 1)];
+            a_[a] = (gk < K && gi < n) ? t : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int gj = j0 + b * 16 + l15;
-            const cplx t = Gr[(size_t)min(gj, n - 1) * ldg + min(gk, K - 1)];
-            bf[b] = (gk < K && gj < n) ? t : make_double2(0.0, 0.0);
+            const cplx t = Gr[(size_t)min(gj, n - 1) * ldg + gkc];
+            b_[b] = (gk < K && gj < n) ? t : make_double2(0.0, 0.0);
         }
+    };
+    cplx af[2], bf[2];
+    loadab(0, af, bf);
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        cplx an[2], bn[2];
+        loadab(k0 + 4, an, bn);                  // past the end: clamped address, masked to zero, never used
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -240,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
                 acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].x, acc_im[a][b], 0, 0, 0);
                 acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
             }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { af[a] = an[a]; bf[a] = bn[a]; }
     }
     // The tile of G is read only now, 16 x 16 at a time: holding it across the MFMA loop costs 64 VGPRs, i.e. the
     // second workgroup per CU whose loads would overlap this one's MFMAs (scripts/micro/flush_tiles.hip: 75 -> 55 us).
