@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
         //      the matrix cores work on the current one (explicit double buffer: left alone the compiler keeps ONE
         //      register quad for v and waits for every load right after issuing it) ----
         q_v4d w_re = (q_v4d)(0.0), w_im = (q_v4d)(0.0);
-        constexpr int CH = (NE < 8 || NCH >= 7) ? 4 : 8;     // NCH >= 7: C alone takes half of the register file
+        constexpr int CH = (NE < 8) ? 4 : 8;
         cplx va[CH], vb[CH];
         auto loadv = [&](const cplx* base, int e0, cplx (&dst)[CH]) {
 #pragma unroll
