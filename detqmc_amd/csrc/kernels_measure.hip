@@ -61,7 +61,16 @@ __global__ __launch_bounds__(256) void k_measure_accum(DevModel dm, const cplx* 
         // greenK0 += [2] Re sum(gs), greenLocal += [2] Re tr(gs) / (4 N)   (:565-588)
         double s = 0.0, t = 0.0;
         const size_t total = (size_t)ng * ng;
-        for (size_t idx = tid; idx < total; idx += 256) s += gs[idx].x;
+        {   // one workgroup sums n_g^2 elements: eight independent partial sums keep eight loads per thread in flight
+            double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            size_t idx = tid;
+            for (; idx + 7 * 256 < total; idx += 8 * 256) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] += gs[idx + (size_t)u * 256].x;
+            }
+            for (; idx < total; idx += 256) p[0] += gs[idx].x;
+            s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        }
         for (int i = tid; i < ng; i += 256) t += gs[(size_t)i * ng + i].x;
         s = block_sum(s, red);
         t = block_sum(t, red);
