@@ -192,7 +192,7 @@ typedef struct dqmc_profile {
                                   decide, other, gather, flush (G += X Gr), unused */
     uint64_t launches[8];
     uint64_t svd_calls, svd_sweeps_total, svd_sweeps_max, qr_calls;
-    double gemm_flops;         /* 8 M N K summed over the launches of family gemm */
+    double gemm_flops;         /* 8 M N K summed over the launches of family gemm (4 M N K for the triangular chaining product) */
     double decomp_round_ms;    /* SVD mode: time inside batches of back-to-back Jacobi rounds only */
     uint64_t decomp_rounds;
     uint64_t blocks_nonempty;   /* delayed-update blocks of the selected chain that really flushed (since create) */
