@@ -3,18 +3,25 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One process per GPU (for N > 1 launched by torch.distributed.run).  A "step" is one
-sweepThermalization() of every replica the rank drives: --workers W worker processes per GPU (own HIP
-runtime and hardware queues each), each holding --batch B independent chains that advance in lockstep
-through ONE kernel context (every launch carries all B chains, grid.z = chain).  value = all sweeps of all
-chains / time; `sweeps_per_s_per_chain` is the single-chain rate.  Workload: SDW O(2), L=16, beta=10,
-dtau=0.1 (m=100), s=10, checkerboard, delayed updates (delaySteps=16), no fermion measurements (SURVEY.md
-section 8d).  Every chain is an independent Markov chain with its own RNG stream (simindex), like the
-replicas the reference's DetQMC / DetQMCPT run one per MPI process; there is no
-data-path collective, so the value is the sum over ranks and scaling is weak.  Rank 0 prints ONE
-JSON line with `roofline` (dominant kernel, timed live with HIP events on the kernel's own stream)
-and, at N=1, `cpu_baseline` (the real reference binary from oracle/_ref when it runs on this host,
-else the numpy oracle port) on a bounded sample of the same workload.
+Starts by itself for any N: the parent never touches a GPU, it spawns `--workers` worker processes per GPU
+(`--device i`), each holding one kernel context with `--batch` independent Markov chains that advance in lockstep
+(every launch carries all chains of the context).  Under torch.distributed.run (WORLD_SIZE > 1, one rank per GPU) every
+rank drives the workers of ITS GPU and the ranks meet at a barrier on both sides of the timed region; the result is the
+same line.  A "step" is one sweepThermalization() of every chain.  value = all sweeps of all chains of all GPUs / the
+slowest participant's time.  Workload: SDW O(2), L=16, beta=10, dtau=0.1 (m=100), s=10, checkerboard, delayed updates,
+no fermion measurements.  Every chain is an independent Markov chain with its own RNG stream
+(simindex), like the replicas the reference runs one per MPI process (`mpirun -n 8`); there is no data-path collective,
+so scaling is weak.
+
+The ONE JSON line carries, besides the contract's keys:
+  per_gpu                    sweeps/s of every GPU
+  one_context_sweeps_per_s   ONE process / ONE context alone on the GPU (what a DetQMCPT port owning one process per GPU gets)
+  single_chain_sweeps_per_s  one context x one chain (latency of a single Markov chain)
+  roofline                   the kernel family with the largest device time, measured with HIP events on the kernel's own
+                             stream while ONE context has the GPU to itself (reproducible with rocprofv3, profiles/),
+                             against its BINDING roof (HBM or fp64 MFMA, whichever fraction is larger)
+  roofline_other_kernels, roofline_whole_step
+  cpu_baseline, cpu_baseline_all_cores   the real reference binary (oracle/_ref) on this host, N = 1 only
 """
 import argparse
 import json
@@ -34,35 +41,48 @@ WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=int(os.envi
                 rngSeed=1020304050,
                 # same Green's functions and Markov chain as the reference-exact "svd" mode (tests), ~10x cheaper
                 stabilisation=os.environ.get("DQMC_STABILISATION", "qr"))
+# production variant (reference example/simulation.job:27-44): a global shift move every 10 sweeps
+if os.environ.get("DQMC_BENCH_GLOBAL_SHIFT"):
+    WORKLOAD.update(globalShift=True, globalUpdateInterval=int(os.environ["DQMC_BENCH_GLOBAL_SHIFT"]))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
-DEFAULT_BATCH = 128            # chains per kernel context (lockstep batch); 4 x 128 chains = 123 GB of the 288 GB HBM
+DEFAULT_BATCH = 128            # chains per kernel context (lockstep batch)
 DEFAULT_WORKERS = 4            # contexts per GPU: the latency-bound kernels of one overlap the streaming kernels of the others
+FAKE = bool(os.environ.get("DQMC_BENCH_FAKE_WORKER"))     # CPU rehearsal of the control flow (tests/test_bench_cpu.py)
 
 
-def cpu_baseline(max_seconds=200):
-    """Reference CPU sweeps/s on this host for the same workload (bounded sample)."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_fast_o2")
-    args = ["L=16", "beta=10", "dtau=0.1", "s=10", "delaySteps=16", "opdim=2", "mode=time", "warmup=0", "sweeps=1"]
-    if os.path.exists(exe):
-        try:
-            env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
-            out = subprocess.run([exe, "/tmp"] + args, capture_output=True, text=True, timeout=max_seconds, env=env)
-            for line in out.stdout.splitlines():
-                if line.startswith("REF_TIMING"):
-                    kv = dict(tok.split("=") for tok in line.split()[1:])
-                    return {"value": float(kv["sweeps_per_s"]), "unit": "sweeps/s", "cores": 1, "kind": "reference",
-                            "sample": "crstnbr/detqmc DetSDW<CB_ASSAAD_BERG,2> built from the reference sources "
-                                      "(-O3 -ffast-math -mavx2 -mfma, MKL 1 thread): 1 sweepThermalization() after "
-                                      "init, %s s" % kv["seconds"]}
-        except Exception as e:                      # binary cannot run on this host: use the port
-            sys.stderr.write("reference binary unusable (%r), timing the oracle port instead\n" % (e,))
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the real reference binary, 1 core and all cores
+# ---------------------------------------------------------------------------------------------------------------------
+REF_EXE = os.path.join(ROOT, "oracle", "_ref", "ref_harness_fast_o2")
+REF_ARGS = ["L=16", "beta=10", "dtau=0.1", "s=10", "delaySteps=16", "opdim=2", "mode=time"]
+REF_DESC = ("crstnbr/detqmc DetSDW<CB_ASSAAD_BERG,2> built from the reference sources "
+            "(-O3 -ffast-math -mavx2 -mfma, MKL 1 thread per process)")
+
+
+def _ref_start(warmup, sweeps, tag):
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    d = "/tmp/dqmc_ref_%d_%s" % (os.getpid(), tag)
+    os.makedirs(d, exist_ok=True)
+    return subprocess.Popen([REF_EXE, d] + REF_ARGS + ["warmup=%d" % warmup, "sweeps=%d" % sweeps], stdout=subprocess.PIPE,
+                            stderr=subprocess.DEVNULL, text=True, env=env)
+
+
+def _ref_finish(p, timeout):
+    out, _ = p.communicate(timeout=timeout)
+    for line in out.splitlines():
+        if line.startswith("REF_TIMING"):
+            kv = dict(tok.split("=") for tok in line.split()[1:])
+            return int(kv["sweeps"]), float(kv["seconds"])
+    raise RuntimeError("reference harness printed no REF_TIMING line")
+
+
+def cpu_baseline_port():
+    """fallback when the reference binary cannot run on this host: the numpy oracle, bounded sample"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))   # cpu_baseline leg: the oracle is what is timed here
     from detsdw_oracle import DetSDWOracle, SDWParams as OP
     kw = {k: v for k, v in WORKLOAD.items() if k in OP.__dataclass_fields__ and k != "stabilisation"}
     o = DetSDWOracle(OP(**kw))
-    # bounded sample: the first slices of a down sweep (local updates + wrap) for ~20 s, one stabilisation step,
-    # extrapolated to the m slices and n stabilisation steps of a full sweep
     m, n, s_ = o.m, o.n, o.s
     t0 = time.time()
     k, nsl = m, 0
@@ -71,10 +91,9 @@ def cpu_baseline(max_seconds=200):
         o.wrapDownGreen(k)
         k -= 1
         nsl += 1
-    t_slice = (time.time() - t0) / nsl
-    sweep_s = m * t_slice
+    sweep_s = m * (time.time() - t0) / nsl
     sample = "%d of %d time slices (local updates + wrap) in %.1f s" % (nsl, m, time.time() - t0)
-    if k == (n - 1) * s_:                      # the slices of the top interval are done: time one advanceDownGreen too
+    if k == (n - 1) * s_:
         t1 = time.time()
         o.advanceDownGreen(n)
         sweep_s += n * (time.time() - t1)
@@ -87,52 +106,115 @@ def cpu_baseline(max_seconds=200):
             "sample": "oracle/detsdw_oracle.py (numpy + scipy zgesvd), extrapolated to a full sweep from " + sample}
 
 
+class CpuBaseline:
+    """1 core: ONE reference process, 1 warm-up + `sweeps` timed sweepThermalization(); may run while the GPU post-phases
+    (one busy host thread) are in progress -- the box has 16+ cores.  All cores: one reference process per core at the same
+    time (how the reference scales: independent replicas under mpirun), aggregate sweeps/s."""
+
+    def __init__(self, sweeps=2):
+        self.sweeps = sweeps
+        self.p1 = None
+        if os.path.exists(REF_EXE) and not FAKE:
+            try:
+                self.p1 = _ref_start(1, sweeps, "one")
+            except Exception as e:
+                sys.stderr.write("reference binary unusable (%r)\n" % (e,))
+
+    def finish(self):
+        out = {}
+        if self.p1 is None:
+            out["cpu_baseline"] = cpu_baseline_port()
+            return out
+        try:
+            n, sec = _ref_finish(self.p1, 600)
+        except Exception as e:
+            sys.stderr.write("reference binary failed (%r), timing the oracle port instead\n" % (e,))
+            out["cpu_baseline"] = cpu_baseline_port()
+            return out
+        out["cpu_baseline"] = {"value": n / sec, "unit": "sweeps/s", "cores": 1, "kind": "reference",
+                               "sample": REF_DESC + ": %d sweepThermalization() after init + 1 warm-up sweep, %.1f s" % (n, sec)}
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            ps = [_ref_start(1, self.sweeps, "all%d" % i) for i in range(ncpu)]
+            res = [_ref_finish(p, 900) for p in ps]
+            out["cpu_baseline_all_cores"] = {
+                "value": sum(n_ / s_ for n_, s_ in res), "unit": "sweeps/s", "cores": ncpu, "kind": "reference",
+                "sample": REF_DESC + ": %d independent replicas at the same time (one process per core, as under mpirun), each %d "
+                                     "sweepThermalization() after init + 1 warm-up sweep; slowest %.1f s, fastest %.1f s"
+                                     % (ncpu, self.sweeps, max(s_ for _, s_ in res), min(s_ for _, s_ in res))}
+        except Exception as e:
+            sys.stderr.write("all-cores baseline failed (%r)\n" % (e,))
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# worker: one kernel context
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeBatch:
+    """stands in for DetSDWBatch in the CPU rehearsal of the control flow (no GPU, no library)"""
+
+    def __init__(self, B):
+        self.B = B
+
+    def sweepThermalization(self):
+        time.sleep(0.01)
+
+
 def worker(a, readline=None, emit=None):
-    """One kernel context with a.batch chains in lockstep: build, warm up, wait for GO, run, report."""
+    """build, warm up, wait for GO, run the timed steps, report; then optionally repeat ALONE with profiling on"""
     import dataclasses
     readline = readline or sys.stdin.readline
     emit = emit or (lambda line: print(line, flush=True))
-    from detqmc_amd import DetSDWBatch, SDWParams
     B = max(1, a.batch)
-    p0 = SDWParams(device=a.device, **WORKLOAD)
-    batch = DetSDWBatch([dataclasses.replace(p0, simindex=a.simindex * B + i) for i in range(B)])
-    ctx = batch.kernel_context
+    if FAKE:
+        batch, ctx = _FakeBatch(B), None
+    else:
+        from detqmc_amd import DetSDWBatch, SDWParams
+        p0 = SDWParams(device=a.device, **WORKLOAD)
+        batch = DetSDWBatch([dataclasses.replace(p0, simindex=a.simindex * B + i) for i in range(B)])
+        ctx = batch.kernel_context
     for _ in range(a.warmup):
         batch.sweepThermalization()
-    blocks0 = 0
-    if a.profile:
-        blocks0 = ctx.profile_read()["blocks_nonempty"]
-        ctx.profile_enable(True)
-    ctx.synchronize()
+    if ctx:
+        ctx.synchronize()
     emit("READY")
     if readline().strip() != "GO":
         return
     t0 = time.perf_counter()
     for _ in range(a.steps):
         batch.sweepThermalization()          # one C call per lockstep sweep of all B chains
-    ctx.synchronize()
+    if ctx:
+        ctx.synchronize()
     dt = time.perf_counter() - t0
-    info = batch.chain(0).info
-    out = {"dt": dt, "n_g": info.n_g, "m": info.m,
-           "acceptance": [batch.chain(i).info.lastAccRatioLocal_phi for i in range(min(B, 4))]}
-    if a.profile:
-        prof = ctx.profile_read()
-        out["prof"] = {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}
-        out["prof"]["blocks_nonempty"] -= blocks0
+    if FAKE:
+        out = {"dt": dt, "n_g": 512, "m": 100, "acceptance": [0.5]}
+    else:
+        info = batch.chain(0).info
+        out = {"dt": dt, "n_g": info.n_g, "m": info.m,
+               "acceptance": [batch.chain(i).info.lastAccRatioLocal_phi for i in range(min(B, 4))]}
     emit("RESULT " + json.dumps(out))
-    # worker 0 is then asked to repeat the steps ALONE on the GPU: kernel durations free of the other contexts
+    # then, if asked: the same steps ALONE on the GPU with per-kernel HIP-event timing (kernel durations free of other contexts)
     if readline().strip() == "SOLO":
-        blocks0 = ctx.profile_read()["blocks_nonempty"]
+        if FAKE:
+            emit("SOLO " + json.dumps({"dt": dt, "prof": None}))
+            return
         ctx.profile_enable(True)
         t0 = time.perf_counter()
         for _ in range(a.steps):
             batch.sweepThermalization()
         ctx.synchronize()
+        dts = time.perf_counter() - t0
         prof = ctx.profile_read()
-        prof["blocks_nonempty"] -= blocks0
-        emit("SOLO " + json.dumps({"dt": time.perf_counter() - t0,
+        ctx.profile_enable(False)
+        # and once more without the event records: the rate of ONE context
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            batch.sweepThermalization()
+        ctx.synchronize()
+        emit("SOLO " + json.dumps({"dt": time.perf_counter() - t0, "dt_profiled": dts,
                                    "prof": {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}}))
-    batch.close()
+    if not FAKE:
+        batch.close()
 
 
 class InprocWorker:
@@ -144,10 +226,8 @@ class InprocWorker:
         import queue
         import threading
         self.inq, self.outq = queue.Queue(), queue.Queue()
-        wa = copy.copy(a)
-        wa.profile = True
         self.stdin, self.stdout = self, self
-        self.th = threading.Thread(target=worker, args=(wa, self.inq.get, self.outq.put), daemon=True)
+        self.th = threading.Thread(target=worker, args=(copy.copy(a), self.inq.get, self.outq.put), daemon=True)
         self.th.start()
 
     def write(self, line):
@@ -171,6 +251,136 @@ class InprocWorker:
         self.th.join()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# rooflines from the per-family HIP-event times of ONE context alone on the GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def qr_apply_work(nn):
+    """algorithmic bytes and flops of the k_qr_apply_reg launches of ONE factorisation incl. explicit Q (run_qr,
+    kernels_qr.hip): a launch reads and writes its columns once and, per block reflector, does two rows x 16 x ncols
+    complex products (W = V^H C, C += V W2)."""
+    byt = flo = 0.0
+    p, npan = 0, (nn + 15) // 16
+
+    def add(rows, ncols, nref):
+        nonlocal byt, flo
+        byt += 2 * 16.0 * rows * ncols + nref * 16.0 * rows * 16
+        flo += nref * 2 * 8.0 * rows * 16 * ncols
+
+    while p < npan:
+        left = nn - p * 16
+        if nn <= 512 and left > 64:
+            for rows, ncols, nref in ((left, 16, 1), (left, 32, 2), (left - 32, 16, 1), (left, left - 64, 4)):
+                add(rows, ncols, nref)
+            p += 4
+        elif nn <= 512 and left > 32:
+            add(left, 16, 1)
+            add(left, left - 32, 2)
+            p += 2
+        else:
+            nbp = min(16, left)
+            if left - nbp > 0:
+                add(left, left - nbp, 1)
+            p += 1
+    p = npan - 1
+    while p >= 0:                       # formation of Q, reflectors in reverse order
+        cnt = 1
+        if nn <= 512 and min(16, nn - p * 16) == 16:
+            cnt = 4 if p >= 3 else (2 if p >= 1 else 1)
+        lo = p - (cnt - 1)
+        add(nn - lo * 16, nn - lo * 16, cnt)
+        p -= cnt
+    return byt, flo
+
+
+def rooflines(rawprof, n, m, B, traffic):
+    """one entry per kernel family: achieved algorithmic GB/s and TFLOP/s over the family's device time, the fraction of
+    each peak, and `bound` = the roof it is closer to.  `traffic` = HBM bytes per launch from the PMC passes, if taken."""
+    prof = {k: (tuple(v) if isinstance(v, list) else v) for k, v in rawprof.items()}
+    N, MSF, D, OPD, s = n // 2, 2, WORKLOAD["delaySteps"], WORKLOAD["opdim"], WORKLOAD["s"]
+
+    def entry(name, kernel, ms, launches, total_bytes, total_flops, note, latency_bound=False):
+        gbs = total_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        tfs = total_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        fh, fm = gbs / HBM_PEAK_GBS, tfs / MFMA_F64_PEAK_TF
+        mf = fm > fh
+        e = {"family": name, "kernel": kernel, "bound": "mfma" if mf else "hbm",
+             "achieved": tfs if mf else gbs, "peak": MFMA_F64_PEAK_TF if mf else HBM_PEAK_GBS, "unit": "TFLOP/s" if mf else "GB/s",
+             "frac": fm if mf else fh, "traffic": None,
+             "hbm_GBps": gbs, "hbm_frac": fh, "mfma_TFLOPps": tfs, "mfma_frac": fm,
+             "algorithmic_bytes_per_launch": total_bytes / max(launches, 1), "algorithmic_flops_per_launch": total_flops / max(launches, 1),
+             "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches, "device_ms": ms, "chains_per_launch": B, "note": note}
+        if latency_bound:
+            e["latency_bound"] = True
+        t = (traffic or {}).get(name)
+        if t:
+            e["traffic"] = t["hbm_bytes_per_launch"]
+            e["traffic_note"] = t.get("note", "")
+        return e
+
+    roofs = []
+    blocks = max(prof["blocks_nonempty"], 1)          # (chain, block) pairs that flushed
+    acc = prof["updates_accepted"]                     # accepted updates, all chains
+    # decision kernel: per proposal (OPDIM+1) uniforms, 2*OPDIM neighbouring-slice field values, cosh/sinh, G[c,I], G[I,c],
+    # G[c,c], G[c,prev], G[prev,c] with |I| = MSF*D/2 on average
+    cand_bytes = (OPD + 1) * 8 + 2 * OPD * 8 + 16 + (2 * MSF * (MSF * D // 2) + 3 * MSF * MSF) * 16
+    nslices = prof["decide"][1] // ((N + D - 1) // D)
+    roofs.append(entry("decide", "k_update_decide<2>", *prof["decide"], float(N) * cand_bytes * nslices * B, 0.0,
+                       "sequential Metropolis chain of one slice: ONE workgroup per chain by construction -- latency bound, "
+                       "neither roof is its limit; launches of finished slices exit at once", latency_bound=True))
+    if WORKLOAD["stabilisation"] == "svd":
+        roofs.append(entry("decomp", "k_jacobi_round<8,2>", prof["decomp_round_ms"], prof["decomp_rounds"],
+                           4.0 * n * n * 16.0 * B * prof["decomp_rounds"], 0.0, "one Jacobi round reads and writes every column of A and V once"))
+    else:
+        qb, qf = qr_apply_work(n)
+        calls = max(prof["qr_calls"], 1)
+        # the Green's-function factorisation applies Q^H to a full matrix instead of forming Q: same launch shapes
+        roofs.append(entry("qr_apply", "k_qr_apply_reg", prof["decomp_round_ms"], max(prof["decomp_rounds"], 1), qb * calls * B, qf * calls * B,
+                           "block reflectors of up to 4 panels applied to the trailing matrix / to Q with the columns in registers: "
+                           "one read + one write per launch, 2 x 8 rows 16 ncols flop per reflector"))
+        rest_ms = max(prof["decomp"][0] - prof["decomp_round_ms"], 0.0)
+        roofs.append(entry("qr_rest", "k_qr_panel, triangular solve, pivoting glue", rest_ms, max(prof["decomp"][1] - prof["decomp_rounds"], 1),
+                           0.0, 0.0, "panel factorisations (a chain of dependent reductions: latency bound) and the small kernels "
+                           "around the QR; no roofline claimed", latency_bound=True))
+    bl = prof["bmult"][1]
+    nst = (m + s - 1) // s
+    slices_per_launch = (2.0 * m + nst * s) / (2.0 * m + nst)      # per sweep: 2 m single-slice wraps + n chains of s slices
+    roofs.append(entry("bmult", "k_bmult_chain", *prof["bmult"], 2 * 16.0 * n * n * B * bl, 56.0 * n * n * B * bl * slices_per_launch,
+                       "one read + one write of A per chain of slices; ~56 flop per element and slice on the vector ALU"))
+    roofs.append(entry("gather", "k_update_gather", *prof["gather"], 4 * 16.0 * n * MSF * acc, 8.0 * n * MSF * MSF * acc * acc / blocks,
+                       "X = G[:,I] W and Gr = G[I,:] - E: reads the accepted rows/columns of G, writes the flush operands; "
+                       "blocks without work exit at once"))
+    roofs.append(entry("flush", "k_flush (G += X Gr)", *prof["flush"], 2 * 16.0 * n * n * blocks + 2 * 16.0 * n * MSF * acc, 8.0 * n * n * MSF * acc,
+                       "read-modify-write of G once per delayed-update block and chain that accepted an update (+ the operand "
+                       "panels), 8 n_g^2 MSF flop per accepted update on the matrix cores"))
+    gms, gl = prof["gemm"]
+    roofs.append(entry("gemm", "k_zgemm<2,2>", gms, gl, 4 * 16.0 * n * n * B * gl, prof["gemm_flops"],
+                       "n_g^3 complex products on v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex step)"))
+    roofs.sort(key=lambda r: -r["device_ms"])
+    tot_ms = sum(r["device_ms"] for r in roofs)
+    tot_b = sum(r["algorithmic_bytes_per_launch"] * r["launches"] for r in roofs if not r.get("latency_bound"))
+    tot_f = sum(r["algorithmic_flops_per_launch"] * r["launches"] for r in roofs)
+    whole = {"device_ms": tot_ms, "hbm_GBps": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0,
+             "mfma_TFLOPps": tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0}
+    whole["hbm_frac"] = whole["hbm_GBps"] / HBM_PEAK_GBS
+    whole["mfma_frac"] = whole["mfma_TFLOPps"] / MFMA_F64_PEAK_TF
+    whole["note"] = "algorithmic bytes and flops of all families / summed device time of one context alone on the GPU"
+    return prof, roofs, whole
+
+
+def load_traffic(B, D):
+    """HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, WRITE_SIZE),
+    taken with scripts/pmc_collect.sh + scripts/pmc_traffic_summary.py for this batch size and delay depth"""
+    for rnd in ("r02",):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_b%d_d%d.json" % (rnd, B, D))
+        if os.path.exists(path):
+            try:
+                return json.load(open(path))["families"]
+            except Exception:
+                pass
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,13 +390,12 @@ def main():
     ap.add_argument("--workers", type=int, default=int(os.environ.get("DQMC_WORKERS_PER_GPU", str(DEFAULT_WORKERS))),
                     help="worker processes (kernel contexts) per GPU")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DQMC_CHAINS_PER_CONTEXT", str(DEFAULT_BATCH))),
-                    help="independent Markov chains per context, advanced in lockstep (grid.z = chain)")
+                    help="independent Markov chains per context, advanced in lockstep")
     ap.add_argument("--inprocess", action="store_true",
                     help="ONE context in this process instead of worker processes (for rocprofv3)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--simindex", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--profile", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.worker:
         return worker(a)
@@ -194,23 +403,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and a.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
-    dist = None
-    torch = None
-    # DQMC_BENCH_BACKEND=gloo + DQMC_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank control flow on a one-GPU box
-    # (all ranks drive device 0, the ranks themselves stay off the GPU); the real runs use nccl (= RCCL)
+    one_device = bool(os.environ.get("DQMC_BENCH_ONE_DEVICE"))     # rehearsal on a one-GPU box: every "GPU" is device 0
+    dist = torch = None
     backend = os.environ.get("DQMC_BENCH_BACKEND", "nccl")
-    if os.environ.get("DQMC_BENCH_ONE_DEVICE"):
-        local = 0
     if world > 1:
+        # launched by torch.distributed.run, one rank per GPU: the ranks only meet at the barriers around the timed region
         import torch
         import torch.distributed as dist
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            torch.cuda.set_device(0 if one_device else local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", 0 if one_device else local))
         else:
             dist.init_process_group(backend)
+        n_gpus, my_gpus = world, [local]
+    else:
+        # started as plain `python bench.py --gpus N`: this process drives the workers of all N GPUs itself
+        n_gpus, my_gpus = max(1, a.gpus), list(range(max(1, a.gpus)))
 
     def fence():
         if dist is not None:
@@ -226,14 +434,21 @@ def main():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
               "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
-    procs = []
+
+    def spawn(device, simindex, batch, steps, warmup):
+        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--device", str(0 if one_device else device), "--simindex",
+               str(simindex), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch)]
+        return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
+
+    procs = []          # (gpu index, process)
     if a.inprocess:
-        a.device, a.simindex = local, rank
-        procs.append(InprocWorker(a))
-    for i in range(0 if a.inprocess else R):
-        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--device", str(local), "--simindex",
-               str(rank * R + i), "--steps", str(a.steps), "--warmup", str(a.warmup), "--batch", str(B)] + (["--profile"] if i == 0 else [])
-        procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env))
+        a.device, a.simindex = (0 if one_device else local), rank
+        procs.append((my_gpus[0], InprocWorker(a)))
+    else:
+        for g in my_gpus:
+            gi = g if world == 1 else rank          # global GPU index -> distinct RNG streams on every GPU
+            for i in range(R):
+                procs.append((gi, spawn(g, gi * R + i, B, a.steps, a.warmup)))
 
     def read_tag(p, tag):
         while True:
@@ -243,140 +458,62 @@ def main():
             if line.startswith(tag):
                 return line[len(tag):].strip()
 
-    for p in procs:
+    def send(p, word):
+        p.stdin.write(word + "\n")
+        p.stdin.flush()
+
+    for _, p in procs:
         read_tag(p, "READY")            # replicas built, warm-up sweeps done, devices idle
     fence()
     t0 = time.perf_counter()
-    for p in procs:
-        p.stdin.write("GO\n")
-        p.stdin.flush()
-    results = [json.loads(read_tag(p, "RESULT")) for p in procs]    # each worker synchronised its stream
+    for _, p in procs:
+        send(p, "GO")
+    results = [json.loads(read_tag(p, "RESULT")) for _, p in procs]    # each worker synchronised its stream
     fence()
     dt = time.perf_counter() - t0
+    # per-GPU rate: the chains of a GPU over the time of its slowest context
+    per_gpu = {}
+    for (g, _), r in zip(procs, results):
+        per_gpu[g] = max(per_gpu.get(g, 0.0), r["dt"])
+    per_gpu = [R * B * a.steps / per_gpu[g] for g in sorted(per_gpu)]
+
+    # post-phase (rank 0, first GPU): context 0 alone on the GPU, profiled and unprofiled; everybody else leaves
+    lead = rank == 0
     solo = None
-    for i, p in enumerate(procs):
-        p.stdin.write("SOLO\n" if (i == 0 and rank == 0) else "QUIT\n")
-        p.stdin.flush()
-    if rank == 0:
-        solo = json.loads(read_tag(procs[0], "SOLO"))
-    for p in procs:
-        p.wait()
+    for i, (_, p) in enumerate(procs):
+        send(p, "SOLO" if (lead and i == 0) else "QUIT")
+    for i, (_, p) in enumerate(procs):
+        if not (lead and i == 0):
+            p.wait()
+    cpu = CpuBaseline() if (lead and n_gpus == 1 and not a.no_cpu_baseline) else None     # 1-core run overlaps the post-phases
+    single = None
+    if lead:
+        solo = json.loads(read_tag(procs[0][1], "SOLO"))
+        procs[0][1].wait()
+        if not a.inprocess:
+            sp = spawn(my_gpus[0], 9999, 1, max(2, min(a.steps, 4)), 1)        # one context x ONE chain
+            read_tag(sp, "READY")
+            send(sp, "GO")
+            sr = json.loads(read_tag(sp, "RESULT"))
+            send(sp, "QUIT")
+            sp.wait()
+            single = max(2, min(a.steps, 4)) / sr["dt"]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        allg = [None] * world
+        dist.all_gather_object(allg, per_gpu)
+        per_gpu = [v for part in allg for v in part]
 
-    if rank == 0:
+    if lead:
         r0 = results[0]
         n = r0["n_g"]
-        N, MSF, D, OPD = n // 2, 2, WORKLOAD["delaySteps"], WORKLOAD["opdim"]
-
-        def rooflines(rawprof, sharing):
-            prof = {k: (tuple(v) if isinstance(v, list) else v) for k, v in rawprof.items()}
-
-            def hbm(name, kernel, ms, launches, bytes_per_chain, note, work_launches=None):
-                """achieved = algorithmic bytes of the launches that had work / device time of ALL launches of the kernel;
-                avg_launch_us is over all launches, like rocprofv3's AverageNs."""
-                work = launches if work_launches is None else work_launches
-                bytes_per_launch = bytes_per_chain * B          # every launch carries all B chains of the context
-                us = 1e3 * ms / max(launches, 1)
-                ach = bytes_per_launch * work / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-                return {"family": name, "kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
-                        "avg_launch_us": us, "launches": launches, "launches_with_work": work, "device_ms": ms,
-                        "chains_per_launch": B, "contexts_sharing_the_gpu": sharing, "note": note}
-
-            roofs = []
-            # decision kernel: per proposal (OPDIM+1) uniforms, 2*OPDIM field values of the neighbouring slices, cosh/sinh,
-            # G[c,I], G[I,c], G[c,c], G[c,prev], G[prev,c] with |I| = MSF*D/2 on average; N proposals per slice over
-            # the launches that found work
-            cand_bytes = (OPD + 1) * 8 + 2 * OPD * 8 + 16 + (2 * MSF * (MSF * D // 2) + 3 * MSF * MSF) * 16
-            nblocks = max(prof["blocks_nonempty"], 1)
-            nslices = prof["decide"][1] // ((N + D - 1) // D)
-            roofs.append(hbm("decide", "k_update_decide<2>", *prof["decide"], N * cand_bytes * nslices / nblocks,
-                             "sequential Metropolis chain of one slice: ONE workgroup per chain by construction -- a latency-bound "
-                             "kernel, HBM is not its limit; blocks without work exit at once", nblocks))
-            if WORKLOAD["stabilisation"] == "svd":
-                r = hbm("decomp", "k_jacobi_round<8,2>", prof["decomp_round_ms"], prof["decomp_rounds"], 4.0 * n * n * 16.0,
-                        "one Jacobi round reads and writes every column of A and V once")
-                roofs.append(r)
-            else:
-                # k_qr_apply_reg reads and writes the columns it is given once per launch; the launch sequence of
-                # run_qr (kernels_qr.hip): groups of 4 panels, look-ahead launches for the group's own columns
-                def qr_apply_traffic(nn):
-                    tot, p, npan = 0.0, 0, (nn + 15) // 16
-                    while p < npan:
-                        j0 = p * 16
-                        left = nn - j0
-                        if nn <= 512 and left > 64:
-                            for rows, ncols in ((left, 16), (left, 32), (left - 32, 16), (left, left - 64)):
-                                tot += 2 * 16.0 * rows * ncols
-                            p += 4
-                        elif nn <= 512 and left > 32:
-                            tot += 2 * 16.0 * left * 16 + 2 * 16.0 * left * (left - 32)
-                            p += 2
-                        else:
-                            nbp = min(16, left)
-                            if left - nbp > 0:
-                                tot += 2 * 16.0 * left * (left - nbp)
-                            p += 1
-                    p = npan - 1
-                    while p >= 0:                       # formation of Q, reflectors in reverse order
-                        cnt = 1
-                        if nn <= 512 and min(16, nn - p * 16) == 16:
-                            cnt = 4 if p >= 3 else (2 if p >= 1 else 1)
-                        lo = p - (cnt - 1)
-                        tot += 2 * 16.0 * (nn - lo * 16) ** 2
-                        p -= cnt
-                    return tot
-                qr_bytes = qr_apply_traffic(n)
-                calls = max(prof["qr_calls"], 1)
-                napply = max(prof["decomp_rounds"], 1)
-                roofs.append(hbm("qr_apply", "k_qr_apply_reg", prof["decomp_round_ms"], napply, qr_bytes * calls / napply,
-                                 "block reflectors of up to 4 panels applied to the trailing matrix / to Q while the columns stay in "
-                                 "registers: one read + one write per launch; bytes = average over the launches of a factorisation"))
-                rest_ms = max(prof["decomp"][0] - prof["decomp_round_ms"], 0.0)
-                rest_l = max(prof["decomp"][1] - napply, 1)
-                roofs.append(hbm("qr_rest", "k_qr_panel, triangular solve, pivoting glue", rest_ms, rest_l, 0.0,
-                                 "panel factorisations (one workgroup per chain, a chain of dependent reductions: latency bound) and the "
-                                 "small kernels around the QR; no roofline claimed"))
-            roofs.append(hbm("bmult", "k_bmult_chain", *prof["bmult"], 2 * 16.0 * n * n, "one read + one write of A per chain of slices"))
-            roofs.append(hbm("gather", "k_update_gather", *prof["gather"], 4 * 16.0 * n * MSF * D,
-                             "X = G[:,I] W and Gr = G[I,:] - E; blocks without work exit at once", nblocks))
-            roofs.append(hbm("flush", "k_flush (G += X Gr)", *prof["flush"], 2 * 16.0 * n * n,
-                             "read-modify-write of G once per delayed-update block that accepted an update; the launches of the "
-                             "other blocks exit at once", nblocks))
-            # HBM bytes of k_flush from the PMC counters (collected separately, profiles/r01_pmc_flush_*.json: FETCH_SIZE and
-            # WRITE_SIZE passes, FETCH doubled as MI355X_MICROARCH.md prescribes), per launch that had work, if the file
-            # was taken with this run's chains per launch and delaySteps
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_flush_b%d_d%d.json" % (B, D))
-            if os.path.exists(pmc):
-                try:
-                    for r_ in roofs:
-                        if r_["family"] == "flush":
-                            r_["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch_with_work"]
-                            r_["traffic_note"] = "per launch with work, rocprofv3 --pmc, " + os.path.basename(pmc)
-                except Exception:
-                    pass
-            gms, gl = prof["gemm"]
-            tf = prof["gemm_flops"] / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
-            roofs.append({"family": "gemm", "kernel": "k_zgemm<2,2>", "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF,
-                          "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF, "traffic": None,
-                          "algorithmic_flops_per_launch": prof["gemm_flops"] / max(gl, 1), "avg_launch_us": 1e3 * gms / max(gl, 1),
-                          "launches": gl, "launches_with_work": gl, "device_ms": gms, "chains_per_launch": B, "contexts_sharing_the_gpu": sharing,
-                          "note": "n_g^3 complex products on v_mfma_f64_16x16x4_f64"})
-            roofs.sort(key=lambda r: -r["device_ms"])
-            return prof, roofs
-
-        prof, roofs = rooflines(r0["prof"], R)
-        fam = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items() if isinstance(v, tuple) and k != "jacobi"}
-        _, roofs_solo = rooflines(solo["prof"], 1)
-        solo_by_family = {r["family"]: r for r in roofs_solo}
         res = {
             "metric": "DQMC sweeps/sec (SDW-O2 L=16 beta=10 fp64)",
-            "value": world * R * B * a.steps / dt,
+            "value": n_gpus * R * B * a.steps / dt,
             "unit": "sweeps/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps,
@@ -387,25 +524,29 @@ def main():
             "dtype": "f64",
             "data": "synthetic (random initial field, fixed seed)",
             "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(%d) " % WORKLOAD["delaySteps"] +
-                                   "sweepThermalization, %d independent chains per GPU (%d kernel contexts x %d lockstep chains), stabilisation=%s"
-                                   % (R * B, R, B, WORKLOAD["stabilisation"]),
-                       "n_g": n, "m": r0["m"], "replicas_per_gpu": R * B, "contexts_per_gpu": R,
-                       "chains_per_context": B},
-            # timed region, context 0 while all contexts share the GPU: durations include waiting for the others
-            "roofline": roofs[0],
-            "roofline_other_kernels": roofs[1:],
-            # the same kernels right after the timed region with ONE context alone on the GPU (clean durations;
-            # this is what the rocprofv3 summary under profiles/ shows)
-            "roofline_solo_context": solo_by_family[roofs[0]["family"]],
-            "roofline_solo_context_other_kernels": [r for r in roofs_solo if r["family"] != roofs[0]["family"]],
-            "solo_context_sweeps_per_s": B * a.steps / solo["dt"],
-            "device_ms_by_family_context0": fam,
-            "decompositions_context0": {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
-                                      "max_sweeps": prof["svd_sweeps_max"], "qr_calls": prof["qr_calls"]},
+                                   "sweepThermalization, %d independent chains per GPU (%d kernel contexts x %d lockstep chains), stabilisation=%s%s"
+                                   % (R * B, R, B, WORKLOAD["stabilisation"],
+                                      ", global shift move every %d sweeps" % WORKLOAD["globalUpdateInterval"] if WORKLOAD.get("globalShift") else ""),
+                       "n_g": n, "m": r0["m"], "replicas_per_gpu": R * B, "contexts_per_gpu": R, "chains_per_context": B,
+                       "launch": "torch.distributed.run" if world > 1 else "self"},
+            "per_gpu": per_gpu,
+            "one_context_sweeps_per_s": B * a.steps / solo["dt"],
+            "single_chain_sweeps_per_s": single,
             "acceptance": r0["acceptance"],
         }
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+        if solo.get("prof"):
+            prof, roofs, whole = rooflines(solo["prof"], n, r0["m"], B, load_traffic(B, WORKLOAD["delaySteps"]))
+            res["roofline"] = roofs[0]
+            res["roofline_other_kernels"] = roofs[1:]
+            res["roofline_whole_step"] = whole
+            res["roofline_conditions"] = ("HIP events on the context's own stream, ONE context (%d chains) alone on the GPU, %d steps right "
+                                          "after the timed region (%.1f sweeps/s with the event records)" % (B, a.steps, B * a.steps / solo["dt_profiled"]))
+            res["device_ms_by_family"] = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()
+                                          if isinstance(v, tuple) and k != "jacobi"}
+            res["decompositions"] = {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
+                                     "max_sweeps": prof["svd_sweeps_max"], "qr_calls": prof["qr_calls"]}
+        if cpu is not None:
+            res.update(cpu.finish())
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -77,6 +77,7 @@ struct dqmc_ctx {
     int currentTimeslice = 0;
     // profiling
     bool prof = false;
+    int prof_depth = 0;                 // open ProfScopes (they nest)
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, int>> ev_open;   // (family, index of begin event); end = index+1
     size_t ev_used = 0;
@@ -120,11 +121,15 @@ static int arena_commit(dqmc_ctx* c) {
 template<class T> static T* selp(dqmc_ctx* c, T* p) { return (T*)((char*)p + (size_t)c->sel * c->lc.cs); }
 template<class T> static T* chainp(dqmc_ctx* c, T* p, int b) { return (T*)((char*)p + (size_t)b * c->lc.cs); }
 
+static void prof_collect(dqmc_ctx* c);
+enum { PROF_EVENT_CAP = 8192 };     // events alive at most: beyond that the finished pairs are collected and reused
 struct ProfScope {
     dqmc_ctx* c; int fam; uint64_t launches; int idx = -1;     // idx: this scope's begin event (scopes may nest)
     ProfScope(dqmc_ctx* c_, int fam_, uint64_t launches_) : c(c_), fam(fam_), launches(launches_) {
         c->fam_launches[fam] += launches;
         if (!c->prof) return;
+        if (c->ev_used + 2 > PROF_EVENT_CAP && c->prof_depth == 0) prof_collect(c);   // not while an outer scope is open
+        ++c->prof_depth;
         if (c->ev_used + 2 > c->ev_pool.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
         }
@@ -136,6 +141,7 @@ struct ProfScope {
     ~ProfScope() {
         if (idx < 0) return;
         (void)hipEventRecord(c->ev_pool[idx + 1], c->st);
+        --c->prof_depth;
     }
 };
 
@@ -362,6 +368,7 @@ static int alloc_slot(dqmc_ctx* c, UdVSlot& sl) {
 }
 
 extern "C" int dqmc_create(const dqmc_params* p, dqmc_ctx** out) { return dqmc_create_batch(p, 1, out); }
+static int create_fill(dqmc_ctx* c, const dqmc_params* p);
 
 extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** out) {
     if (!p || !out) return fail(DQMC_EINVAL, "null argument");
@@ -393,6 +400,15 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     c->nb = nchains;
     c->N = N; c->MSF = MSF; c->n_g = ng; c->m = p->m; c->s = p->s; c->D = p->delaySteps;
     c->n = (p->m + p->s - 1) / p->s;       // ceil(m/s), detmodel.h:518
+    // every failure below leaves through ONE cleanup: the context, its stream and all device memory allocated so far
+    const int rc = create_fill(c, p);
+    if (rc != DQMC_OK) { dqmc_destroy(c); return rc; }
+    *out = c;
+    return DQMC_OK;
+}
+
+static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
+    const int N = c->N, MSF = c->MSF, ng = c->n_g;
     HIPCHK(hipStreamCreate(&c->st));
 
     DevModel& hm = c->hm;
@@ -413,7 +429,7 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     { std::vector<int> ps2, nb2; build_tables(*p, ps2, pmats_h, pabcd_h, nb2, true); }
     int *d_psites, *d_neigh; cplx *d_pmats, *d_pmats_h; double *d_pabcd, *d_pabcd_h;
     int rc;
-#define A_(x) if ((rc = (x))) { dqmc_destroy(c); return rc; }
+#define A_(x) if ((rc = (x))) return rc;
     A_(salloc(c, &d_psites, psites.size()));
     A_(salloc(c, &d_neigh, neigh.size()));
     A_(salloc(c, &d_pmats, pmats.size()));
@@ -503,9 +519,8 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     hus.slice_done = 1;
     hus.r = p->r;
     for (int b = 0; b < c->nb; ++b) HIPCHK(hipMemcpy(chainp(c, c->us, b), &hus, sizeof(hus), hipMemcpyHostToDevice));
-    { int rc2 = set_slot_identity(c, c->eye); if (rc2) { dqmc_destroy(c); return rc2; } }
+    { int rc2 = set_slot_identity(c, c->eye); if (rc2) return rc2; }
     HIPCHK(hipDeviceSynchronize());
-    *out = c;
     return DQMC_OK;
 }
 
@@ -1160,6 +1175,9 @@ extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
     c->prof = on != 0;
     for (int i = 0; i < FAM_COUNT; ++i) { c->fam_ms[i] = 0; c->fam_launches[i] = 0; }
     c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0; c->qr_calls = 0; c->gemm_flops = 0.0;
+    const unsigned long long zero[2] = {0, 0};
+    for (int b = 0; b < c->nb; ++b)
+        HIPCHK(hipMemcpy((char*)chainp(c, c->us, b) + offsetof(DevUpdateState, blocks_nonempty), zero, sizeof(zero), hipMemcpyHostToDevice));
     return DQMC_OK;
 }
 extern "C" int dqmc_profile_read(dqmc_ctx* c, dqmc_profile* out) {
@@ -1175,10 +1193,11 @@ extern "C" int dqmc_profile_read(dqmc_ctx* c, dqmc_profile* out) {
     out->gemm_flops = c->gemm_flops;
     out->decomp_round_ms = c->fam_ms[FAM_ROUNDS];
     out->decomp_rounds = c->fam_launches[FAM_ROUNDS];
-    {
-        DevUpdateState h;
-        HIPCHK(hipMemcpy(&h, selp(c, c->us), sizeof(h), hipMemcpyDeviceToHost));
-        out->blocks_nonempty = h.blocks_nonempty;
+    for (int b = 0; b < c->nb; ++b) {            // summed over the chains: independent of the selected chain
+        unsigned long long v[2];
+        HIPCHK(hipMemcpy(v, (char*)chainp(c, c->us, b) + offsetof(DevUpdateState, blocks_nonempty), sizeof(v), hipMemcpyDeviceToHost));
+        out->blocks_nonempty += v[0];
+        out->updates_accepted += v[1];
     }
     out->chains = (uint64_t)c->nb;
     return DQMC_OK;

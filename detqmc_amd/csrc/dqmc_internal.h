@@ -82,6 +82,7 @@ struct DevUpdateState {
     double r;                // this chain's exchange parameter (differs between the chains of a batch)
     int block_sites[DQMC_MAX_WDIM];
     unsigned long long blocks_nonempty;  // delayed-update blocks that accepted at least one update (-> real flushes)
+    unsigned long long updates_accepted; // accepted local updates (sum of the block ranks j); must follow blocks_nonempty
     unsigned long long dbg_cycles[16];   // developer phase timers of the decision kernel (DQMC_DBG & 8)
 };
 

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         us->site_cursor = site;
         us->acc_count = acc_count;
         us->block_j = j;
-        if (j > 0) us->blocks_nonempty += 1;
+        if (j > 0) { us->blocks_nonempty += 1; us->updates_accepted += (unsigned long long)j; }
         for (int l = 0; l < j; ++l) us->block_sites[l] = isite[l];
         us->pub.rng_consumed = cur;
         us->pub.error = err;

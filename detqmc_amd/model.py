@@ -245,7 +245,8 @@ class KernelContext:
         out.update(svd_calls=int(pr.svd_calls), svd_sweeps_total=int(pr.svd_sweeps_total),
                    svd_sweeps_max=int(pr.svd_sweeps_max), qr_calls=int(pr.qr_calls), gemm_flops=pr.gemm_flops,
                    decomp_round_ms=pr.decomp_round_ms, decomp_rounds=int(pr.decomp_rounds),
-                   blocks_nonempty=int(pr.blocks_nonempty), chains=int(pr.chains))
+                   blocks_nonempty=int(pr.blocks_nonempty), chains=int(pr.chains),
+                   updates_accepted=int(pr.updates_accepted))
         return out
 
 

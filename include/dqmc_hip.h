@@ -195,8 +195,9 @@ typedef struct dqmc_profile {
     double gemm_flops;         /* 8 M N K summed over the launches of family gemm (4 M N K for the triangular chaining product) */
     double decomp_round_ms;    /* SVD mode: time inside batches of back-to-back Jacobi rounds only */
     uint64_t decomp_rounds;
-    uint64_t blocks_nonempty;   /* delayed-update blocks of the selected chain that really flushed (since create) */
+    uint64_t blocks_nonempty;   /* delayed-update blocks that really flushed, summed over all chains, since dqmc_profile_enable */
     uint64_t chains;            /* chains every launch of this context carries */
+    uint64_t updates_accepted;  /* accepted local updates, summed over all chains, since dqmc_profile_enable (flush flops = 8 n_g^2 MSF each) */
 } dqmc_profile;
 int dqmc_profile_enable(dqmc_ctx* ctx, int on);
 int dqmc_profile_read(dqmc_ctx* ctx, dqmc_profile* out);

@@ -72,6 +72,19 @@ CASES = {
                       drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi"), subsample=4),
     "o3_L6": dict(args=dict(opdim=3, L=6, beta=3, s=10, delaySteps=12, sweeps=2, sliceTrace=0),
                   drop=("bchain_", "bdense", "bmult_leftinv", "bmult_rightinv", "init_coshTermPhi", "init_sinhTermPhi"), subsample=4),
+    # BASELINE config 4 (O(2) L = 16, beta = 20: m = 200, n = 20): 2 sweeps, a global shift move in the first; fields as
+    # SHA-256, G as checksums
+    "o2_L16_b20": dict(args=dict(opdim=2, L=16, beta=20, s=10, delaySteps=16, sweeps=2, sliceTrace=0, globalShift=1,
+                                 globalUpdateInterval=2, setupOnly=1),
+                       drop=("init_coshTermPhi", "init_sinhTermPhi", "init_udv"), subsample=32, hash_fields=True),
+    # BASELINE config 5's size (O(3) L = 24, beta = 20, n_g = 2304; no flux -- the reference rejects weakZflux for opdim 3,
+    # src/detsdwparams.cpp:57-60): the state after construction only (200 B-multiplies + 20 SVDs of 2304 x 2304 on the CPU)
+    "o3_L24_b20_init": dict(args=dict(opdim=3, L=24, beta=20, s=10, delaySteps=16, sweeps=0, sliceTrace=0, setupOnly=1),
+                            drop=("init_coshTermPhi", "init_sinhTermPhi", "init_udv_U", "init_udv_Vt", "sweep"), subsample=64,
+                            hash_fields=True, threads=4),
+    # one FULL Green's function at the headline size (closes the gap the sub-sampled checksums leave)
+    "o2_L16_b10_fullG": dict(args=dict(opdim=2, L=16, beta=10, s=10, delaySteps=16, sweeps=1, sliceTrace=0, setupOnly=1),
+                             keep=("sweep1_g", "sweep1_phi", "init_phi", "meta"), hash_fields=True),
     # BASELINE config 3 (headline): checksums / subsamples only
     "o2_L16_b10": dict(args=dict(opdim=2, L=16, beta=10, s=10, delaySteps=16, sweeps=2, sliceTrace=0),
                        drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi"),
@@ -86,13 +99,15 @@ def run_case(name, spec):
         raise SystemExit(f"{exe} missing: run `make -C oracle/ref_build OPDIM={opdim}` first")
     with tempfile.TemporaryDirectory() as td:
         cmd = [exe, td] + [f"{k}={v}" for k, v in spec["args"].items()]
-        env = dict(os.environ, MKL_NUM_THREADS="1")
+        env = dict(os.environ, MKL_NUM_THREADS=str(spec.get("threads", 1)))
         subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL)
         arrays = {}
         for line in open(os.path.join(td, "manifest.txt")):
             parts = line.split()
             nm, dt, shape = parts[0], parts[1], tuple(int(x) for x in parts[2:])
             if any(nm.startswith(d) for d in spec.get("drop", ())):
+                continue
+            if spec.get("keep") and nm not in spec["keep"]:
                 continue
             raw = np.fromfile(os.path.join(td, nm + ".bin"), dtype=np.complex128 if dt == "c16" else np.float64)
             a = raw.reshape(shape, order="F")          # harness writes column-major

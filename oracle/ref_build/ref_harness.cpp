@@ -238,7 +238,7 @@ static int run(const std::map<std::string, std::string>& kv) {
     }
 
     // --- the four B multipliers on a fixed test matrix, single slice and chains ---
-    {
+    if (!get<int>(kv, "setupOnly", 0)) {      // setupOnly=1: only the state after construction (largest sizes)
         arma::Mat<cpx_t> A = test_matrix(ng);
         uint32_t k = std::min<uint32_t>(3, m);
         dump_scalar("bmult_k", k);

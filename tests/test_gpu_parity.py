@@ -860,3 +860,146 @@ def test_o3_deepest_delay_blocks_vs_reference():
         assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}"
         _check_subsampled(rep.g, g, f"sweep{i}", 4)
     rep.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 at FULL size, and one complete Green's function at the headline size
+# ------------------------------------------------------------------------------------------------
+def _sha_phi(phi_kNd):
+    import hashlib
+    cube = np.asfortranarray(np.transpose(phi_kNd, (1, 2, 0)))          # (N, OPDIM, m+1) column-major, as the harness dumps it
+    return np.frombuffer(hashlib.sha256(cube.tobytes(order="F")).digest(), dtype=np.uint8)
+
+
+def test_headline_size_full_green_function_vs_reference():
+    """All 512 x 512 entries of G after the first sweep at L = 16, beta = 10 (the other headline fixtures keep
+    sub-sampled checksums): a localised error off the sampled lattice cannot hide."""
+    from detqmc_amd import DetSDW
+    g = load_golden("o2_L16_b10_fullG")
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr", delaySteps=32))
+    assert np.array_equal(_sha_phi(rep.phi), g["init_phi_sha256"])
+    rep.sweepThermalization()
+    assert np.array_equal(_sha_phi(rep.phi), g["sweep1_phi_sha256"]), "field differs from the reference after sweep 1"
+    G = rep.g
+    assert G.shape == g["sweep1_g"].shape == (512, 512)
+    assert relerr(G, g["sweep1_g"]) < TOL
+    # entry-wise, not only in the max norm: every 16 x 16 block to 1e-9 of the block's own scale
+    D = np.abs(G - g["sweep1_g"]).reshape(32, 16, 32, 16).max(axis=(1, 3))
+    S = np.abs(g["sweep1_g"]).reshape(32, 16, 32, 16).max(axis=(1, 3))
+    assert np.all(D <= 1e-9 * np.maximum(S, 1e-6))
+    rep.close()
+
+
+def test_config4_L16_beta20_eight_replicas_with_exchange_vs_reference():
+    """BASELINE config 4 on one GPU: O(2) L = 16, beta = 20 (m = 200, n = 20), 8 replicas on an r ladder swept in
+    lockstep by one context, global shift moves, replica exchange (detqmc_amd/pt.py, src/detqmcpt.h:963-1118).
+    Sweeps 1-2: chain 0 (the fixture's parameters) must reproduce the reference's field (SHA-256), Green's function
+    checksums, step size and global-move counters after every sweep.  Then exchange steps after every sweep: all 8
+    chains must stay on the trajectories of 8 single-replica twins driven through the same exchange protocol."""
+    import dataclasses
+    from detqmc_amd import DetSDW, DetSDWBatch
+    from detqmc_amd.pt import ExchangeState, ReplicaAdapter, replica_exchange_step, replica_exchange_consistency_check
+    g = load_golden("o2_L16_b20")
+    p0 = _sdw_params(g["params"], stabilisation="qr", delaySteps=32)
+    assert p0.beta == 20 and p0.globalShift
+    rvals = [p0.r + 0.004 * i for i in range(8)]
+    plist = [dataclasses.replace(p0, r=rvals[i], simindex=i) for i in range(8)]
+    batch = DetSDWBatch(plist)
+    twins = [DetSDW(p) for p in plist]
+    c0 = batch.chain(0)
+    assert c0.info.m == 200 and c0.info.n == 20 and c0.info.n_g == 512
+    assert np.array_equal(_sha_phi(c0.phi), g["init_phi_sha256"])
+    G = c0.g
+    assert relerr(G[::32, ::32], g["init_g_sub32"]) < TOL and relerr(np.diag(G), g["init_g_diag"]) < TOL
+    assert abs(np.sum(np.log(c0.g_inv_sv)) - np.sum(np.log(g["init_g_inv_sv"]))) < 1e-9 * 512
+
+    def step():
+        batch.sweepThermalization()
+        for t in twins:
+            t.sweepThermalization()
+
+    def compare_twins(tag):
+        for b, t in enumerate(twins):
+            cb = batch.chain(b)
+            assert np.array_equal(cb.phi, t.phi), (tag, b)
+            assert relerr(cb.g, t.g) < 1e-9, (tag, b)
+            assert cb.info.phiDelta == t.info.phiDelta and cb.info.acceptedGlobalShifts == t.info.acceptedGlobalShifts, (tag, b)
+
+    for i in (1, 2):
+        step()
+        assert np.array_equal(_sha_phi(c0.phi), g[f"sweep{i}_phi_sha256"]), f"sweep {i}: field differs from the reference"
+        G = c0.g
+        assert relerr(G[::32, ::32], g[f"sweep{i}_g_sub32"]) < TOL
+        assert relerr(np.diag(G), g[f"sweep{i}_g_diag"]) < TOL
+        assert abs(np.linalg.norm(G) - g[f"sweep{i}_g_fro"][0]) < TOL * g[f"sweep{i}_g_fro"][0]
+        inf = c0.info
+        assert inf.phiDelta == g[f"sweep{i}_phiDelta"][0]
+        assert inf.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert inf.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+    compare_twins("before exchange")
+    breps = [ReplicaAdapter(batch.chain(b)) for b in range(8)]
+    treps = [ReplicaAdapter(t) for t in twins]
+    stb = ExchangeState.create(rvals, 0, 1, n_local=8)
+    stt = ExchangeState.create(rvals, 0, 1, n_local=8)
+    for it in range(2):
+        ib = replica_exchange_step(breps, stb, None)
+        itw = replica_exchange_step(treps, stt, None)
+        replica_exchange_consistency_check(breps, stb, None)
+        assert ib == itw and sorted(ib) == list(range(8))
+        for b in range(8):
+            assert batch.chain(b).get_exchange_parameter_value() == rvals[ib[b]]
+        step()
+        compare_twins(f"after exchange {it}")
+    assert stb.par_swapUpProposed == [2] * 7 + [0]
+    for t in twins:
+        t.close()
+    batch.close()
+
+
+def test_config5_O3_L24_beta20_full_size():
+    """BASELINE config 5's size (O(3) L = 24, beta = 20: n_g = 2304, m = 200, n = 20; without the flux, which the
+    reference rejects for opdim = 3, src/detsdwparams.cpp:57-60).  G(beta) and log det against the reference's
+    construction (20 SVDs of 2304 x 2304 on the CPU), then a thermalisation sweep with size-independent
+    properties: B^-1 B = 1, wrapped vs re-stabilised G, cosh/sinh caches, unitarity of the chain factor."""
+    from detqmc_amd import DetSDW
+    g = load_golden("o3_L24_b20_init")
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr"))
+    inf = rep.info
+    assert (inf.n_g, inf.m, inf.n) == (2304, 200, 20)
+    assert np.array_equal(_sha_phi(rep.phi), g["init_phi_sha256"])
+    G = rep.g
+    assert relerr(G[::64, ::64], g["init_g_sub64"]) < TOL
+    assert relerr(np.diag(G), g["init_g_diag"]) < TOL
+    assert abs(np.linalg.norm(G) - g["init_g_fro"][0]) < TOL * g["init_g_fro"][0]
+    assert abs(np.sum(np.log(rep.g_inv_sv)) - np.sum(np.log(g["init_g_inv_sv"]))) < 1e-9 * 2304
+    ctx = rep.kernel_context
+    # wrapped vs re-stabilised Green's function (the reference's greenConsistencyCheck, src/detmodel.h:960-1010):
+    # wrap G(beta) down through the top interval without updates, then let advanceDownGreen rebuild it from the UdV chain
+    m, s, n = inf.m, inf.s, inf.n
+    for k in range(m, (n - 1) * s, -1):
+        ctx.wrapDownGreen(k)
+    Gw = ctx.g
+    assert ctx.currentTimeslice == (n - 1) * s
+    ctx.advanceDownGreen(n)
+    Ga = ctx.g
+    assert relerr(Gw, Ga) < 1e-7, "wrapped and re-stabilised G differ"
+    # back to a consistent state, then one full thermalisation sweep
+    ctx.setupUdVStorage_and_calculateGreen()
+    assert relerr(ctx.g, G) < 1e-12
+    rep.sweepThermalization()
+    phi, ch, sh = ctx.get_fields()
+    nrm = np.sqrt(np.sum(phi[1:] ** 2, axis=2))
+    assert relerr(ch[1:], np.cosh(0.1 * nrm)) < 1e-14 and relerr(sh[1:], np.sinh(0.1 * nrm) / nrm) < 1e-13
+    acc = rep.info.lastAccRatioLocal_phi
+    assert 0.05 < acc < 0.99
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((2304, 64)) + 1j * rng.standard_normal((2304, 64))
+    A = np.hstack([A] * 36)
+    assert relerr(ctx.leftMultiplyBmatInv(ctx.leftMultiplyBmat(A, 20, 10), 20, 10), A) < 1e-10
+    assert relerr(ctx.rightMultiplyBmat(ctx.rightMultiplyBmatInv(A, 200, 190), 200, 190), A) < 1e-10
+    # after the down sweep storage[l] holds the L-type factors B(beta, l s): V_t = Q is unitary
+    U, d, Vt = ctx.udv(3)
+    assert np.all(d > 0)
+    E = Vt.conj().T @ Vt - np.eye(2304)
+    assert np.max(np.abs(E)) < 1e-11
+    rep.close()
