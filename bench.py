@@ -4,8 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 Starts by itself for any N: the parent never touches a GPU, it spawns `--workers` worker processes per GPU
-(`--device i`), each holding one kernel context with `--batch` independent Markov chains that advance in lockstep
-(every launch carries all chains of the context).  Under torch.distributed.run (WORLD_SIZE > 1, one rank per GPU) every
+(`--device i`, default ONE), each holding `--batch` independent Markov chains spread over `--sub-batches` kernel contexts
+that the host layer sweeps concurrently (one host thread + HIP stream per context; every launch of a context carries all
+of its chains).  Under torch.distributed.run (WORLD_SIZE > 1, one rank per GPU) every
 rank drives the workers of ITS GPU and the ranks meet at a barrier on both sides of the timed region; the result is the
 same line.  A "step" is one sweepThermalization() of every chain.  value = all sweeps of all chains of all GPUs / the
 slowest participant's time.  Workload: SDW O(2), L=16, beta=10, dtau=0.1 (m=100), s=10, checkerboard, delayed updates,
@@ -15,7 +16,8 @@ so scaling is weak.
 
 The ONE JSON line carries, besides the contract's keys:
   per_gpu                    sweeps/s of every GPU
-  one_context_sweeps_per_s   ONE process / ONE context alone on the GPU (what a DetQMCPT port owning one process per GPU gets)
+  one_process_sweeps_per_s   what ONE detsdw_create_batch handle in ONE process delivers (a DetQMCPT port owning one process per GPU)
+  one_context_sweeps_per_s   ONE kernel context (one stream) alone on the GPU
   single_chain_sweeps_per_s  one context x one chain (latency of a single Markov chain)
   roofline                   the kernel family with the largest device time, measured with HIP events on the kernel's own
                              stream while ONE context has the GPU to itself (reproducible with rocprofv3, profiles/),
@@ -46,8 +48,10 @@ if os.environ.get("DQMC_BENCH_GLOBAL_SHIFT"):
     WORKLOAD.update(globalShift=True, globalUpdateInterval=int(os.environ["DQMC_BENCH_GLOBAL_SHIFT"]))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
-DEFAULT_BATCH = 128            # chains per kernel context (lockstep batch)
-DEFAULT_WORKERS = 4            # contexts per GPU: the latency-bound kernels of one overlap the streaming kernels of the others
+DEFAULT_BATCH = 512            # chains per worker process (detsdw_create_batch), spread over DEFAULT_SUB kernel contexts
+DEFAULT_SUB = 4                # kernel contexts (sub-batches, one host thread + HIP stream each) per process: the latency-bound
+                               # kernels of one context overlap the streaming / MFMA kernels of the others
+DEFAULT_WORKERS = 1            # worker processes per GPU
 FAKE = bool(os.environ.get("DQMC_BENCH_FAKE_WORKER"))     # CPU rehearsal of the control flow (tests/test_bench_cpu.py)
 
 
@@ -106,6 +110,19 @@ def cpu_baseline_port():
             "sample": "oracle/detsdw_oracle.py (numpy + scipy zgesvd), extrapolated to a full sweep from " + sample}
 
 
+def host_cores():
+    """cores this job may use: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256 logical CPUs and
+    grants 16 cores' worth of time)"""
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            ncpu = min(ncpu, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return ncpu
+
+
 class CpuBaseline:
     """1 core: ONE reference process, 1 warm-up + `sweeps` timed sweepThermalization(); may run while the GPU post-phases
     (one busy host thread) are in progress -- the box has 16+ cores.  All cores: one reference process per core at the same
@@ -133,7 +150,7 @@ class CpuBaseline:
             return out
         out["cpu_baseline"] = {"value": n / sec, "unit": "sweeps/s", "cores": 1, "kind": "reference",
                                "sample": REF_DESC + ": %d sweepThermalization() after init + 1 warm-up sweep, %.1f s" % (n, sec)}
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncpu = host_cores()
         try:
             ps = [_ref_start(1, self.sweeps, "all%d" % i) for i in range(ncpu)]
             res = [_ref_finish(p, 900) for p in ps]
@@ -171,7 +188,7 @@ def worker(a, readline=None, emit=None):
     else:
         from detqmc_amd import DetSDWBatch, SDWParams
         p0 = SDWParams(device=a.device, **WORKLOAD)
-        batch = DetSDWBatch([dataclasses.replace(p0, simindex=a.simindex * B + i) for i in range(B)])
+        batch = DetSDWBatch([dataclasses.replace(p0, simindex=a.simindex * B + i) for i in range(B)], sub_batches=a.sub_batches)
         ctx = batch.kernel_context
     for _ in range(a.warmup):
         batch.sweepThermalization()
@@ -193,10 +210,10 @@ def worker(a, readline=None, emit=None):
         out = {"dt": dt, "n_g": info.n_g, "m": info.m,
                "acceptance": [batch.chain(i).info.lastAccRatioLocal_phi for i in range(min(B, 4))]}
     emit("RESULT " + json.dumps(out))
-    # then, if asked: the same steps ALONE on the GPU with per-kernel HIP-event timing (kernel durations free of other contexts)
+    # then, if asked: the same steps again with per-kernel HIP-event timing (the profile worker: ONE context alone on the GPU)
     if readline().strip() == "SOLO":
         if FAKE:
-            emit("SOLO " + json.dumps({"dt": dt, "prof": None}))
+            emit("SOLO " + json.dumps({"dt_profiled": dt, "prof": None}))
             return
         ctx.profile_enable(True)
         t0 = time.perf_counter()
@@ -206,13 +223,7 @@ def worker(a, readline=None, emit=None):
         dts = time.perf_counter() - t0
         prof = ctx.profile_read()
         ctx.profile_enable(False)
-        # and once more without the event records: the rate of ONE context
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            batch.sweepThermalization()
-        ctx.synchronize()
-        emit("SOLO " + json.dumps({"dt": time.perf_counter() - t0, "dt_profiled": dts,
-                                   "prof": {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}}))
+        emit("SOLO " + json.dumps({"dt_profiled": dts, "prof": {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}}))
     if not FAKE:
         batch.close()
 
@@ -389,8 +400,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("DQMC_WORKERS_PER_GPU", str(DEFAULT_WORKERS))),
                     help="worker processes (kernel contexts) per GPU")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DQMC_CHAINS_PER_CONTEXT", str(DEFAULT_BATCH))),
-                    help="independent Markov chains per context, advanced in lockstep")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DQMC_CHAINS_PER_WORKER", str(DEFAULT_BATCH))),
+                    help="independent Markov chains per worker process")
+    ap.add_argument("--sub-batches", type=int, default=int(os.environ.get("DQMC_SUB_BATCHES", str(DEFAULT_SUB))),
+                    help="kernel contexts per worker process the chains are spread over (swept concurrently, one host thread each)")
     ap.add_argument("--inprocess", action="store_true",
                     help="ONE context in this process instead of worker processes (for rocprofv3)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
@@ -435,9 +448,13 @@ def main():
               "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
 
-    def spawn(device, simindex, batch, steps, warmup):
+    S = max(1, a.sub_batches)
+    while B % S != 0:          # the contexts of a process hold the same number of chains
+        S -= 1
+
+    def spawn(device, simindex, batch, steps, warmup, sub=None):
         cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--device", str(0 if one_device else device), "--simindex",
-               str(simindex), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch)]
+               str(simindex), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch), "--sub-batches", str(sub or S)]
         return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
 
     procs = []          # (gpu index, process)
@@ -477,27 +494,39 @@ def main():
         per_gpu[g] = max(per_gpu.get(g, 0.0), r["dt"])
     per_gpu = [R * B * a.steps / per_gpu[g] for g in sorted(per_gpu)]
 
-    # post-phase (rank 0, first GPU): context 0 alone on the GPU, profiled and unprofiled; everybody else leaves
+    # post-phases (rank 0, first GPU), after every timed worker has left the GPU:
+    #   ONE kernel context (B / S chains, one stream) alone: its rate, then the same steps with per-kernel HIP-event timing;
+    #   ONE context with ONE chain: the latency of a single Markov chain
     lead = rank == 0
-    solo = None
+    inproc_solo = None
     for i, (_, p) in enumerate(procs):
-        send(p, "SOLO" if (lead and i == 0) else "QUIT")
-    for i, (_, p) in enumerate(procs):
-        if not (lead and i == 0):
-            p.wait()
+        send(p, "SOLO" if (a.inprocess and lead and i == 0) else "QUIT")
+    if a.inprocess and lead:
+        inproc_solo = json.loads(read_tag(procs[0][1], "SOLO"))
+    for _, p in procs:
+        p.wait()
     cpu = CpuBaseline() if (lead and n_gpus == 1 and not a.no_cpu_baseline) else None     # 1-core run overlaps the post-phases
-    single = None
-    if lead:
-        solo = json.loads(read_tag(procs[0][1], "SOLO"))
-        procs[0][1].wait()
-        if not a.inprocess:
-            sp = spawn(my_gpus[0], 9999, 1, max(2, min(a.steps, 4)), 1)        # one context x ONE chain
-            read_tag(sp, "READY")
-            send(sp, "GO")
-            sr = json.loads(read_tag(sp, "RESULT"))
-            send(sp, "QUIT")
-            sp.wait()
-            single = max(2, min(a.steps, 4)) / sr["dt"]
+    single = one_ctx = solo = None
+    Bc = B // S                                                                          # chains of one kernel context
+    if lead and not a.inprocess:
+        pw = spawn(my_gpus[0], 7777, Bc, a.steps, a.warmup, sub=1)
+        read_tag(pw, "READY")
+        send(pw, "GO")
+        one_ctx = Bc * a.steps / json.loads(read_tag(pw, "RESULT"))["dt"]
+        send(pw, "SOLO")
+        solo = json.loads(read_tag(pw, "SOLO"))
+        pw.wait()
+        nst = max(2, min(a.steps, 4))
+        sp = spawn(my_gpus[0], 9999, 1, nst, 1, sub=1)                                   # one context x ONE chain
+        read_tag(sp, "READY")
+        send(sp, "GO")
+        sr = json.loads(read_tag(sp, "RESULT"))
+        send(sp, "QUIT")
+        sp.wait()
+        single = nst / sr["dt"]
+    elif lead:
+        solo, one_ctx = inproc_solo, B * a.steps / results[0]["dt"]
+        Bc = B
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -524,23 +553,27 @@ def main():
             "dtype": "f64",
             "data": "synthetic (random initial field, fixed seed)",
             "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(%d) " % WORKLOAD["delaySteps"] +
-                                   "sweepThermalization, %d independent chains per GPU (%d kernel contexts x %d lockstep chains), stabilisation=%s%s"
-                                   % (R * B, R, B, WORKLOAD["stabilisation"],
+                                   "sweepThermalization, %d independent chains per GPU (%d process x %d kernel contexts x %d lockstep chains), stabilisation=%s%s"
+                                   % (R * B, R, S, B // S, WORKLOAD["stabilisation"],
                                       ", global shift move every %d sweeps" % WORKLOAD["globalUpdateInterval"] if WORKLOAD.get("globalShift") else ""),
-                       "n_g": n, "m": r0["m"], "replicas_per_gpu": R * B, "contexts_per_gpu": R, "chains_per_context": B,
+                       "n_g": n, "m": r0["m"], "replicas_per_gpu": R * B, "processes_per_gpu": R, "contexts_per_process": S,
+                       "chains_per_context": B // S,
                        "launch": "torch.distributed.run" if world > 1 else "self"},
             "per_gpu": per_gpu,
-            "one_context_sweeps_per_s": B * a.steps / solo["dt"],
+            # what ONE detsdw_create_batch handle (one process) delivers: the headline itself when processes_per_gpu is 1
+            "one_process_sweeps_per_s": per_gpu[0] / R,
+            # ONE kernel context (dqmc_create_batch: one stream, one launch sequence) of chains_per_context chains alone on the GPU
+            "one_context_sweeps_per_s": one_ctx,
             "single_chain_sweeps_per_s": single,
             "acceptance": r0["acceptance"],
         }
-        if solo.get("prof"):
-            prof, roofs, whole = rooflines(solo["prof"], n, r0["m"], B, load_traffic(B, WORKLOAD["delaySteps"]))
+        if solo and solo.get("prof"):
+            prof, roofs, whole = rooflines(solo["prof"], n, r0["m"], Bc, load_traffic(Bc, WORKLOAD["delaySteps"]))
             res["roofline"] = roofs[0]
             res["roofline_other_kernels"] = roofs[1:]
             res["roofline_whole_step"] = whole
             res["roofline_conditions"] = ("HIP events on the context's own stream, ONE context (%d chains) alone on the GPU, %d steps right "
-                                          "after the timed region (%.1f sweeps/s with the event records)" % (B, a.steps, B * a.steps / solo["dt_profiled"]))
+                                          "after the timed region (%.1f sweeps/s with the event records)" % (Bc, a.steps, Bc * a.steps / solo["dt_profiled"]))
             res["device_ms_by_family"] = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()
                                           if isinstance(v, tuple) and k != "jacobi"}
             res["decompositions"] = {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],

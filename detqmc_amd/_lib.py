@@ -108,6 +108,8 @@ SYMBOLS = [
     ("dqmc_stream", _P, [_P]),
     ("dqmc_set_fields_host", C.c_int, [_P, _DP]),
     ("dqmc_get_fields_host", C.c_int, [_P, _DP, _DP, _DP]),
+    ("dqmc_set_fields_all_host", C.c_int, [_P, _DP]),
+    ("dqmc_get_fields_all_host", C.c_int, [_P, _DP]),
     ("dqmc_bmult_host", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("dqmc_udv_decompose_host", C.c_int, [_P, _P, _P, _DP, _P, C.POINTER(C.c_int)]),
     ("dqmc_gemm_host", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
@@ -116,12 +118,15 @@ SYMBOLS = [
     ("dqmc_wrap", C.c_int, [_P, C.c_int, C.c_int]),
     ("dqmc_reset_storage0", C.c_int, [_P]),
     ("dqmc_push_uniforms_host", C.c_int, [_P, _DP, C.c_size_t]),
+    ("dqmc_push_uniforms_all_host", C.c_int, [_P, _DP, C.c_size_t]),
     ("dqmc_update_slice", C.c_int, [_P, C.c_int, C.c_int]),
+    ("dqmc_get_update_states_all_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),
     ("dqmc_get_update_state_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),
     ("dqmc_set_update_state_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),
     ("dqmc_get_green_host", C.c_int, [_P, _P]),
     ("dqmc_set_green_host", C.c_int, [_P, _P, C.c_int]),
     ("dqmc_get_sv_host", C.c_int, [_P, _DP]),
+    ("dqmc_get_sv_all_host", C.c_int, [_P, _DP]),
     ("dqmc_get_udv_host", C.c_int, [_P, C.c_int, _P, _DP, _P]),
     ("dqmc_current_timeslice", C.c_int, [_P]),
     ("dqmc_backup", C.c_int, [_P]),
@@ -137,6 +142,9 @@ SYMBOLS = [
     ("dqmc_profile_read", C.c_int, [_P, C.POINTER(dqmc_profile)]),
     ("detsdw_create", C.c_int, [C.POINTER(detsdw_params), C.POINTER(_P)]),
     ("detsdw_create_batch", C.c_int, [C.POINTER(detsdw_params), C.c_int, C.POINTER(_P)]),
+    ("detsdw_create_batch_ex", C.c_int, [C.POINTER(detsdw_params), C.c_int, C.c_int, C.POINTER(_P)]),
+    ("detsdw_num_sub_batches", C.c_int, [_P]),
+    ("detsdw_ctx_of_chain", _P, [_P, C.c_int, C.POINTER(C.c_int)]),
     ("detsdw_select_chain", C.c_int, [_P, C.c_int]),
     ("detsdw_num_chains", C.c_int, [_P]),
     ("detsdw_destroy", None, [_P]),

@@ -110,7 +110,8 @@ static int arena_commit(dqmc_ctx* c) {
     void* q = nullptr;
     HIPCHK(hipMalloc(&q, cs * (size_t)c->nb));
     c->allocs.push_back(q);
-    HIPCHK(hipMemset(q, 0, cs * (size_t)c->nb));
+    HIPCHK(hipMemsetAsync(q, 0, cs * (size_t)c->nb, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
     c->arena = (char*)q;
     for (void** pp : c->fixups) *pp = c->arena + ((uintptr_t)*pp - 256);
     c->fixups.clear();
@@ -120,6 +121,13 @@ static int arena_commit(dqmc_ctx* c) {
 // the selected chain's copy of a per-chain buffer (host-buffer entry points)
 template<class T> static T* selp(dqmc_ctx* c, T* p) { return (T*)((char*)p + (size_t)c->sel * c->lc.cs); }
 template<class T> static T* chainp(dqmc_ctx* c, T* p, int b) { return (T*)((char*)p + (size_t)b * c->lc.cs); }
+// Blocking copy on the context's OWN (non-blocking) stream.  Nothing in this library touches the legacy null stream: a
+// null-stream copy would wait for -- and hold up -- every blocking stream of the process, i.e. serialise contexts that
+// different host threads drive concurrently (one context per sub-batch of replicas, host/detsdw.cpp).
+static hipError_t copy_sync(dqmc_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->st);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->st);
+}
 
 static void prof_collect(dqmc_ctx* c);
 enum { PROF_EVENT_CAP = 8192 };     // events alive at most: beyond that the finished pairs are collected and reused
@@ -409,7 +417,7 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
 
 static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     const int N = c->N, MSF = c->MSF, ng = c->n_g;
-    HIPCHK(hipStreamCreate(&c->st));
+    HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
 
     DevModel& hm = c->hm;
     memset(&hm, 0, sizeof(hm));
@@ -434,14 +442,14 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     A_(salloc(c, &d_neigh, neigh.size()));
     A_(salloc(c, &d_pmats, pmats.size()));
     A_(salloc(c, &d_pabcd, pabcd.size()));
-    HIPCHK(hipMemcpy(d_pabcd, pabcd.data(), pabcd.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_psites, psites.data(), psites.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_neigh, neigh.data(), neigh.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_pmats, pmats.data(), pmats.size() * sizeof(hc), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, d_pabcd, pabcd.data(), pabcd.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, d_psites, psites.data(), psites.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, d_neigh, neigh.data(), neigh.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, d_pmats, pmats.data(), pmats.size() * sizeof(hc), hipMemcpyHostToDevice));
     A_(salloc(c, &d_pmats_h, pmats_h.size()));
     A_(salloc(c, &d_pabcd_h, pabcd_h.size()));
-    HIPCHK(hipMemcpy(d_pmats_h, pmats_h.data(), pmats_h.size() * sizeof(hc), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_pabcd_h, pabcd_h.data(), pabcd_h.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, d_pmats_h, pmats_h.data(), pmats_h.size() * sizeof(hc), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, d_pabcd_h, pabcd_h.data(), pabcd_h.size() * sizeof(double), hipMemcpyHostToDevice));
     hm.psites = d_psites; hm.neigh = d_neigh; hm.pmats = d_pmats; hm.pabcd = d_pabcd; hm.pm_real = p->weakZflux ? 0 : 1;
     hm.pmats_h = d_pmats_h; hm.pabcd_h = d_pabcd_h;
     if (p->cb_none) {
@@ -451,12 +459,12 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
         build_dense_propK(*p, neigh, MSF, em, ep);
         const size_t nn = (size_t)ng * ng;
         A_(salloc(c, &c->propK[0], nn)); A_(salloc(c, &c->propK[1], nn)); A_(dalloc(c, &c->Tdense, nn));
-        HIPCHK(hipMemcpy(c->propK[0], em.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->propK[1], ep.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(c, c->propK[0], em.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(c, c->propK[1], ep.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
         build_dense_propK(*p, neigh, MSF, em, ep, 0.5);           // propK_half, propK_half_inv (detsdwopdim.cpp:1282-1283)
         A_(salloc(c, &c->propKh[0], nn)); A_(salloc(c, &c->propKh[1], nn));
-        HIPCHK(hipMemcpy(c->propKh[0], em.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->propKh[1], ep.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(c, c->propKh[0], em.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(c, c->propKh[1], ep.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
     }
 
     const size_t nphi = (size_t)(p->m + 1) * p->opdim * N, ncs = (size_t)(p->m + 1) * N;
@@ -477,7 +485,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     c->sw.hflag[0] = 0; c->sw.hflag[1] = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&c->sw.hslot_dev, c->sw.hflag, 0));
     A_(salloc(c, &c->sw.seqctr, 1));
-    HIPCHK(hipMemset(c->sw.seqctr, 0, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(c->sw.seqctr, 0, sizeof(unsigned long long), c->st));
     c->sw.host_seq = &c->jacobi_host_seq;
     c->sw.last_residual = &c->last_svd_residual;
     c->sw.sweep_graph = &c->jacobi_graph;
@@ -488,7 +496,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
         build_tournament(nblk, rounds);
         int* d_rounds;
         A_(salloc(c, &d_rounds, rounds.size()));
-        HIPCHK(hipMemcpy(d_rounds, rounds.data(), rounds.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(c, d_rounds, rounds.data(), rounds.size() * sizeof(int), hipMemcpyHostToDevice));
         c->sw.rounds = d_rounds; c->sw.nrounds = nblk - 1; c->sw.nblk = nblk;
     }
     c->stab = p->stabilisation;
@@ -518,9 +526,9 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     hus.pub.targetAccRatio = p->accRatio;
     hus.slice_done = 1;
     hus.r = p->r;
-    for (int b = 0; b < c->nb; ++b) HIPCHK(hipMemcpy(chainp(c, c->us, b), &hus, sizeof(hus), hipMemcpyHostToDevice));
+    for (int b = 0; b < c->nb; ++b) HIPCHK(copy_sync(c, chainp(c, c->us, b), &hus, sizeof(hus), hipMemcpyHostToDevice));
     { int rc2 = set_slot_identity(c, c->eye); if (rc2) return rc2; }
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(c->st));
     return DQMC_OK;
 }
 
@@ -568,9 +576,28 @@ extern "C" int dqmc_get_fields_host(dqmc_ctx* c, double* phi, double* coshT, dou
     (void)hipSetDevice(c->p.device);
     const size_t nphi = (size_t)(c->m + 1) * c->p.opdim * c->N, ncs = (size_t)(c->m + 1) * c->N;
     HIPCHK(hipStreamSynchronize(c->st));
-    if (phi) HIPCHK(hipMemcpy(phi, selp(c, c->phi), nphi * sizeof(double), hipMemcpyDeviceToHost));
-    if (coshT) HIPCHK(hipMemcpy(coshT, selp(c, c->coshT), ncs * sizeof(double), hipMemcpyDeviceToHost));
-    if (sinhT) HIPCHK(hipMemcpy(sinhT, selp(c, c->sinhT), ncs * sizeof(double), hipMemcpyDeviceToHost));
+    if (phi) HIPCHK(copy_sync(c, phi, selp(c, c->phi), nphi * sizeof(double), hipMemcpyDeviceToHost));
+    if (coshT) HIPCHK(copy_sync(c, coshT, selp(c, c->coshT), ncs * sizeof(double), hipMemcpyDeviceToHost));
+    if (sinhT) HIPCHK(copy_sync(c, sinhT, selp(c, c->sinhT), ncs * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+
+// all chains in one strided transfer each way: phi_all = nchains cubes of (m+1) * opdim * N doubles, back to back
+extern "C" int dqmc_set_fields_all_host(dqmc_ctx* c, const double* phi_all) {
+    if (!c || !phi_all) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    const size_t bytes = (size_t)(c->m + 1) * c->p.opdim * c->N * sizeof(double);
+    HIPCHK(hipMemcpy2DAsync(c->phi, c->lc.cs, phi_all, bytes, bytes, (size_t)c->nb, hipMemcpyHostToDevice, c->st));
+    { ProfScope ps(c, FAM_OTHER, 1); launch_cosh_sinh(c->lc, c->hm); }
+    HIPCHK(hipStreamSynchronize(c->st));
+    return DQMC_OK;
+}
+extern "C" int dqmc_get_fields_all_host(dqmc_ctx* c, double* phi_all) {
+    if (!c || !phi_all) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    const size_t bytes = (size_t)(c->m + 1) * c->p.opdim * c->N * sizeof(double);
+    HIPCHK(hipMemcpy2DAsync(phi_all, bytes, c->phi, c->lc.cs, bytes, (size_t)c->nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
     return DQMC_OK;
 }
 
@@ -910,10 +937,35 @@ extern "C" int dqmc_push_uniforms_host(dqmc_ctx* c, const double* u, size_t nval
     if (nvals > c->uni_cap)
         return fail(DQMC_EINVAL, "more uniforms than one sweep can consume ((opdim+1)*N*m + 64)");
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(selp(c, c->uniforms), u, nvals * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, selp(c, c->uniforms), u, nvals * sizeof(double), hipMemcpyHostToDevice));
     uint64_t vals[2] = {0, (uint64_t)nvals};
-    HIPCHK(hipMemcpy((char*)selp(c, c->us) + offsetof(DevUpdateState, pub) + offsetof(dqmc_update_state, rng_consumed), vals,
+    HIPCHK(copy_sync(c, (char*)selp(c, c->us) + offsetof(DevUpdateState, pub) + offsetof(dqmc_update_state, rng_consumed), vals,
                      sizeof(vals), hipMemcpyHostToDevice));
+    return DQMC_OK;
+}
+
+// all chains at once: u holds nchains windows of nvals uniforms each, back to back; ONE strided copy into the arena
+extern "C" int dqmc_push_uniforms_all_host(dqmc_ctx* c, const double* u, size_t nvals) {
+    if (!c || (!u && nvals)) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    if (nvals > c->uni_cap)
+        return fail(DQMC_EINVAL, "more uniforms than one sweep can consume ((opdim+1)*N*m + 64)");
+    HIPCHK(hipMemcpy2DAsync(c->uniforms, c->lc.cs, u, nvals * sizeof(double), nvals * sizeof(double), (size_t)c->nb, hipMemcpyHostToDevice, c->st));
+    std::vector<uint64_t> vals((size_t)2 * c->nb);
+    for (int b = 0; b < c->nb; ++b) { vals[2 * b] = 0; vals[2 * b + 1] = (uint64_t)nvals; }
+    HIPCHK(hipMemcpy2DAsync((char*)c->us + offsetof(DevUpdateState, pub) + offsetof(dqmc_update_state, rng_consumed), c->lc.cs, vals.data(),
+                            2 * sizeof(uint64_t), 2 * sizeof(uint64_t), (size_t)c->nb, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return DQMC_OK;
+}
+// out[nchains]: the update state of every chain, one strided copy
+extern "C" int dqmc_get_update_states_all_host(dqmc_ctx* c, dqmc_update_state* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(dqmc_update_state), &c->us->pub, c->lc.cs, sizeof(dqmc_update_state), (size_t)c->nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    for (int b = 0; b < c->nb; ++b)
+        if (out[b].error) return fail(out[b].error, "device ran out of pre-drawn uniforms");
     return DQMC_OK;
 }
 
@@ -946,12 +998,12 @@ extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
     HIPCHK(hipStreamSynchronize(c->st));
     if (c->hm.dbg & 8) {     // developer phase timers of the decision kernel
         DevUpdateState h;
-        HIPCHK(hipMemcpy(&h, selp(c, c->us), sizeof(h), hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(c, &h, selp(c, c->us), sizeof(h), hipMemcpyDeviceToHost));
         fprintf(stderr, "[decide cycles, chain %d, %llu launches]", c->sel, h.dbg_cycles[12]);
         for (int i = 0; i < 10; ++i) fprintf(stderr, " t%d=%llu", i, h.dbg_cycles[i]);
         fprintf(stderr, "\n");
     }
-    HIPCHK(hipMemcpy(out, &selp(c, c->us)->pub, sizeof(*out), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(c, out, &selp(c, c->us)->pub, sizeof(*out), hipMemcpyDeviceToHost));
     if (out->error) return fail(out->error, "device ran out of pre-drawn uniforms");
     return DQMC_OK;
 }
@@ -959,7 +1011,7 @@ extern "C" int dqmc_set_update_state_host(dqmc_ctx* c, const dqmc_update_state* 
     if (!c || !in) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(&selp(c, c->us)->pub, in, sizeof(*in), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, &selp(c, c->us)->pub, in, sizeof(*in), hipMemcpyHostToDevice));
     return DQMC_OK;
 }
 
@@ -990,9 +1042,9 @@ extern "C" int dqmc_udv_decompose_host(dqmc_ctx* c, const dqmc_cplx* M, dqmc_cpl
     int rc = decompose(c, c->T1, nullptr, nullptr, KIND_R, c->tmpudv);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(U, selp(c, c->tmpudv.U), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(d, selp(c, c->tmpudv.d), c->n_g * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(V_t, selp(c, c->tmpudv.Vt), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(c, U, selp(c, c->tmpudv.U), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(c, d, selp(c, c->tmpudv.d), c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(c, V_t, selp(c, c->tmpudv.Vt), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
     if (sweeps_used) *sweeps_used = c->last_svd_sweeps;
     return DQMC_OK;
 }
@@ -1016,14 +1068,14 @@ extern "C" int dqmc_get_green_host(dqmc_ctx* c, dqmc_cplx* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(out, selp(c, c->G), (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(c, out, selp(c, c->G), (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 extern "C" int dqmc_set_green_host(dqmc_ctx* c, const dqmc_cplx* in, int currentTimeslice) {
     if (!c || !in) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(selp(c, c->G), in, (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, selp(c, c->G), in, (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyHostToDevice));
     c->currentTimeslice = currentTimeslice;
     return DQMC_OK;
 }
@@ -1031,7 +1083,16 @@ extern "C" int dqmc_get_sv_host(dqmc_ctx* c, double* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(out, selp(c, c->sv), c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(c, out, selp(c, c->sv), c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+// green_inv_sv of every chain: out[nchains][n_g]
+extern "C" int dqmc_get_sv_all_host(dqmc_ctx* c, double* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    const size_t bytes = (size_t)c->n_g * sizeof(double);
+    HIPCHK(hipMemcpy2DAsync(out, bytes, c->sv, c->lc.cs, bytes, (size_t)c->nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
     return DQMC_OK;
 }
 extern "C" int dqmc_get_udv_host(dqmc_ctx* c, int l, dqmc_cplx* U, double* d, dqmc_cplx* V_t) {
@@ -1040,9 +1101,9 @@ extern "C" int dqmc_get_udv_host(dqmc_ctx* c, int l, dqmc_cplx* U, double* d, dq
     if (l < 0 || l > c->n) return fail(DQMC_EINVAL, "l out of range");
     const size_t n2 = (size_t)c->n_g * c->n_g;
     HIPCHK(hipStreamSynchronize(c->st));
-    if (U) HIPCHK(hipMemcpy(U, selp(c, c->storage[l].U), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
-    if (d) HIPCHK(hipMemcpy(d, selp(c, c->storage[l].d), c->n_g * sizeof(double), hipMemcpyDeviceToHost));
-    if (V_t) HIPCHK(hipMemcpy(V_t, selp(c, c->storage[l].Vt), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    if (U) HIPCHK(copy_sync(c, U, selp(c, c->storage[l].U), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
+    if (d) HIPCHK(copy_sync(c, d, selp(c, c->storage[l].d), c->n_g * sizeof(double), hipMemcpyDeviceToHost));
+    if (V_t) HIPCHK(copy_sync(c, V_t, selp(c, c->storage[l].Vt), n2 * sizeof(cplx), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 extern "C" int dqmc_current_timeslice(dqmc_ctx* c) { return c ? c->currentTimeslice : -1; }
@@ -1109,7 +1170,7 @@ extern "C" int dqmc_shift_green_symmetric_host(dqmc_ctx* c, dqmc_cplx* out) {
     shift_green_dev(c);
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(out, selp(c, c->T1), (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(c, out, selp(c, c->T1), (size_t)c->n_g * c->n_g * sizeof(cplx), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 extern "C" int dqmc_measure_reset(dqmc_ctx* c) {
@@ -1131,7 +1192,7 @@ extern "C" int dqmc_measure_read_host(dqmc_ctx* c, double* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipMemcpy(out, selp(c, c->macc), c->macc_n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(c, out, selp(c, c->macc), c->macc_n * sizeof(double), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 
@@ -1141,7 +1202,7 @@ extern "C" int dqmc_exchange_action_host(dqmc_ctx* c, double* out) {
     { ProfScope ps(c, FAM_OTHER, 1); launch_phi_sq_sum(c->lc, c->hm, c->scalar_out); }
     HIPCHK(hipStreamSynchronize(c->st));
     double v;
-    HIPCHK(hipMemcpy(&v, selp(c, c->scalar_out), sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(c, &v, selp(c, c->scalar_out), sizeof(double), hipMemcpyDeviceToHost));
     *out = 0.5 * c->p.dtau * v;
     return DQMC_OK;
 }
@@ -1151,7 +1212,7 @@ extern "C" int dqmc_set_exchange_parameter(dqmc_ctx* c, double r) {
     (void)hipSetDevice(c->p.device);
     if (c->sel == 0) { c->p.r = r; c->hm.r = r; }
     HIPCHK(hipStreamSynchronize(c->st));     // the decision kernel reads DevUpdateState::r of its chain
-    HIPCHK(hipMemcpy((char*)selp(c, c->us) + offsetof(DevUpdateState, r), &r, sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(c, (char*)selp(c, c->us) + offsetof(DevUpdateState, r), &r, sizeof(double), hipMemcpyHostToDevice));
     return DQMC_OK;
 }
 
@@ -1177,7 +1238,7 @@ extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
     c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0; c->qr_calls = 0; c->gemm_flops = 0.0;
     const unsigned long long zero[2] = {0, 0};
     for (int b = 0; b < c->nb; ++b)
-        HIPCHK(hipMemcpy((char*)chainp(c, c->us, b) + offsetof(DevUpdateState, blocks_nonempty), zero, sizeof(zero), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(c, (char*)chainp(c, c->us, b) + offsetof(DevUpdateState, blocks_nonempty), zero, sizeof(zero), hipMemcpyHostToDevice));
     return DQMC_OK;
 }
 extern "C" int dqmc_profile_read(dqmc_ctx* c, dqmc_profile* out) {
@@ -1195,7 +1256,7 @@ extern "C" int dqmc_profile_read(dqmc_ctx* c, dqmc_profile* out) {
     out->decomp_rounds = c->fam_launches[FAM_ROUNDS];
     for (int b = 0; b < c->nb; ++b) {            // summed over the chains: independent of the selected chain
         unsigned long long v[2];
-        HIPCHK(hipMemcpy(v, (char*)chainp(c, c->us, b) + offsetof(DevUpdateState, blocks_nonempty), sizeof(v), hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(c, v, (char*)chainp(c, c->us, b) + offsetof(DevUpdateState, blocks_nonempty), sizeof(v), hipMemcpyDeviceToHost));
         out->blocks_nonempty += v[0];
         out->updates_accepted += v[1];
     }

@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <thread>
 
 namespace detqmc {
 
@@ -34,9 +36,25 @@ static bool same_model(const detsdw_params& a, const detsdw_params& b, bool seed
     return ints && reals && bc && seeds;
 }
 
-void DetSDW::select(int b) {
+dqmc_ctx* DetSDW::select(int b) {
     if (b < 0 || b >= (int)ch_.size()) throw ParameterWrong("chain index out of range");
-    check(dqmc_select_chain(ctx_, b), "dqmc_select_chain");
+    Group& g = grp(b);
+    check(dqmc_select_chain(g.ctx, b - g.first), "dqmc_select_chain");
+    return g.ctx;
+}
+
+// fn(group) for every sub-batch; with more than one group each runs on its own host thread (contexts are independent:
+// own stream, own device buffers; the kernel ABI allows different contexts on different threads).  The first exception
+// is rethrown after all threads have finished.
+void DetSDW::forEachGroup(const std::function<void(Group&)>& fn) {
+    if (groups_.size() == 1) { fn(groups_[0]); return; }
+    std::vector<std::exception_ptr> err(groups_.size());
+    std::vector<std::thread> th;
+    th.reserve(groups_.size());
+    for (size_t i = 0; i < groups_.size(); ++i)
+        th.emplace_back([&, i]() { try { fn(groups_[i]); } catch (...) { err[i] = std::current_exception(); } });
+    for (auto& t : th) t.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 // updateTemperatureParameters + ModelParamsDetSDW::check + createReplica on one parameter set
@@ -82,8 +100,15 @@ void DetSDW::normalise(detsdw_params& p, int& bcv) {
     if (!p.has_mux_muy) { p.mux = p.mu; p.muy = p.mu; }
 }
 
-DetSDW::DetSDW(const detsdw_params* in, int nchains) {
+DetSDW::DetSDW(const detsdw_params* in, int nchains, int sub_batches) {
     if (!in || nchains < 1) throw ParameterWrong("need at least one replica");
+    int S = sub_batches;
+    if (S == 0) {                                 // automatic: up to 4 groups, each at least 32 chains
+        S = 1;
+        for (int cand = 4; cand >= 2; --cand)
+            if (nchains % cand == 0 && nchains / cand >= 32) { S = cand; break; }
+    }
+    if (S < 1 || nchains % S != 0) throw ParameterWrong("sub_batches must divide the number of replicas");
     int bcv = 0;
     for (int b = 0; b < nchains; ++b) {
         detsdw_params p = in[b];
@@ -112,20 +137,30 @@ DetSDW::DetSDW(const detsdw_params* in, int nchains) {
     kp.mux = p.mux; kp.muy = p.muy; kp.accRatio = p.accRatio;
     kp.stabilisation = p.stabilisation;
     kp.cb_none = p.cb_none ? 1 : 0;          // reference option checkerboard=false (DetSDW<CB_NONE, OPDIM>)
-    check(dqmc_create_batch(&kp, nchains, &ctx_), "dqmc_create");
-
-    for (int b = 0; b < nchains; ++b) {
-        Chain& c = ch_[b];
-        c.phi.assign((size_t)N_ * opdim_ * (m_ + 1), 0.0);
-        setupRandomField(c);
-        select(b);
-        check(dqmc_set_exchange_parameter(ctx_, c.pars.r), "dqmc_set_exchange_parameter");
-        check(dqmc_set_fields_host(ctx_, c.phi.data()), "dqmc_set_fields_host");
+    groups_.resize(S);
+    try {
+        for (int g = 0; g < S; ++g) {
+            groups_[g].first = g * (nchains / S);
+            groups_[g].count = nchains / S;
+            check(dqmc_create_batch(&kp, nchains / S, &groups_[g].ctx), "dqmc_create");
+        }
+        for (int b = 0; b < nchains; ++b) {
+            Chain& c = ch_[b];
+            c.phi.assign((size_t)N_ * opdim_ * (m_ + 1), 0.0);
+            setupRandomField(c);
+            dqmc_ctx* ctx = select(b);
+            check(dqmc_set_exchange_parameter(ctx, c.pars.r), "dqmc_set_exchange_parameter");
+            check(dqmc_set_fields_host(ctx, c.phi.data()), "dqmc_set_fields_host");
+        }
+        forEachGroup([this](Group& g) { setupUdVStorage_and_calculateGreen(g); });
+    } catch (...) {
+        for (auto& g : groups_) dqmc_destroy(g.ctx);
+        throw;
     }
-    setupUdVStorage_and_calculateGreen();
+    lastSweepDir_ = Up;                                    // detmodel.h:711
 }
 
-DetSDW::~DetSDW() { dqmc_destroy(ctx_); }
+DetSDW::~DetSDW() { for (auto& g : groups_) dqmc_destroy(g.ctx); }
 
 // detsdwopdim.cpp:1099-1113: k outer, site, dim; one more draw per site for the (unused) cdwl field
 void DetSDW::setupRandomField(Chain& c) {
@@ -136,46 +171,44 @@ void DetSDW::setupRandomField(Chain& c) {
         }
 }
 
-void DetSDW::setupUdVStorage_and_calculateGreen() {
-    check(dqmc_udv_setup(ctx_), "setupUdVStorage_and_calculateGreen");
-    lastSweepDir_ = Up;                                    // detmodel.h:711
+void DetSDW::setupUdVStorage_and_calculateGreen(Group& g) {
+    check(dqmc_udv_setup(g.ctx), "setupUdVStorage_and_calculateGreen");
 }
 
 // Ship the worst-case number of upcoming uniforms of this sweep; the device consumes a prefix.
-void DetSDW::beginLocalUpdates() {
+void DetSDW::beginLocalUpdates(Group& g) {
     const size_t need = (size_t)(opdim_ + 1) * N_ * m_;
-    for (int b = 0; b < (int)ch_.size(); ++b) {
-        const double* w = ch_[b].rng.peek(need);
-        select(b);
-        check(dqmc_push_uniforms_host(ctx_, w, need), "dqmc_push_uniforms_host");
-    }
+    g.window.resize(need * g.count);               // all chains' windows back to back: one host -> device transfer
+    for (int b = 0; b < g.count; ++b) std::memcpy(&g.window[b * need], ch_[g.first + b].rng.peek(need), need * sizeof(double));
+    check(dqmc_push_uniforms_all_host(g.ctx, g.window.data(), need), "dqmc_push_uniforms_all_host");
 }
-void DetSDW::endLocalUpdates() {
-    for (int b = 0; b < (int)ch_.size(); ++b) {
-        dqmc_update_state st;
-        select(b);
-        check(dqmc_get_update_state_host(ctx_, &st), "dqmc_get_update_state_host");
-        ch_[b].rng.consume((size_t)st.rng_consumed);
-        ch_[b].phiDelta = st.phiDelta;
-        ch_[b].lastAccRatio = st.lastAccRatio;
+void DetSDW::endLocalUpdates(Group& g) {
+    std::vector<dqmc_update_state> st(g.count);
+    check(dqmc_get_update_states_all_host(g.ctx, st.data()), "dqmc_get_update_states_all_host");
+    for (int b = 0; b < g.count; ++b) {
+        Chain& c = ch_[g.first + b];
+        c.rng.consume((size_t)st[b].rng_consumed);
+        c.phiDelta = st[b].phiDelta;
+        c.lastAccRatio = st[b].lastAccRatio;
     }
 }
 
-void DetSDW::updateInSlice(int k, bool thermalization) {
-    check(dqmc_update_slice(ctx_, k, thermalization ? 1 : 0), "updateInSlice");
-    if (measuring_) check(dqmc_measure_slice(ctx_), "measure");     // updateInSliceAndMaybeMeasure (detmodel.h:1279-1285)
+void DetSDW::updateInSlice(Group& g, int k, bool thermalization) {
+    check(dqmc_update_slice(g.ctx, k, thermalization ? 1 : 0), "updateInSlice");
+    if (measuring_) check(dqmc_measure_slice(g.ctx), "measure");     // updateInSliceAndMaybeMeasure (detmodel.h:1279-1285)
 }
 
 // detmodel.h:1333-1399
-void DetSDW::sweepDown(bool thermalization) {
+void DetSDW::sweepDown(Group& g, bool thermalization) {
+    dqmc_ctx* ctx_ = g.ctx;
     for (int k = m_; k >= (n_ - 1) * s_ + 1; --k) {
-        updateInSlice(k, thermalization);
+        updateInSlice(g, k, thermalization);
         check(dqmc_wrap(ctx_, DQMC_DOWN, k), "wrapDownGreen");
     }
     for (int l = n_ - 1; l >= 1; --l) {
         check(dqmc_advance(ctx_, DQMC_DOWN, l + 1), "advanceDownGreen");
         for (int k = l * s_; k >= (l - 1) * s_ + 1; --k) {
-            updateInSlice(k, thermalization);
+            updateInSlice(g, k, thermalization);
             check(dqmc_wrap(ctx_, DQMC_DOWN, k), "wrapDownGreen");
         }
     }
@@ -183,37 +216,35 @@ void DetSDW::sweepDown(bool thermalization) {
 }
 
 // detmodel.h:1266-1325
-void DetSDW::sweepUp(bool thermalization) {
+void DetSDW::sweepUp(Group& g, bool thermalization) {
+    dqmc_ctx* ctx_ = g.ctx;
     check(dqmc_reset_storage0(ctx_), "reset storage[0]");
     for (int l = 0; l <= n_ - 2; ++l) {
         for (int k = l * s_ + 1; k <= (l + 1) * s_; ++k) {
             check(dqmc_wrap(ctx_, DQMC_UP, k - 1), "wrapUpGreen");
-            updateInSlice(k, thermalization);
+            updateInSlice(g, k, thermalization);
         }
         check(dqmc_advance(ctx_, DQMC_UP, l), "advanceUpGreen");
     }
     for (int k = (n_ - 1) * s_ + 1; k <= m_; ++k) {
         check(dqmc_wrap(ctx_, DQMC_UP, k - 1), "wrapUpGreen");
-        updateInSlice(k, thermalization);
+        updateInSlice(g, k, thermalization);
     }
     check(dqmc_advance(ctx_, DQMC_UP, n_ - 1), "advanceUpGreen");
 }
 
 // detmodel.h:1408-1478 and detsdwopdim.cpp:4423-4502
-void DetSDW::sweep_skeleton(bool thermalization) {
+void DetSDW::sweep_skeleton(Group& g, bool thermalization) {
     if (lastSweepDir_ == Up) {
-        globalMove();
-        beginLocalUpdates();
-        sweepDown(thermalization);
-        endLocalUpdates();
-        lastSweepDir_ = Down;
+        globalMove(g);
+        beginLocalUpdates(g);
+        sweepDown(g, thermalization);
+        endLocalUpdates(g);
     } else {
-        beginLocalUpdates();
-        sweepUp(thermalization);
-        endLocalUpdates();
-        lastSweepDir_ = Up;
+        beginLocalUpdates(g);
+        sweepUp(g, thermalization);
+        endLocalUpdates(g);
     }
-    ++performedSweeps_;
 }
 
 // sweep(takeMeasurements): the bosonic observables depend on the field only, and measure(k) runs right after the
@@ -221,10 +252,12 @@ void DetSDW::sweep_skeleton(bool thermalization) {
 // the sweep, so they are accumulated afterwards from the final field, in the slice order of the sweep just done.
 void DetSDW::sweep(bool takeMeasurements) {
     const bool fermionic = takeMeasurements && ch_[0].pars.fermionMeasurements;
-    if (fermionic) check(dqmc_measure_reset(ctx_), "initMeasurements");
+    if (fermionic) for (auto& g : groups_) check(dqmc_measure_reset(g.ctx), "initMeasurements");
     measuring_ = fermionic;
-    try { sweep_skeleton(false); } catch (...) { measuring_ = false; throw; }
+    try { forEachGroup([this](Group& g) { sweep_skeleton(g, false); }); } catch (...) { measuring_ = false; throw; }
     measuring_ = false;
+    lastSweepDir_ = (lastSweepDir_ == Up) ? Down : Up;
+    ++performedSweeps_;
     for (int b = 0; b < (int)ch_.size(); ++b) {
         if (takeMeasurements) {
             syncPhiFromDevice(b);
@@ -240,7 +273,7 @@ void DetSDW::sweep(bool takeMeasurements) {
 // finishMeasurements, fermionic part (detsdwopdim.cpp:923-1015) from the device accumulators of chain b
 void DetSDW::finishFermionic(int b) {
     Chain& c = ch_[b];
-    select(b);
+    dqmc_ctx* ctx_ = select(b);
     std::vector<double> acc(dqmc_measure_accum_size(ctx_));
     check(dqmc_measure_read_host(ctx_, acc.data()), "dqmc_measure_read_host");
     const int L = c.pars.L, N = N_, m = m_;
@@ -343,21 +376,25 @@ void DetSDW::measureBosonic(Chain& c, bool descending) {
     o.associatedEnergy = assoc / (2.0 * N_ * m_);
     o.valid = 1;
 }
-void DetSDW::sweepThermalization() { sweep_skeleton(true); }
+void DetSDW::sweepThermalization() {
+    forEachGroup([this](Group& g) { sweep_skeleton(g, true); });
+    lastSweepDir_ = (lastSweepDir_ == Up) ? Down : Up;
+    ++performedSweeps_;
+}
 
 // detsdwopdim.cpp:3461-3486 -- all chains of a batch attempt their global moves in the same sweep, in the reference's
 // order: shift, Wolff cluster, combined cluster + shift
-void DetSDW::globalMove() {
+void DetSDW::globalMove(Group& g) {
     const detsdw_params& p = ch_[0].pars;
     if (p.globalUpdateInterval > 0 && performedSweeps_ % p.globalUpdateInterval == 0) {
-        if (p.globalShift) attemptGlobalMove(MoveShift);
-        if (p.wolffClusterUpdate) attemptGlobalMove(MoveWolff);
-        if (p.wolffClusterShiftUpdate) attemptGlobalMove(MoveWolffShift);
+        if (p.globalShift) attemptGlobalMove(g, MoveShift);
+        if (p.wolffClusterUpdate) attemptGlobalMove(g, MoveWolff);
+        if (p.wolffClusterShiftUpdate) attemptGlobalMove(g, MoveWolffShift);
     }
 }
 
 void DetSDW::syncPhiFromDevice(int b) {
-    select(b);
+    dqmc_ctx* ctx_ = select(b);
     check(dqmc_get_fields_host(ctx_, ch_[b].phi.data(), nullptr, nullptr), "dqmc_get_fields_host");
 }
 
@@ -478,22 +515,22 @@ unsigned DetSDW::buildAndFlipCluster(Chain& c) {
 // attemptWolffClusterShiftUpdate (:3647-3751) for every chain of the batch: the proposal of each chain is drawn from
 // its own RNG stream on the host mirror of its field, the UdV storage / G of all chains are rebuilt by ONE batched
 // set-up, then each chain accepts or restores on its own.
-void DetSDW::attemptGlobalMove(GlobalMoveKind kind) {
-    const int nb = (int)ch_.size();
-    std::vector<double> prob_scalar(nb, 1.0), old_sv((size_t)nb * ng_), new_sv(ng_), added(nb, 0.0);
-    std::vector<std::vector<double>> phi_backup(nb);
+void DetSDW::attemptGlobalMove(Group& g, GlobalMoveKind kind) {
+    const int nb = g.count;
+    dqmc_ctx* ctx = g.ctx;
+    const size_t nphi = (size_t)N_ * opdim_ * (m_ + 1);
+    std::vector<double> prob_scalar(nb, 1.0), old_sv((size_t)nb * ng_), new_sv((size_t)nb * ng_), added(nb, 0.0);
+    std::vector<dqmc_update_state> st(nb);
+    // ONE transfer each for the fields, the step sizes and the old log-determinant data of all chains of the group
+    g.fields.resize(nphi * nb);
+    check(dqmc_get_fields_all_host(ctx, g.fields.data()), "dqmc_get_fields_all_host");
+    check(dqmc_get_update_states_all_host(ctx, st.data()), "dqmc_get_update_states_all_host");
+    check(dqmc_get_sv_all_host(ctx, old_sv.data()), "dqmc_get_sv_all_host");
+    check(dqmc_backup(ctx), "globalMoveStoreBackups");
     for (int b = 0; b < nb; ++b) {
-        Chain& c = ch_[b];
-        syncPhiFromDevice(b);
-        dqmc_update_state st;
-        check(dqmc_get_update_state_host(ctx_, &st), "dqmc_get_update_state_host");
-        c.phiDelta = st.phiDelta;
-        check(dqmc_get_sv_host(ctx_, &old_sv[(size_t)b * ng_]), "dqmc_get_sv_host");
-    }
-    check(dqmc_backup(ctx_), "globalMoveStoreBackups");
-    for (int b = 0; b < nb; ++b) {
-        Chain& c = ch_[b];
-        phi_backup[b] = c.phi;
+        Chain& c = ch_[g.first + b];
+        std::memcpy(c.phi.data(), &g.fields[nphi * b], nphi * sizeof(double));     // g.fields keeps the backup copy
+        c.phiDelta = st[b].phiDelta;
         if (kind != MoveShift)
             for (int r = 0; r < c.pars.repeatWolffPerSweep; ++r) added[b] += (double)buildAndFlipCluster(c);
         if (kind != MoveWolff) {
@@ -502,16 +539,18 @@ void DetSDW::attemptGlobalMove(GlobalMoveKind kind) {
             const double new_scalar_action = phiAction(c);
             prob_scalar[b] = std::exp(-(new_scalar_action - old_scalar_action));
         }
-        select(b);
-        check(dqmc_set_fields_host(ctx_, c.phi.data()), "updateCoshSinhTermsPhi");
     }
-    setupUdVStorage_and_calculateGreen();
+    {
+        std::vector<double> proposed(nphi * nb);
+        for (int b = 0; b < nb; ++b) std::memcpy(&proposed[nphi * b], ch_[g.first + b].phi.data(), nphi * sizeof(double));
+        check(dqmc_set_fields_all_host(ctx, proposed.data()), "updateCoshSinhTermsPhi");
+    }
+    setupUdVStorage_and_calculateGreen(g);
+    check(dqmc_get_sv_all_host(ctx, new_sv.data()), "dqmc_get_sv_all_host");
     for (int b = 0; b < nb; ++b) {
-        Chain& c = ch_[b];
-        select(b);
-        check(dqmc_get_sv_host(ctx_, new_sv.data()), "dqmc_get_sv_host");
+        Chain& c = ch_[g.first + b];
         double log_prob = 0.0;
-        for (int j = 0; j < ng_; ++j) log_prob += std::log(new_sv[j]) - std::log(old_sv[(size_t)b * ng_ + j]);
+        for (int j = 0; j < ng_; ++j) log_prob += std::log(new_sv[(size_t)b * ng_ + j]) - std::log(old_sv[(size_t)b * ng_ + j]);
         double prob_fermion = std::exp(log_prob);
         if (opdim_ < 3) prob_fermion = prob_fermion * prob_fermion;
         const double prob = (kind == MoveWolff) ? prob_fermion : prob_scalar[b] * prob_fermion;
@@ -524,25 +563,26 @@ void DetSDW::attemptGlobalMove(GlobalMoveKind kind) {
             accepted += 1;
             c.addedWolffClusterSize += added[b];
         } else {
-            check(dqmc_restore(ctx_), "globalMoveRestoreBackups");
-            c.phi = phi_backup[b];
+            check(dqmc_select_chain(ctx, b), "dqmc_select_chain");
+            check(dqmc_restore(ctx), "globalMoveRestoreBackups");
+            std::memcpy(c.phi.data(), &g.fields[nphi * b], nphi * sizeof(double));
         }
     }
 }
 
 void DetSDW::set_exchange_parameter_value(double r, int b) {
-    select(b);
+    dqmc_ctx* ctx_ = select(b);
     ch_[b].pars.r = r;
     check(dqmc_set_exchange_parameter(ctx_, r), "set_exchange_parameter_value");
 }
 double DetSDW::get_exchange_action_contribution(int b) {
     double v = 0.0;
-    select(b);
+    dqmc_ctx* ctx_ = select(b);
     check(dqmc_exchange_action_host(ctx_, &v), "get_exchange_action_contribution");
     return v;
 }
 void DetSDW::get_control_data(detsdw_control_data& out, int b) {
-    select(b);
+    dqmc_ctx* ctx_ = select(b);
     out.acceptedGlobalShifts = ch_[b].acceptedGlobalShifts;
     out.attemptedGlobalShifts = ch_[b].attemptedGlobalShifts;
     out.acceptedWolffClusterUpdates = ch_[b].acceptedWolffClusterUpdates;
@@ -553,7 +593,7 @@ void DetSDW::get_control_data(detsdw_control_data& out, int b) {
     check(dqmc_get_update_state_host(ctx_, &out.adjust), "get_control_data");
 }
 void DetSDW::set_control_data(const detsdw_control_data& in, int b) {
-    select(b);
+    dqmc_ctx* ctx_ = select(b);
     ch_[b].acceptedGlobalShifts = in.acceptedGlobalShifts;
     ch_[b].attemptedGlobalShifts = in.attemptedGlobalShifts;
     ch_[b].acceptedWolffClusterUpdates = in.acceptedWolffClusterUpdates;
@@ -569,7 +609,7 @@ void DetSDW::set_control_data(const detsdw_control_data& in, int b) {
 }
 
 void DetSDW::getInfo(detsdw_info& o, int b) {
-    select(b);
+    dqmc_ctx* ctx_ = select(b);
     const Chain& c = ch_[b];
     std::memset(&o, 0, sizeof(o));
     o.opdim = opdim_; o.L = c.pars.L; o.N = N_; o.MSF = MSF_; o.n_g = ng_; o.m = m_; o.s = s_; o.n = n_;
@@ -589,10 +629,11 @@ void DetSDW::getPhi(double* out, int b) {
 }
 // also rebuilds UdV storage and G -- of every chain of the batch (one batched setup)
 void DetSDW::setPhi(const double* in, int b) {
-    select(b);
+    dqmc_ctx* ctx_ = select(b);
     std::memcpy(ch_[b].phi.data(), in, ch_[b].phi.size() * sizeof(double));
     check(dqmc_set_fields_host(ctx_, ch_[b].phi.data()), "dqmc_set_fields_host");
-    setupUdVStorage_and_calculateGreen();
+    setupUdVStorage_and_calculateGreen(grp(b));             // one batched set-up: every chain of b's sub-batch is rebuilt
+    lastSweepDir_ = Up;
 }
 // detsdwopdim.cpp:4991-5012
 void DetSDW::saveConfigurationStreamBinary(const std::string& directory, int b) {
@@ -660,18 +701,19 @@ void DetSDW::loadState(const std::string& path) {
         if (np != c.phi.size()) throw GeneralError(DQMC_EINVAL, "checkpoint: field size mismatch");
         rd(fc.f, c.phi.data(), np * 8);
         c.rng.deserialize(rng);
-        select(b);
+        dqmc_ctx* ctx_ = select(b);
         c.pars.r = p.r;
         check(dqmc_set_exchange_parameter(ctx_, p.r), "dqmc_set_exchange_parameter");
         check(dqmc_set_fields_host(ctx_, c.phi.data()), "dqmc_set_fields_host");
         set_control_data(cd, b);
     }
     performedSweeps_ = hdr[2];
-    setupUdVStorage_and_calculateGreen();         // like the reference's resume: G(beta) from scratch, next sweep goes down
+    forEachGroup([this](Group& g) { setupUdVStorage_and_calculateGreen(g); });   // like the reference's resume: G(beta) from scratch, next sweep goes down
+    lastSweepDir_ = Up;
 }
 
-void DetSDW::getGreen(dqmc_cplx* g, int b) { select(b); check(dqmc_get_green_host(ctx_, g), "dqmc_get_green_host"); }
-void DetSDW::getGreenInvSv(double* sv, int b) { select(b); check(dqmc_get_sv_host(ctx_, sv), "dqmc_get_sv_host"); }
+void DetSDW::getGreen(dqmc_cplx* g, int b) { check(dqmc_get_green_host(select(b), g), "dqmc_get_green_host"); }
+void DetSDW::getGreenInvSv(double* sv, int b) { check(dqmc_get_sv_host(select(b), sv), "dqmc_get_sv_host"); }
 
 }  // namespace detqmc
 
@@ -701,6 +743,16 @@ extern "C" int detsdw_create_batch(const detsdw_params* p, int nchains, detsdw_r
     if (!p || !out) { g_host_err = "null argument"; return DQMC_EINVAL; }
     *out = nullptr;
     GUARD({ DetSDW* d = new DetSDW(p, nchains); *out = new detsdw_replica{d, 0}; })
+}
+extern "C" int detsdw_create_batch_ex(const detsdw_params* p, int nchains, int sub_batches, detsdw_replica** out) {
+    if (!p || !out) { g_host_err = "null argument"; return DQMC_EINVAL; }
+    *out = nullptr;
+    GUARD({ DetSDW* d = new DetSDW(p, nchains, sub_batches); *out = new detsdw_replica{d, 0}; })
+}
+extern "C" int detsdw_num_sub_batches(detsdw_replica* r) { return r ? r->impl->numSubBatches() : 0; }
+extern "C" dqmc_ctx* detsdw_ctx_of_chain(detsdw_replica* r, int chain, int* local_index) {
+    if (!r || chain < 0 || chain >= r->impl->numChains()) return nullptr;
+    return r->impl->ctx(chain, local_index);
 }
 extern "C" int detsdw_num_chains(detsdw_replica* r) { return r ? r->impl->numChains() : 0; }
 extern "C" int detsdw_select_chain(detsdw_replica* r, int chain) {
@@ -734,7 +786,7 @@ extern "C" int detsdw_save_configuration_stream_binary(detsdw_replica* r, const 
     RGUARD(r->impl->saveConfigurationStreamBinary(directory ? directory : ".", r->sel))
 }
 extern "C" double detsdw_rng_rand01(detsdw_replica* r) { return r ? r->impl->rand01(r->sel) : -1.0; }
-extern "C" dqmc_ctx* detsdw_ctx(detsdw_replica* r) { return r ? r->impl->ctx() : nullptr; }
+extern "C" dqmc_ctx* detsdw_ctx(detsdw_replica* r) { return r ? r->impl->ctx(r->sel) : nullptr; }
 extern "C" double detsdw_get_exchange_parameter_value(detsdw_replica* r) { return r ? r->impl->get_exchange_parameter_value(r->sel) : 0.0; }
 extern "C" int detsdw_set_exchange_parameter_value(detsdw_replica* r, double v) { RGUARD(r->impl->set_exchange_parameter_value(v, r->sel)) }
 extern "C" const char* detsdw_get_exchange_parameter_name(detsdw_replica* r) { return r ? r->impl->get_exchange_parameter_name() : ""; }

@@ -3,6 +3,7 @@
 // numerical step is a call into the kernel ABI (include/dqmc_hip.h).  Method names follow the
 // reference so the parity tests read like the reference's own call sites.
 #pragma once
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -22,13 +23,19 @@ struct ParameterWrong : GeneralError {
 
 // One object drives nb >= 1 replicas ("chains") that share lattice, temperature and couplings and differ in
 // RNG stream (rngSeed / simindex), field configuration and the exchange parameter r -- exactly the set of
-// replicas of a DetQMCPT run (src/detqmcpt.h).  All chains advance in lockstep through ONE kernel context
-// (dqmc_create_batch), i.e. every launch carries all chains; nb = 1 is the reference's single replica.
+// replicas of a DetQMCPT run (src/detqmcpt.h).  nb = 1 is the reference's single replica.
 // Per-replica methods take the chain index b.
+//
+// The chains are held in S sub-batches ("groups"), each ONE kernel context (dqmc_create_batch: every launch carries
+// all chains of the group, own HIP stream).  A sweep runs the groups concurrently, one host thread per group: the
+// groups drift out of phase, so the latency-bound kernels of one (decision kernel, QR panel: one workgroup per chain)
+// overlap the streaming / MFMA kernels of the others -- within one process what round 1 needed four worker
+// processes for.  Chains are independent Markov chains, so the grouping changes no result (tests).
 class DetSDW {
 public:
     explicit DetSDW(const detsdw_params& pars) : DetSDW(&pars, 1) {}     // createReplica + ctor
-    DetSDW(const detsdw_params* pars, int nchains);
+    // sub_batches: 0 = automatic (up to 4 groups of at least 32 chains each), otherwise a divisor of nchains
+    DetSDW(const detsdw_params* pars, int nchains, int sub_batches = 0);
     ~DetSDW();
     DetSDW(const DetSDW&) = delete;
     DetSDW& operator=(const DetSDW&) = delete;
@@ -56,7 +63,9 @@ public:
     void saveState(const std::string& path);
     void loadState(const std::string& path);
     double rand01(int b = 0) { return ch_[b].rng.rand01(); }
-    dqmc_ctx* ctx() { return ctx_; }
+    int numSubBatches() const { return (int)groups_.size(); }
+    // kernel context that holds chain b and b's index inside it
+    dqmc_ctx* ctx(int b = 0, int* local = nullptr) { if (local) *local = b - grp(b).first; return grp(b).ctx; }
 
 private:
     enum SweepDirection { Up = +1, Down = -1 };
@@ -74,28 +83,36 @@ private:
         Chain(const detsdw_params& p) : pars(p), rng(p.rngSeed, (uint32_t)p.simindex + 1u) {}   // detqmc.h:181
     };
     std::vector<Chain> ch_;
+    struct Group {                                 // one sub-batch = one kernel context, chains [first, first + count)
+        dqmc_ctx* ctx = nullptr;
+        int first = 0, count = 0;
+        std::vector<double> window;                // uniforms of the coming sweep, all chains of the group
+        std::vector<double> fields;                // host staging of all chains' fields (global moves)
+    };
+    std::vector<Group> groups_;
     int N_, MSF_, ng_, m_, s_, n_, opdim_;
-    dqmc_ctx* ctx_ = nullptr;
     SweepDirection lastSweepDir_ = Up;
     int performedSweeps_ = 0;
 
-    void check(int rc, const char* what);
-    void select(int b);
+    Group& grp(int b) { return groups_[(size_t)b / (size_t)groups_[0].count]; }
+    static void check(int rc, const char* what);
+    dqmc_ctx* select(int b);                       // selects chain b in its context and returns that context
     static void normalise(detsdw_params& p, int& bcv);
     void setupRandomField(Chain& c);
-    void setupUdVStorage_and_calculateGreen();
-    void sweep_skeleton(bool thermalization);
+    void setupUdVStorage_and_calculateGreen(Group& g);
+    void forEachGroup(const std::function<void(Group&)>& fn);      // concurrently, one host thread per group
+    void sweep_skeleton(Group& g, bool thermalization);
     void measureBosonic(Chain& c, bool descending);
     void finishFermionic(int b);
     bool measuring_ = false;          // measure(k) after the updates of slice k (updateInSliceAndMaybeMeasure)
-    void sweepDown(bool thermalization);
-    void sweepUp(bool thermalization);
-    void updateInSlice(int k, bool thermalization);
-    void beginLocalUpdates();
-    void endLocalUpdates();
-    void globalMove();
+    void sweepDown(Group& g, bool thermalization);
+    void sweepUp(Group& g, bool thermalization);
+    void updateInSlice(Group& g, int k, bool thermalization);
+    void beginLocalUpdates(Group& g);
+    void endLocalUpdates(Group& g);
+    void globalMove(Group& g);
     enum GlobalMoveKind { MoveShift, MoveWolff, MoveWolffShift };
-    void attemptGlobalMove(GlobalMoveKind kind);
+    void attemptGlobalMove(Group& g, GlobalMoveKind kind);
     unsigned buildAndFlipCluster(Chain& c);
     void addGlobalRandomDisplacement(Chain& c);
     double phiAction(const Chain& c) const;

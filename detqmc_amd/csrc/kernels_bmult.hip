@@ -16,6 +16,7 @@
 #include "dqmc_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
@@ -57,7 +58,7 @@ __device__ __forceinline__ void build_V(cplx (&V)[MSF][MSF], double sign, double
 }
 
 template<int MSF, bool RIGHT, bool INV>
-__global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restrict__ A, int lda, int nvec,
+__global__ __launch_bounds__(512) void k_bmult_chain(DevModel dm, cplx* __restrict__ A, int lda, int nvec,
                                                       int kfirst, int kstep, int kcount, int shift, size_t cs) {
     extern __shared__ cplx sm[];
     dm = chain_model(dm, cs); CHAIN(A);
@@ -207,21 +208,49 @@ __global__ __launch_bounds__(256) void k_bmult_chain(DevModel dm, cplx* __restri
 void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, int side, int inverse,
                   int kfirst, int kstep, int kcount, cplx* A, int lda, int shift) {
     const int ng = hm.ng;
-    const int max_fit = (int)(65536 / ((size_t)ng * sizeof(cplx))) - (side == DQMC_LEFT ? 0 : 1);   // keep <= 64 KiB of LDS
+    // LEFT: <= 64 KiB of LDS; RIGHT: up to 144 KiB (one workgroup per CU then, two below 80 KiB) so that a row tile can be
+    // 8 rows = one full 128-byte line of every column
+    const size_t lds_cap = side == DQMC_LEFT ? 65536 : 144 * 1024;
+    const int max_fit = (int)(lds_cap / ((size_t)ng * sizeof(cplx))) - (side == DQMC_LEFT ? 0 : 1);
     static const int env_l = getenv("DQMC_BMULT_NVEC_L") ? atoi(getenv("DQMC_BMULT_NVEC_L")) : 0;   // developer knobs
     static const int env_r = getenv("DQMC_BMULT_NVEC_R") ? atoi(getenv("DQMC_BMULT_NVEC_R")) : 0;
     int nvec;
     if (side == DQMC_LEFT) {
         nvec = env_l ? env_l : ng / 256;                 // aim at >= 256 workgroups
     } else {
-        nvec = env_r ? env_r : 4;                        // 64-byte pieces of each column per row tile
+        // row tiles of 8 rows: every global transaction of the strided row access is a FULL 128-byte line.  With 4-row
+        // tiles (64-byte pieces) the other half of each line belongs to the neighbouring workgroup, which runs on another
+        // XCD: rocprofv3 FETCH_SIZE showed 2.0x the matrix per launch (profiles/r02_pmc_traffic_*.json)
+        nvec = env_r ? env_r : 8;
     }
     if (nvec > max_fit) nvec = max_fit;
     if (nvec < 1) nvec = 1;
     const int grid = (ng + nvec - 1) / nvec;
     const size_t lds = (size_t)(side == DQMC_LEFT ? nvec : nvec + 1) * ng * sizeof(cplx);
+    if (lds > 48 * 1024) {      // raise the dynamic-LDS limit of the instantiation once per device
+        static std::mutex mu;
+        static size_t raised_tab[64][8] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const int slot = (hm.MSF == 4 ? 4 : 0) + (side == DQMC_LEFT ? 0 : 2) + (inverse ? 1 : 0);
+        std::lock_guard<std::mutex> lk(mu);
+        size_t& raised = raised_tab[dev & 63][slot];
+        if (lds > raised) {
+            const void* f = nullptr;
+            if (hm.MSF == 2) f = side == DQMC_LEFT ? (inverse ? (const void*)k_bmult_chain<2, false, true> : (const void*)k_bmult_chain<2, false, false>)
+                                                   : (inverse ? (const void*)k_bmult_chain<2, true, true> : (const void*)k_bmult_chain<2, true, false>);
+            else             f = side == DQMC_LEFT ? (inverse ? (const void*)k_bmult_chain<4, false, true> : (const void*)k_bmult_chain<4, false, false>)
+                                                   : (inverse ? (const void*)k_bmult_chain<4, true, true> : (const void*)k_bmult_chain<4, true, false>);
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised = lds;
+            else (void)hipGetLastError();      // the launch below then reports the problem
+        }
+    }
+    // 8-row tiles hold twice the work of a 4-row tile and leave room for two workgroups per CU: 512 threads keep the
+    // number of resident waves (the only thing that hides the LDS / memory latency of this streaming kernel) the same
+    static const int env_t = getenv("DQMC_BMULT_THREADS_R") ? atoi(getenv("DQMC_BMULT_THREADS_R")) : 0;
+    const int nthreads = (side == DQMC_LEFT) ? 256 : (env_t ? env_t : (nvec >= 8 ? 512 : 256));
 #define LAUNCH(MSFV, R, I)                                                                              \
-    hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I>), dim3(grid, 1, lc.nb), dim3(256), lds, lc.st, hm, A, lda, nvec, \
+    hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I>), dim3(grid, 1, lc.nb), dim3(nthreads), lds, lc.st, hm, A, lda, nvec, \
                        kfirst, kstep, kcount, shift, lc.cs)
     if (hm.MSF == 2) {
         if (side == DQMC_LEFT) { if (!inverse) LAUNCH(2, false, false); else LAUNCH(2, false, true); }

@@ -401,16 +401,21 @@ struct QrRefs { const cplx* V[QR_MAXREF]; const cplx* Tn[QR_MAXREF]; int nb[QR_M
 // straight-line, so the compiler issues the loads of a pass in batches instead of one guarded load + s_waitcnt vmcnt(0)
 // per element (what the bounds-checked version compiled to: waves were parked half of their cycles).
 template<bool TRANS_T, int NCH>
-__global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, cplx* __restrict__ C, int ldc, int rows, int ncols, size_t cs) {
+__global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, cplx* __restrict__ C, int ldc, int rows, int ncols, size_t cs, int nb_chains) {
     __shared__ cplx sW[QR_NB][QR_NB + 1];      // W, then W2, as [k][j]
     __shared__ cplx sT[QR_NB][QR_NB + 1];      // -T as [i][k]
     __shared__ cplx sPart[4][QR_NB][QR_NB + 1];
-    CHAIN(C);
+    // all column blocks of a chain on ONE XCD (1-D grid, chains a multiple of 8): the reflector panels V, which every
+    // workgroup of the chain reads twice per reflector, are then fetched into one L2 instead of eight (rocprofv3 FETCH_SIZE of
+    // the trailing update before: 2.3x its algorithmic bytes, profiles/r02_pmc_traffic_b128_d32.json)
+    int chain, cblk;
+    xcd_chain_tile((ncols + QR_NB - 1) / QR_NB, nb_chains, chain, cblk);
+    C = chain_ptr_i(C, cs, chain);
     constexpr int RW = 16 * NCH;                    // rows per wave
     constexpr int NE = 4 * NCH;                     // elements per lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int c0 = blockIdx.x * QR_NB;
+    const int c0 = cblk * QR_NB;
     const int nc = min(QR_NB, ncols - c0);
     const int slab = wave * RW;
     const int rlast = rows - 1;
@@ -428,8 +433,8 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
     // once per GROUP of panels.
     const int wi = tid & 15, wj = tid >> 4;
     for (int rf = 0; rf < refs.n; ++rf) {
-        const cplx* Vp = chain_ptr(refs.V[rf], cs);
-        const cplx* Tn = chain_ptr(refs.Tn[rf], cs);
+        const cplx* Vp = chain_ptr_i(refs.V[rf], cs, chain);
+        const cplx* Tn = chain_ptr_i(refs.Tn[rf], cs, chain);
         const int nb = refs.nb[rf];
         // per-iteration copies of the bounds the compiler cannot see through: otherwise the 32 clamped row indices and
         // 32 lane masks of the passes are hoisted out of this loop and kept alive across it (spills at NCH = 8)
@@ -556,15 +561,16 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
 
 template<bool TRANS_T>
 static void launch_apply_reg(const Launch& lc, dim3 grid, const QrRefs& r, int ldv, cplx* C, int ldc, int rows, int ncols) {
+    if (lc.nb % 8 == 0) grid = dim3(grid.x * lc.nb, 1, 1);          // XCD-aware 1-D grid, see xcd_chain_tile
     switch ((rows + 63) / 64) {
-        case 1: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 1>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
-        case 2: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 2>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
-        case 3: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 3>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
-        case 4: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 4>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
-        case 5: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 5>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
-        case 6: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 6>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
-        case 7: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 7>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
-        default: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 8>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs); break;
+        case 1: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 1>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs, lc.nb); break;
+        case 2: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 2>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs, lc.nb); break;
+        case 3: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 3>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs, lc.nb); break;
+        case 4: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 4>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs, lc.nb); break;
+        case 5: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 5>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs, lc.nb); break;
+        case 6: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 6>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs, lc.nb); break;
+        case 7: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 7>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs, lc.nb); break;
+        default: hipLaunchKernelGGL((k_qr_apply_reg<TRANS_T, 8>), grid, dim3(256), 0, lc.st, r, ldv, C, ldc, rows, ncols, lc.cs, lc.nb); break;
     }
 }
 

@@ -397,8 +397,10 @@ class DetSDW:
 
     @property
     def kernel_context(self):
-        kc = _CtxView(self.lib, self.lib.detsdw_ctx(self.h), self.info)
-        check(self.lib.dqmc_select_chain(kc.h, self._chain))
+        """the kernel context that holds this chain (a batch may spread its chains over several), this chain selected"""
+        local = C.c_int(0)
+        kc = _CtxView(self.lib, self.lib.detsdw_ctx_of_chain(self.h, self._chain, C.byref(local)), self.info)
+        check(self.lib.dqmc_select_chain(kc.h, local.value))
         return kc
 
     # replica exchange surface (reference src/detsdwopdim.h:116-153)
@@ -435,13 +437,16 @@ class DetSDWBatch:
     (detsdw_create_batch): every launch carries all chains, which is what fills the chip.  The parameter sets
     may differ only in r, rngSeed and simindex; chain b follows exactly the Markov chain of DetSDW(pars[b])."""
 
-    def __init__(self, pars_list):
+    def __init__(self, pars_list, sub_batches=0):
+        """sub_batches: kernel contexts the chains are spread over and swept concurrently (one host thread each);
+        0 = automatic (up to 4 contexts of at least 32 chains), 1 = one context / one launch sequence for all chains"""
         self.lib = load()
         self.pars_list = list(pars_list)
         arr = (_lib.detsdw_params * len(self.pars_list))(*[_host_params(p) for p in self.pars_list])
         h = C.c_void_p()
-        check(self.lib.detsdw_create_batch(arr, len(self.pars_list), C.byref(h)), host=True)
+        check(self.lib.detsdw_create_batch_ex(arr, len(self.pars_list), int(sub_batches), C.byref(h)), host=True)
         self.h = h
+        self.sub_batches = self.lib.detsdw_num_sub_batches(h)
         self.chains = [DetSDW(_batch=self, _chain=b) for b in range(len(self.pars_list))]
 
     def __len__(self):
@@ -464,7 +469,13 @@ class DetSDWBatch:
 
     @property
     def kernel_context(self):
-        return _CtxView(self.lib, self.lib.detsdw_ctx(self.h), self.chains[0].info)
+        """the kernel context of chain 0 (the only one unless the batch has several sub-batches)"""
+        return self.chains[0].kernel_context
+
+    def kernel_contexts(self):
+        """one view per sub-batch"""
+        per = len(self.chains) // self.sub_batches
+        return [self.chains[g * per].kernel_context for g in range(self.sub_batches)]
 
     def close(self):
         if self.h:

@@ -110,6 +110,13 @@ int detsdw_create(const detsdw_params* p, detsdw_replica** out);
  * single replica created from p[b] would.  detsdw_sweep* act on all chains, every other call below on the
  * chain chosen with detsdw_select_chain (default 0). */
 int detsdw_create_batch(const detsdw_params* p, int nchains, detsdw_replica** out);
+/* The chains of a batch live in `sub_batches` kernel contexts (own HIP stream each) that a sweep drives concurrently, one
+ * host thread per context: the contexts drift out of phase, so the latency-bound kernels of one overlap the streaming /
+ * MFMA kernels of the others inside ONE process.  Results do not depend on the grouping (independent Markov chains).
+ * sub_batches = 0 (what detsdw_create_batch passes): automatic, up to 4 contexts of at least 32 chains each; otherwise a
+ * divisor of nchains. */
+int detsdw_create_batch_ex(const detsdw_params* p, int nchains, int sub_batches, detsdw_replica** out);
+int detsdw_num_sub_batches(detsdw_replica* r);
 int detsdw_select_chain(detsdw_replica* r, int chain);
 int detsdw_num_chains(detsdw_replica* r);
 void detsdw_destroy(detsdw_replica* r);
@@ -129,7 +136,8 @@ int detsdw_set_phi(detsdw_replica* r, const double* phi);      /* also rebuilds 
 int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g);
 int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv);
 double detsdw_rng_rand01(detsdw_replica* r);                   /* draws from the replica's stream */
-dqmc_ctx* detsdw_ctx(detsdw_replica* r);
+dqmc_ctx* detsdw_ctx(detsdw_replica* r);                       /* kernel context holding the selected chain */
+dqmc_ctx* detsdw_ctx_of_chain(detsdw_replica* r, int chain, int* local_index);   /* ... and the chain's index inside it */
 
 /* saveConfigurationStreamBinary (src/detsdwopdim.cpp:4991-5012): appends the current field configuration to
  * <directory>/configs-phi.binarystream in the reference's order (x outer, y, k = 1..m, component; raw fp64), the

@@ -112,6 +112,9 @@ void* dqmc_stream(dqmc_ctx* ctx);
 /* upload phi and recompute cosh/sinh caches: updateCoshSinhTermsPhi (detsdwopdim.cpp:1175-1181) */
 int dqmc_set_fields_host(dqmc_ctx* ctx, const double* phi);
 int dqmc_get_fields_host(dqmc_ctx* ctx, double* phi, double* coshTermPhi, double* sinhTermPhi);
+/* all chains of a batched context in ONE transfer: phi_all = nchains cubes of (m+1) * opdim * N doubles, back to back */
+int dqmc_set_fields_all_host(dqmc_ctx* ctx, const double* phi_all);
+int dqmc_get_fields_all_host(dqmc_ctx* ctx, double* phi_all);
 
 /* ---- checkerboard B-multiplies (a10-a14) -------------------------------------------------- */
 /* A <- B(k2,k1) A | B(k2,k1)^-1 A | A B(k2,k1) | A B(k2,k1)^-1 on a HOST matrix:
@@ -142,11 +145,14 @@ int dqmc_reset_storage0(dqmc_ctx* ctx);
 /* ---- local updates (a17-a20) ---------------------------------------------------------------- */
 /* replace the window of pre-drawn uniforms (0,1) the device consumes in stream order */
 int dqmc_push_uniforms_host(dqmc_ctx* ctx, const double* u, size_t n);
+/* the same for ALL chains of a batched context in one transfer: u = nchains windows of n uniforms each, back to back */
+int dqmc_push_uniforms_all_host(dqmc_ctx* ctx, const double* u, size_t n);
 /* updateInSlice (detsdwopdim.cpp:2428-2489, delayed updates :3023-3175, box proposals :3922-3931,
  * deltaSPhi :4186-4239, get_delta_forsite :3179-3289); thermalization != 0 adds the step-size
  * adaptation of updateInSliceThermalization (:3294-3375) */
 int dqmc_update_slice(dqmc_ctx* ctx, int k, int thermalization);
 int dqmc_get_update_state_host(dqmc_ctx* ctx, dqmc_update_state* out);
+int dqmc_get_update_states_all_host(dqmc_ctx* ctx, dqmc_update_state* out /* [nchains] */);
 int dqmc_set_update_state_host(dqmc_ctx* ctx, const dqmc_update_state* in);
 
 /* ---- state access ------------------------------------------------------------------------------ */
@@ -155,6 +161,7 @@ int dqmc_set_green_host(dqmc_ctx* ctx, const dqmc_cplx* in, int currentTimeslice
 /* green_inv_sv (detmodel.h:466): singular values of G^-1 in SVD mode; in QR mode a positive vector with
  * the same log-sum (= log|det G^-1|), which is all the global moves use (detsdwopdim.cpp:3613-3620) */
 int dqmc_get_sv_host(dqmc_ctx* ctx, double* out);
+int dqmc_get_sv_all_host(dqmc_ctx* ctx, double* out /* [nchains][n_g] */);
 int dqmc_get_udv_host(dqmc_ctx* ctx, int l, dqmc_cplx* U, double* d, dqmc_cplx* V_t);
 int dqmc_current_timeslice(dqmc_ctx* ctx);
 

@@ -1003,3 +1003,61 @@ def test_config5_O3_L24_beta20_full_size():
     E = Vt.conj().T @ Vt - np.eye(2304)
     assert np.max(np.abs(E)) < 1e-11
     rep.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# sub-batches: the chains of one handle spread over several kernel contexts swept by concurrent host threads
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["o2_L4_gshift", "o2_L4_wolffshift", "o2_L4_fmeas"])
+def test_sub_batches_do_not_change_the_chains(name, tmp_path):
+    """8 replicas in 4 kernel contexts x 2 chains (one host thread + HIP stream per context) against the same 8 replicas in
+    ONE context: identical fields, step sizes, global-move statistics and observables -- and chain 0 on the reference's
+    trajectory.  Also checkpoint / resume across the two layouts."""
+    import dataclasses
+    from detqmc_amd import DetSDWBatch
+    g = load_golden(name)
+    p0 = _sdw_params(g["params"], stabilisation="qr")
+    plist = [dataclasses.replace(p0, simindex=p0.simindex + b, r=p0.r + 0.03 * b) for b in range(8)]
+    one = DetSDWBatch(plist, sub_batches=1)
+    four = DetSDWBatch(plist, sub_batches=4)
+    assert one.sub_batches == 1 and four.sub_batches == 4 and len(four.kernel_contexts()) == 4
+    nsw = 0
+    while f"sweep{nsw + 1}_phi" in g:
+        nsw += 1
+        one.sweepThermalization()
+        four.sweepThermalization()
+        assert np.array_equal(four.chain(0).phi[1:], _golden_phi(g, f"sweep{nsw}_phi")[1:]), f"sweep {nsw}"
+    assert nsw >= 1
+    meas = "meas1_phi" in g
+    if meas:
+        one.sweep(True)
+        four.sweep(True)
+        assert np.array_equal(four.chain(0).phi[1:], _golden_phi(g, "meas1_phi")[1:])
+    for b in range(8):
+        a, c = one.chain(b), four.chain(b)
+        assert np.array_equal(a.phi, c.phi), b
+        assert relerr(c.g, a.g) < 1e-12, b
+        ia, ic = a.info, c.info
+        for f in ("phiDelta", "acceptedGlobalShifts", "attemptedGlobalShifts", "acceptedWolffClusterShiftUpdates", "addedWolffClusterSize",
+                  "rngDrawn", "performedSweeps", "lastSweepDir", "currentTimeslice"):
+            assert getattr(ia, f) == getattr(ic, f), (b, f)
+        assert c.kernel_context.currentTimeslice == ic.currentTimeslice
+        if meas:
+            oa, oc = a.observables, c.observables
+            assert oa.normMeanPhi == oc.normMeanPhi and oa.associatedEnergy == oc.associatedEnergy
+            if oa.fermionic_valid:
+                assert abs(oa.greenK0 - oc.greenK0) < 1e-10 * abs(oa.greenK0) and np.allclose(a.observable_vector("kOccX"), c.observable_vector("kOccX"), rtol=1e-10)
+    # a checkpoint written by the 4-context layout resumes in the 1-context layout (even number of sweeps so far or not:
+    # both continue from G(beta) rebuilt from the fields)
+    ck = str(tmp_path / "state.bin")
+    four.save_state(ck)
+    one.load_state(ck)
+    four.load_state(ck)
+    one.sweepThermalization()
+    four.sweepThermalization()
+    for b in range(8):
+        assert np.array_equal(one.chain(b).phi, four.chain(b).phi), b
+    with pytest.raises(Exception):
+        DetSDWBatch(plist, sub_batches=3)
+    one.close()
+    four.close()
