@@ -39,6 +39,10 @@ class ExchangeState:
     current_par_process: list = field(default_factory=list)   # rank 0: parameter index -> process
     par_swapUpProposed: list = field(default_factory=list)
     par_swapUpAccepted: list = field(default_factory=list)
+    # replica diffusion in parameter space (ExchangeStatistics, src/detqmcpt.h:92-115): 0 = NONE_P, +1 = UP_P, -1 = DOWN_P
+    process_goingWhere: list = field(default_factory=list)
+    par_countGoingUp: list = field(default_factory=list)
+    par_countGoingDown: list = field(default_factory=list)
 
     n_local: int = 1
     local_parameter_indices: list = field(default_factory=list)   # one per local replica
@@ -58,6 +62,9 @@ class ExchangeState:
             st.current_par_process = list(range(nproc))
             st.par_swapUpProposed = [0] * nproc
             st.par_swapUpAccepted = [0] * nproc
+            st.process_goingWhere = [0] * nproc
+            st.par_countGoingUp = [0] * nproc
+            st.par_countGoingDown = [0] * nproc
         return st
 
 
@@ -121,6 +128,18 @@ def replica_exchange_step(replica, state: ExchangeState, dist, device="cpu"):
         gathered = b"".join(r.cpu().numpy().tobytes() for r in recv)
         actions = [float(np.frombuffer(gathered[p * rec:p * rec + 8], dtype=np.float64)[0]) for p in range(nproc)]
         blobs = [gathered[p * rec + 8:(p + 1) * rec] for p in range(nproc)]
+        # histograms of replicas moving up or down in parameter space (src/detqmcpt.h:1016-1029): a replica that visited
+        # the highest parameter last is "going down", the lowest "going up"
+        for pi in range(nproc):
+            npar = state.current_process_par[pi]
+            if npar == nproc - 1:
+                state.process_goingWhere[pi] = -1
+            elif npar == 0:
+                state.process_goingWhere[pi] = +1
+            if state.process_goingWhere[pi] == -1:
+                state.par_countGoingDown[npar] += 1
+            elif state.process_goingWhere[pi] == +1:
+                state.par_countGoingUp[npar] += 1
         for cpi1 in range(nproc - 1):
             cpi2 = cpi1 + 1
             par1, par2 = state.controlParameterValues[cpi1], state.controlParameterValues[cpi2]
@@ -177,3 +196,173 @@ def replica_exchange_consistency_check(replica, state: ExchangeState, dist, devi
     if int(flag.item()) != 1:
         raise RuntimeError("replica exchange consistency check failed")
     return True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Observable routing and exchange statistics of a replica-exchange run: every measurement of every
+# replica is accumulated under the CONTROL PARAMETER the replica holds at that moment, not under the rank that
+# produced it.  Reference: ObservableHandlerPTCommon / ScalarObservableHandlerPT / VectorObservableHandlerPT
+# (src/mpiobservablehandlerpt.h:171-212, src/mpiobservablehandlerpt.cpp:65-110, 176-215, 221-300) and
+# DetQMCPT::saveReplicaExchangeStatistics / control_parameter_subdir (src/detqmcpt.h:596-660).
+# ---------------------------------------------------------------------------------------------------------------------
+def num_to_string(v):
+    """numToString (src/tools.h:45-50): default ostream formatting of a number"""
+    return ("%g" % v) if isinstance(v, float) else str(v)
+
+
+def control_parameter_subdir(cpi, name, value):
+    """src/detqmcpt.h:655-660"""
+    return "p%d_%s%s" % (cpi, name, num_to_string(float(value)))
+
+
+def _write_data_map(path, header_lines, metas, key_name, rows):
+    """DataMapWriter::writeToFile (src/datamapwriter.h:116-160): '## text' lines, '# key = value' metadata (every
+    MetadataMap sorted by key, the maps in the order given), then key <tab> value [<tab> error] with 15 digits, scientific"""
+    with open(path, "w") as f:
+        f.write("## %s\n" % header_lines[0])
+        for meta in metas:
+            for k in sorted(meta):
+                f.write("# %s = %s\n" % (k, meta[k]))
+        f.write("# key = %s\n" % key_name)
+        for line in header_lines[1:]:
+            f.write("## %s\n" % line)
+        for row in rows:
+            key = row[0]
+            f.write((("%d" % key) if isinstance(key, (int, np.integer)) else ("%.15e" % key) if isinstance(key, float) else str(key)))
+            for v in row[1:]:
+                f.write("\t%.15e" % v)
+            f.write("\n")
+
+
+class ObservableRouterPT:
+    """One handler for ALL observables of a replica-exchange run.  Collective: `insert` is called on every rank after a
+    measurement sweep with the local replicas' current values; the values meet at rank 0 (one all_gather -- the
+    reference does one MPI gather per observable) and are added, replica by replica, to the accumulators of the control
+    parameter index that replica currently holds (`state.current_process_par`, kept up to date by replica_exchange_step).
+
+    scalar_names / vector_specs = [(name, length)] fix the payload layout.  sweeps, jk_blocks, measure_interval as in
+    DetQMCParams."""
+
+    def __init__(self, state: ExchangeState, scalar_names, vector_specs, sweeps, jk_blocks=1, measure_interval=1, timeseries=False):
+        self.state = state
+        self.scalar_names = list(scalar_names)
+        self.vector_specs = [(n, int(l)) for n, l in vector_specs]
+        self.width = len(self.scalar_names) + sum(l for _, l in self.vector_specs)
+        self.sweeps, self.jk_blocks, self.measure_interval = int(sweeps), max(1, int(jk_blocks)), int(measure_interval)
+        self.jk_block_size_sweeps = max(1, self.sweeps // self.jk_blocks)              # mpiobservablehandlerpt.h:141-142
+        self.timeseries = timeseries
+        self.count_values = 0
+        self.last_sweep_logged = 0
+        self.nproc = len(state.controlParameterValues)
+        self.is_root = bool(state.current_process_par)
+        if self.is_root:
+            self.par_total = np.zeros((self.nproc, self.width))
+            self.par_jk = np.zeros((self.nproc, self.jk_blocks, self.width))
+            self.par_series = [[] for _ in range(self.nproc)]
+
+    def _pack(self, scalars, vectors):
+        row = np.empty(self.width)
+        row[:len(self.scalar_names)] = [float(scalars[n]) for n in self.scalar_names]
+        o = len(self.scalar_names)
+        for n, l in self.vector_specs:
+            v = np.asarray(vectors[n], dtype=np.float64)
+            if v.shape != (l,):
+                raise ValueError("vector observable %s has shape %s, expected (%d,)" % (n, v.shape, l))
+            row[o:o + l] = v
+            o += l
+        return row
+
+    def insert(self, cur_sweep, local_values, dist, device="cpu"):
+        """local_values: one (scalars dict, vectors dict) per local replica, in the order of the rank's replicas"""
+        import torch
+        nl = self.state.n_local
+        if len(local_values) != nl:
+            raise ValueError("expected %d local replicas, got %d" % (nl, len(local_values)))
+        send = torch.from_numpy(np.stack([self._pack(s, v) for s, v in local_values])).to(device)
+        if dist is not None:
+            recv = [torch.empty_like(send) for _ in range(dist.get_world_size())]
+            dist.all_gather(recv, send)
+        else:
+            recv = [send]
+        if self.is_root:
+            vals = np.concatenate([r.cpu().numpy() for r in recv], axis=0)          # [process][width]
+            cur_block = cur_sweep // self.jk_block_size_sweeps                        # handleValues, :171-186
+            for p_i in range(self.nproc):
+                cpi = self.state.current_process_par[p_i]
+                for jb in range(self.jk_blocks):
+                    if jb != cur_block:
+                        self.par_jk[cpi, jb] += vals[p_i]
+                self.par_total[cpi] += vals[p_i]
+                if self.timeseries:
+                    self.par_series[cpi].append(vals[p_i, :len(self.scalar_names)].copy())
+        self.count_values += 1
+        self.last_sweep_logged = cur_sweep
+
+    def evaluate_jackknife(self, cpi):
+        """(mean, error) rows of width `width` for control parameter index cpi (evaluateJackknife, :188-212 and the
+        scalar handler's plain standard deviation for a single block, mpiobservablehandlerpt.cpp:88-103)"""
+        if not self.is_root:
+            return None, None
+        mean = self.par_total[cpi] / self.count_values
+        err = np.zeros(self.width)
+        if self.sweeps - self.last_sweep_logged <= self.measure_interval:
+            if self.jk_blocks > 1:
+                block_samples = self.count_values // self.jk_blocks
+                total_samples = self.count_values - block_samples
+                blocks = self.par_jk[cpi] / total_samples
+                bc = self.jk_blocks
+                err = np.sqrt((bc - 1.0) / bc * np.sum((mean[None, :] - blocks) ** 2, axis=0))      # jackknife(), statistics.h:132-144
+            elif self.timeseries and len(self.par_series[cpi]) == self.count_values:
+                ns = len(self.scalar_names)
+                ts = np.array(self.par_series[cpi])
+                err[:ns] = np.sqrt(np.mean((ts - mean[None, :ns]) ** 2, axis=0))
+        return mean, err
+
+    def write_results(self, directory, parameter_name, meta_model=None, meta_mc=None, meta_pt=None):
+        """the reference's output tree: <directory>/p<cpi>_<name><value>/results.values and results-<vector>.values
+        (outputResults, src/mpiobservablehandlerpt.cpp:221-300); rank 0 only"""
+        import os
+        if not self.is_root:
+            return
+        for cpi in range(self.nproc):
+            value = self.state.controlParameterValues[cpi]
+            sub = os.path.join(directory, control_parameter_subdir(cpi, parameter_name, value))
+            os.makedirs(sub, exist_ok=True)
+            mean, err = self.evaluate_jackknife(cpi)
+            mm = dict(meta_model or {})
+            mm[parameter_name] = num_to_string(float(value))                          # par_metaModel[cpi]: only that entry replaced
+            meta = [mm, dict(meta_mc or {}), dict(meta_pt or {})]
+            ns = len(self.scalar_names)
+            order = sorted(range(ns), key=lambda i: self.scalar_names[i])               # std::map<std::string, num>: sorted by name
+            _write_data_map(os.path.join(sub, "results.values"), ["Monte Carlo results for observable expectation values", "observable\t value \t error"],
+                            meta, "observable", [(self.scalar_names[i], mean[i], err[i]) for i in order])
+            o = ns
+            for name, l in self.vector_specs:
+                _write_data_map(os.path.join(sub, "results-%s.values" % name),
+                                ["Monte Carlo results for vector observable %s expectation values" % name, "site\t value \t error"], meta, "site",
+                                [(float(i), mean[o + i], err[o + i]) for i in range(l)])
+                o += l
+
+
+def write_exchange_statistics(state: ExchangeState, directory, meta=None):
+    """exchange-parameters.values, exchange-acceptance.values, exchange-diffusion.values
+    (DetQMCPT::saveReplicaExchangeStatistics, src/detqmcpt.h:596-651); rank 0 only"""
+    import os
+    if not state.current_process_par:
+        return
+    n = len(state.controlParameterValues)
+    meta = [dict(m) for m in (meta or [])] if isinstance(meta, (list, tuple)) else [dict(meta or {})]
+    acc = [(state.par_swapUpAccepted[c] / state.par_swapUpProposed[c]) if state.par_swapUpProposed[c] else 0.0 for c in range(n)]
+    df = []
+    for c in range(n):
+        up, down = state.par_countGoingUp[c], state.par_countGoingDown[c]
+        df.append(up / (up + down) if (up + down) else 0.0)
+    _write_data_map(os.path.join(directory, "exchange-parameters.values"),
+                    ["Control parameter values", "control parameter index \t control parameter value"], meta, "control parameter index",
+                    [(c, float(state.controlParameterValues[c])) for c in range(n)])
+    _write_data_map(os.path.join(directory, "exchange-acceptance.values"),
+                    ["Acceptance ratio of exchanging replicas at control parameters (upwards)", "control parameter index \t acceptance ratio"],
+                    meta, "control parameter index", [(c, acc[c]) for c in range(n)])
+    _write_data_map(os.path.join(directory, "exchange-diffusion.values"),
+                    ["Diffusion fraction of replicas at control parameters: df = nUp / (nUp + nDown)", "control parameter index \t diffusion fraction"],
+                    meta, "control parameter index", [(c, df[c]) for c in range(n)])

@@ -12,7 +12,7 @@ prof = len(sys.argv) > 6 and sys.argv[6] == "prof"
 p0 = SDWParams(opdim=int(os.environ.get("DQMC_OPDIM", "2")), L=L, beta=beta, s=10, delaySteps=int(os.environ.get("DQMC_DELAY_STEPS", "16")), stabilisation=stab)
 for B in Bs:
     t0 = time.time()
-    batch = DetSDWBatch([dataclasses.replace(p0, simindex=b, r=p0.r + 0.01 * b) for b in range(B)])
+    batch = DetSDWBatch([dataclasses.replace(p0, simindex=b, r=p0.r + 0.01 * b) for b in range(B)], sub_batches=int(os.environ.get("DQMC_SUB_BATCHES", "1")))
     tinit = time.time() - t0
     ctx = batch.kernel_context
     batch.sweepThermalization(); batch.sweepThermalization()

@@ -47,7 +47,8 @@ class OracleReplica:
 
 def main():
     import torch.distributed as dist
-    from detqmc_amd.pt import ExchangeState, replica_exchange_step, replica_exchange_consistency_check
+    from detqmc_amd.pt import (ExchangeState, ObservableRouterPT, replica_exchange_step, replica_exchange_consistency_check,
+                               write_exchange_statistics)
     out = sys.argv[1]
     rvalues = json.loads(sys.argv[2])
     steps = int(sys.argv[3])
@@ -60,9 +61,17 @@ def main():
         rep.o.phiDelta = 0.5 + 0.1 * p              # make the control data distinguishable
     st = ExchangeState.create(rvalues, rank, world, n_local)
     hist = [[] for _ in reps]
+    # observable routing: every replica "measures" after each sweep; rank 0 files the values under the
+    # control parameter the replica holds at that moment
+    router = ObservableRouterPT(st, ["rHeld", "action"], [("vec", 3)], sweeps=steps, jk_blocks=steps if steps % 3 else 3, timeseries=True)
     for it in range(steps):
         for rep in reps:
             rep.sweepThermalization()
+        vals = []
+        for rep in reps:
+            r_, a_ = rep.get_exchange_parameter_value(), rep.get_exchange_action_contribution()
+            vals.append(({"rHeld": r_, "action": a_}, {"vec": [r_, r_ * r_, a_]}))
+        router.insert(it, vals, dist)
         idx = replica_exchange_step(reps if n_local > 1 else reps[0], st, dist)
         replica_exchange_consistency_check(reps, st, dist)
         idx = idx if n_local > 1 else [idx]
@@ -74,6 +83,10 @@ def main():
         res["proposed"] = st.par_swapUpProposed
         res["accepted"] = st.par_swapUpAccepted
         res["process_par"] = st.current_process_par
+        res["going_up"], res["going_down"] = st.par_countGoingUp, st.par_countGoingDown
+        res["routed"] = [[list(x) for x in router.evaluate_jackknife(c)] for c in range(len(rvalues))]
+        router.write_results(out, "r", {"L": 4, "opdim": 2, "r": "overwritten"}, {"sweeps": steps}, {"controlParameterName": "r"})
+        write_exchange_statistics(st, out, [{"L": 4}, {"sweeps": steps}])
     json.dump(res, open(os.path.join(out, "rank%d.json" % rank), "w"))
     dist.barrier()
     dist.destroy_process_group()

@@ -1061,3 +1061,34 @@ def test_sub_batches_do_not_change_the_chains(name, tmp_path):
         DetSDWBatch(plist, sub_batches=3)
     one.close()
     four.close()
+
+
+def test_replica_exchange_across_two_processes_with_real_chains(tmp_path):
+    """detqmc_amd/pt.py with REAL batched chains across two PROCESSES (torch.distributed, gloo; both ranks on this box's one
+    GPU): 2 ranks x 2 chains must follow, step by step, the single-process run that holds all 4 chains in one batch --
+    parameter indices, r on the device, step sizes, field configurations, and the observables filed per control parameter."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    rvalues, steps = [-1.2, -1.1, -1.0, -0.9], 4
+    worker = os.path.join(ROOT, "tests", "pt_gpu_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable, worker, str(tmp_path), json.dumps(rvalues), str(steps), "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29500 + (os.getpid() % 400)), worker, str(tmp_path), json.dumps(rvalues), str(steps), "2"],
+                         env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    ref = json.load(open(tmp_path / "rank0_of1.json"))
+    got = [json.load(open(tmp_path / ("rank%d_of2.json" % r))) for r in range(2)]
+    moved = False
+    for p in range(4):
+        for it in range(steps):
+            a, b = ref["hist"][p][it], got[p // 2]["hist"][p % 2][it]
+            assert a == b, (p, it, a, b)
+            moved |= a["index"] != p
+    assert moved, "ladder too steep for any swap"
+    assert ref["proposed"] == got[0]["proposed"] and ref["accepted"] == got[0]["accepted"]
+    assert np.allclose(np.array(ref["routed"]), np.array(got[0]["routed"]), rtol=1e-14, atol=0)

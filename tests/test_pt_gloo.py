@@ -116,3 +116,92 @@ def test_rank_count_must_match_parameter_count():
     from detqmc_amd.pt import ExchangeState
     with pytest.raises(ValueError):
         ExchangeState.create([-1.0, -0.5, 0.0], rank=0, world=2)
+
+
+# ------------------------------------------------------------------------------------------------
+# observable routing by control parameter + exchange statistics
+# ------------------------------------------------------------------------------------------------
+def _reference_jackknife(series, jk_blocks):
+    """jackknifeBlockEstimates + jackknife as the reference computes them from a time series
+    (src/statistics.h:51-75, 132-144); mean = plain average of all samples"""
+    import numpy as np
+    series = np.asarray(series, dtype=float)
+    n = len(series)
+    block = n // jk_blocks
+    est = np.zeros((jk_blocks,) + series.shape[1:])
+    for i in range(jk_blocks * block):
+        for jb in range(jk_blocks):
+            if jb != i // block:
+                est[jb] += series[i]
+    est /= (jk_blocks * block - block)
+    mean = series.mean(axis=0)
+    return mean, np.sqrt((jk_blocks - 1.0) / jk_blocks * np.sum((mean[None] - est) ** 2, axis=0))
+
+
+def test_observables_are_routed_to_the_control_parameter_two_ranks_gloo(tmp_path):
+    """2 ranks x 2 replicas: each replica reports (the r it holds, its action, a 3-vector) after every sweep; the values
+    must land under the control parameter index the replica holds at that moment (ObservableHandlerPTCommon::handleValues,
+    src/mpiobservablehandlerpt.h:171-186), with the reference's jackknife, and the output tree must be the reference's
+    p<cpi>_r<value>/results.values + exchange-*.values."""
+    import numpy as np
+    rvalues, steps = [-1.0, -0.9, -0.8, -0.7], 6
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + ((os.getpid() + 13) % 500)), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "pt_worker.py"), str(tmp_path),
+           json.dumps(rvalues), str(steps), "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    got = [json.load(open(tmp_path / ("rank%d.json" % p))) for p in range(2)]
+    # serial replay: the parameter index a replica holds DURING sweep `it` is the one set by the exchange after sweep it-1
+    hist = {rank * 2 + b: got[rank]["hist_all"][b] for rank in range(2) for b in range(2)}
+    series = {c: [] for c in range(4)}
+    moved = False
+    for it in range(steps):
+        for p in range(4):
+            held = p if it == 0 else hist[p][it - 1]["index"]
+            moved |= held != p
+            r_, a_ = rvalues[held], hist[p][it]["action"]
+            series[held].append([r_, a_, r_, r_ * r_, a_])
+    assert moved, "no exchange was accepted: the routing would not be exercised"
+    jk = 3
+    for c in range(4):
+        assert len(series[c]) == steps                     # every parameter is held by exactly one replica in every sweep
+        mean, err = _reference_jackknife(series[c], jk)
+        gm, ge = (np.array(x) for x in got[0]["routed"][c])
+        assert np.allclose(gm, mean, rtol=1e-13, atol=1e-13) and np.allclose(ge, err, rtol=1e-9, atol=1e-13), c
+        assert abs(gm[0] - rvalues[c]) < 1e-15 and ge[0] < 1e-13       # "the r it holds" filed under r: constant
+        sub = tmp_path / ("p%d_r%s" % (c, ("%g" % rvalues[c])))
+        lines = open(sub / "results.values").read().splitlines()
+        assert lines[0] == "## Monte Carlo results for observable expectation values"
+        assert "# r = %g" % rvalues[c] in lines and "# key = observable" in lines and lines[-3].startswith("## observable")
+        rows = [l.split("\t") for l in lines if not l.startswith("#")]
+        assert [r[0] for r in rows] == ["action", "rHeld"]
+        assert abs(float(rows[0][1]) - mean[1]) <= 1e-14 * abs(mean[1]) and abs(float(rows[1][1]) - rvalues[c]) < 1e-15
+        vrows = [l.split("\t") for l in open(sub / "results-vec.values").read().splitlines() if not l.startswith("#")]
+        assert len(vrows) == 3 and abs(float(vrows[1][1]) - rvalues[c] ** 2) < 1e-14
+    # exchange statistics files (src/detqmcpt.h:596-651)
+    prop, acc = got[0]["proposed"], got[0]["accepted"]
+    arows = [l.split("\t") for l in open(tmp_path / "exchange-acceptance.values").read().splitlines() if not l.startswith("#")]
+    assert [int(r[0]) for r in arows] == [0, 1, 2, 3]
+    for c in range(4):
+        assert abs(float(arows[c][1]) - (acc[c] / prop[c] if prop[c] else 0.0)) < 1e-14
+    prow = [l.split("\t") for l in open(tmp_path / "exchange-parameters.values").read().splitlines() if not l.startswith("#")]
+    assert [float(r[1]) for r in prow] == rvalues
+    # diffusion histogram replayed from the exchange history (src/detqmcpt.h:1016-1029)
+    going = {p: 0 for p in range(4)}
+    up, down = [0] * 4, [0] * 4
+    for it in range(steps):
+        for p in range(4):
+            held = p if it == 0 else hist[p][it - 1]["index"]
+            if held == 3:
+                going[p] = -1
+            elif held == 0:
+                going[p] = +1
+            if going[p] == -1:
+                down[held] += 1
+            elif going[p] == +1:
+                up[held] += 1
+    assert got[0]["going_up"] == up and got[0]["going_down"] == down
+    drow = [l.split("\t") for l in open(tmp_path / "exchange-diffusion.values").read().splitlines() if not l.startswith("#")]
+    for c in range(4):
+        assert abs(float(drow[c][1]) - (up[c] / (up[c] + down[c]) if up[c] + down[c] else 0.0)) < 1e-14
