@@ -6,8 +6,12 @@
 //
 //   C[MxN] (+)= rowscale_i * ( op(A)[MxK] . diag(kscale^{+-1}) . op(B)[KxN] ) * colscale_j
 //
-// op = N or conjugate transpose.  A complex product is 4 real MFMAs per 16x16x4 step
-// (re += ar*br - ai*bi, im += ar*bi + ai*br).  Operands are staged through LDS as [k][i] / [k][j]
+// op = N or conjugate transpose.  A complex product is THREE real MFMAs per 16x16x4 step ("3M", Karatsuba):
+//   P1 += ar*br,  P2 += ai*bi,  P3 += (ar + ai)*(br + bi);   re = P1 - P2,  im = P3 - P1 - P2
+// instead of four (re += ar*br - ai*bi, im += ar*bi + ai*br): these kernels are bound by the fp64 matrix cores (the 4M
+// form ran at 0.60-0.68 of the MFMA peak), so 25 % fewer MFMAs is 25 % less time in the MFMA loop; the two extra
+// adds per fragment go to the vector ALU, which idles next to a 64-cycle MFMA.  The cancellation in `im` costs a few
+// ulps relative to |a||b| -- far inside the 1e-10 parity tolerance (tests).  DQMC_GEMM_4M=1 selects the 4-MFMA form.  Operands are staged through LDS as [k][i] / [k][j]
 // interleaved (re,im) so one ds_read_b128 feeds both the real and the imaginary fragment.  The MFMA
 // is issued with the operand roles swapped (D^T = B^T A^T): the f64 accumulator then holds 16
 // CONSECUTIVE ROWS of one column per register across lanes 0..15 -- a 256-byte contiguous run in the
@@ -16,10 +20,11 @@
 // Workgroup = 4 waves in a 2x2 arrangement, each wave TMxTN MFMA tiles: 32x32 block tiles when
 // n_g = 512 (256 workgroups = one per CU), 64x64 for the large O(3) lattices.
 #include "dqmc_internal.h"
+#include <cstdlib>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template<int TM, int TN>
+template<int TM, int TN, bool M3>
 __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb) {   // 2 workgroups per CU: <= 256 registers
     constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16;
     constexpr int NA = BM * BK / 256, NB_ = BN * BK / 256;      // elements of the A / B tile staged per thread
@@ -43,11 +48,12 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
     const int i0 = (tile % tm) * BM, j0 = (tile / tm) * BN;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    v4d acc_re[TM][TN], acc_im[TM][TN];
+    // 4M: acc_re / acc_im; 3M: acc_re = P1, acc_im = P3, acc_p2 = P2
+    v4d acc_re[TM][TN], acc_im[TM][TN], acc_p2[M3 ? TM : 1][M3 ? TN : 1];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); }
+        for (int b = 0; b < TN; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); if (M3) acc_p2[a][b] = (v4d)(0.0); }
 
     cplx ra[NA], rb[NB_];
     // global -> registers: op(A) tile element (i, k), op(B) tile element (k, j).  Every load has a clamped, always valid
@@ -145,15 +151,28 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
             for (int a = 0; a < TM; ++a) af[a] = sA[buf][kk + l4][wm * 16 * TM + a * 16 + l15];
 #pragma unroll
             for (int b = 0; b < TN; ++b) bf[b] = sB[buf][kk + l4][wn * 16 * TN + b * 16 + l15];
+            double asum[TM], bsum[TN];
+            if (M3) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) asum[a] = af[a].x + af[a].y;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bsum[b] = bf[b].x + bf[b].y;
+            }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     // roles swapped: first operand indexes the OUTPUT "row" (= column j of C)
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bf[b].y, af[a].y, acc_re[a][b], 0, 0, 0);
-                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].x, acc_im[a][b], 0, 0, 0);
-                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
+                    if (M3) {
+                        acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
+                        acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].y, acc_p2[a][b], 0, 0, 0);
+                        acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+                    } else {
+                        acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
+                        acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bf[b].y, af[a].y, acc_re[a][b], 0, 0, 0);
+                        acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].x, acc_im[a][b], 0, 0, 0);
+                        acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
+                    }
                 }
         }
         if (more) sstore(buf ^ 1);
@@ -179,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
             for (int r = 0; r < 4; ++r) {
                 const int gj = j0 + wn * 16 * TN + b * 16 + l4 + 4 * r;
                 double re = acc_re[a][b][r], im = acc_im[a][b][r];
+                if (M3) { const double p1 = re, p2 = acc_p2[a][b][r]; re = p1 - p2; im = (im - p1) - p2; }
                 if (g.rowscale) { double sc = g.rowscale[gic] * g.colscale[min(gj, Nm1)]; re *= sc; im *= sc; }
                 else if (g.colscale) { double sc = g.colscale[min(gj, Nm1)]; re *= sc; im *= sc; }
                 if (g.negate) { re = -re; im = -im; }
@@ -196,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
 // memory into registers; two workgroups per CU so that one's loads overlap the other's MFMAs.
 // Fragment convention as in k_zgemm (operand roles swapped so that the stores coalesce).
 // ---------------------------------------------------------------------------------------------
+template<bool M3>
 __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, int ldx, const cplx* __restrict__ Gr, int ldg,
                                                   cplx* __restrict__ G, int ldc, int n, int Kmax, const int* __restrict__ Kdev,
                                                   int Kmul, size_t cs, int nb) {
@@ -210,11 +231,11 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
     const int l15 = lane & 15, l4 = lane >> 4;
     const int i0 = (tile % tn) * 64 + (wave >> 1) * 32, j0 = (tile / tn) * 64 + (wave & 1) * 32;
     if (i0 >= n || j0 >= n) return;
-    v4d acc_re[2][2], acc_im[2][2];
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[M3 ? 2 : 1][M3 ? 2 : 1];      // 3M: P1, P3, P2 (see the top of this file)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); }
+        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); if (M3) acc_p2[a][b] = (v4d)(0.0); }
     // operand fragments of k-step k0 (clamped addresses + select: no branch, no wait per load); the fragments of step
     // k0 + 4 are requested before the MFMAs of step k0 are issued
     auto loadab = [&](int k0, cplx (&a_)[2], cplx (&b_)[2]) {
@@ -237,14 +258,25 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
     for (int k0 = 0; k0 < K; k0 += 4) {
         cplx an[2], bn[2];
         loadab(k0 + 4, an, bn);                  // past the end: clamped address, masked to zero, never used
+        double asum[2], bsum[2];
+        if (M3) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { asum[a] = af[a].x + af[a].y; bsum[a] = bf[a].x + bf[a].y; }
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
-                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bf[b].y, af[a].y, acc_re[a][b], 0, 0, 0);
-                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].x, acc_im[a][b], 0, 0, 0);
-                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
+                if (M3) {
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
+                    acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].y, acc_p2[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+                } else {
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bf[b].y, af[a].y, acc_re[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].x, acc_im[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
+                }
             }
 #pragma unroll
         for (int a = 0; a < 2; ++a) { af[a] = an[a]; bf[a] = bn[a]; }
@@ -265,16 +297,25 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gj = j0 + b * 16 + l4 + 4 * r;
-                if (gi < n && gj < n) G[(size_t)gj * ldc + gi] = make_double2(c[r].x + acc_re[a][b][r], c[r].y + acc_im[a][b][r]);
+                double re = acc_re[a][b][r], im = acc_im[a][b][r];
+                if (M3) { const double p1 = re, p2 = acc_p2[a][b][r]; re = p1 - p2; im = (im - p1) - p2; }
+                if (gi < n && gj < n) G[(size_t)gj * ldc + gi] = make_double2(c[r].x + re, c[r].y + im);
             }
         }
+}
+
+// developer knob: DQMC_GEMM_4M=1 runs the 4-MFMA complex product (A/B measurements, rounding cross-checks)
+static bool use_4m() {
+    static const bool v = getenv("DQMC_GEMM_4M") && atoi(getenv("DQMC_GEMM_4M")) != 0;
+    return v;
 }
 
 void launch_flush(const Launch& lc, const cplx* X, int ldx, const cplx* Gr, int ldg, cplx* G, int ldc, int n, int Kmax,
                   const int* Kdev, int Kmul) {
     const int tn = (n + 63) / 64;
     const dim3 grid = (lc.nb % 8 == 0) ? dim3(tn * tn * lc.nb, 1, 1) : dim3(tn * tn, 1, lc.nb);
-    hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, lc.st, X, ldx, Gr, ldg, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb);
+    if (use_4m()) hipLaunchKernelGGL(k_flush<false>, grid, dim3(256), 0, lc.st, X, ldx, Gr, ldg, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb);
+    else          hipLaunchKernelGGL(k_flush<true>, grid, dim3(256), 0, lc.st, X, ldx, Gr, ldg, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb);
 }
 
 void launch_gemm(const Launch& lc, const GemmArgs& a) {
@@ -283,10 +324,12 @@ void launch_gemm(const Launch& lc, const GemmArgs& a) {
     if (tiles64 >= 256 && a.N > 32 && a.M > 32) {
         const int t = ((a.M + 63) / 64) * ((a.N + 63) / 64);
         const dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
-        hipLaunchKernelGGL((k_zgemm<2, 2>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        if (use_4m()) hipLaunchKernelGGL((k_zgemm<2, 2, false>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        else          hipLaunchKernelGGL((k_zgemm<2, 2, true>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
     } else {
         const int t = ((a.M + 31) / 32) * ((a.N + 31) / 32);
         const dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
-        hipLaunchKernelGGL((k_zgemm<1, 1>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        if (use_4m()) hipLaunchKernelGGL((k_zgemm<1, 1, false>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        else          hipLaunchKernelGGL((k_zgemm<1, 1, true>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
     }
 }
