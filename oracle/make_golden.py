@@ -85,6 +85,13 @@ CASES = {
     # one FULL Green's function at the headline size (closes the gap the sub-sampled checksums leave)
     "o2_L16_b10_fullG": dict(args=dict(opdim=2, L=16, beta=10, s=10, delaySteps=16, sweeps=1, sliceTrace=0, setupOnly=1),
                              keep=("sweep1_g", "sweep1_phi", "init_phi", "meta"), hash_fields=True),
+    # BASELINE config 1: the half-filled Hubbard model (src/dethubbard.cpp), plus checkerboard propagator, s not dividing m,
+    # a larger lattice away from half filling
+    "hub_L4": dict(harness="hubbard", args=dict(L=4, d=2, beta=2, dtau=0.1, s=10, t=1, U=4, mu=0, checkerboard=0, sweeps=4, measureSweeps=2)),
+    "hub_L4_cb": dict(harness="hubbard", args=dict(L=4, d=2, beta=2, dtau=0.1, s=10, t=1, U=4, mu=0, checkerboard=1, sweeps=3, measureSweeps=1)),
+    "hub_L4_s7": dict(harness="hubbard", args=dict(L=4, d=2, beta=2.3, dtau=0.1, s=7, t=1, U=2.5, mu=-0.2, checkerboard=0, sweeps=3, measureSweeps=1,
+                                                   rngSeed=777, simindex=2)),
+    "hub_L6": dict(harness="hubbard", args=dict(L=6, d=2, beta=3, dtau=0.1, s=10, t=1, U=6, mu=0.3, checkerboard=0, sweeps=2, measureSweeps=1)),
     # BASELINE config 3 (headline): checksums / subsamples only
     "o2_L16_b10": dict(args=dict(opdim=2, L=16, beta=10, s=10, delaySteps=16, sweeps=2, sliceTrace=0),
                        drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi"),
@@ -95,8 +102,10 @@ CASES = {
 def run_case(name, spec):
     opdim = spec["args"].get("opdim", 2)
     exe = os.path.join(REFDIR, f"ref_harness_o{opdim}")
+    if spec.get("harness") == "hubbard":
+        exe = os.path.join(REFDIR, "ref_harness_hubbard")
     if not os.path.exists(exe):
-        raise SystemExit(f"{exe} missing: run `make -C oracle/ref_build OPDIM={opdim}` first")
+        raise SystemExit(f"{exe} missing: run `make -C oracle/ref_build OPDIM={opdim}` (or `hubbard`) first")
     with tempfile.TemporaryDirectory() as td:
         cmd = [exe, td] + [f"{k}={v}" for k, v in spec["args"].items()]
         env = dict(os.environ, MKL_NUM_THREADS=str(spec.get("threads", 1)))

@@ -222,3 +222,44 @@ def test_cold_and_large_o3_cases(name):
     assert np.array_equal(o.phi[1:], phi_ref[1:])
     assert relerr(o.g[::4, ::4], g["sweep1_g_sub4"]) < TOL
     assert relerr(o.g_inv_sv, g["sweep1_g_inv_sv"]) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# Hubbard replica (BASELINE config 1): oracle/dethubbard_oracle.py against the real reference
+# ------------------------------------------------------------------------------------------------
+def _hubbard_params(a):
+    from dethubbard_oracle import HubbardParams
+    return HubbardParams(L=int(a["L"]), d=int(a["d"]), beta=float(a["beta"]), dtau=float(a["dtau"]), s=int(a["s"]), t=float(a["t"]),
+                         U=float(a["U"]), mu=float(a["mu"]), checkerboard=bool(int(a["checkerboard"])),
+                         rngSeed=int(a.get("rngSeed", 1020304050)), simindex=int(a.get("simindex", 0)))
+
+
+@pytest.mark.parametrize("name", ["hub_L4", "hub_L4_cb", "hub_L4_s7", "hub_L6"])
+def test_hubbard_oracle_vs_reference(name):
+    from dethubbard_oracle import DetHubbardOracle
+    g = load_golden(name)
+    o = DetHubbardOracle(_hubbard_params(g["params"]))
+    assert (o.N, o.m, o.s, o.n) == tuple(int(x) for x in g["meta"][1:5]) and abs(o.alpha - g["meta"][5]) < 1e-15
+    assert relerr(o.proptmat, g["proptmat"]) < 1e-13
+    assert np.array_equal(o.auxfield[:, 1:], g["init_auxfield"][:, 1:])
+    assert relerr(o.g[0], g["init_gUp"]) < 1e-10 and relerr(o.g[1], g["init_gDn"]) < 1e-10
+    assert relerr(o.computeBmat(3, 2, o.UP), g["bmat_up_k3"]) < 1e-13
+    assert relerr(o.computeBmat(min(o.s, o.m), 0, o.DN), g["bmat_dn_chain"]) < 1e-12
+    assert relerr(np.column_stack([st.d for st in o.storage[0]]), g["init_udv_d_up"]) < 1e-10
+    i = 1
+    while f"sweep{i}_auxfield" in g:
+        o.sweepThermalization()
+        assert np.array_equal(o.auxfield[:, 1:], g[f"sweep{i}_auxfield"][:, 1:]), f"sweep {i}: auxiliary field trajectory diverged"
+        assert relerr(o.g[0], g[f"sweep{i}_gUp"]) < 1e-10 and relerr(o.g[1], g[f"sweep{i}_gDn"]) < 1e-10
+        i += 1
+    i = 1
+    while f"meas{i}_auxfield" in g:
+        o.sweep(True)
+        assert np.array_equal(o.auxfield[:, 1:], g[f"meas{i}_auxfield"][:, 1:])
+        got = [o.obs[k] for k in ("occUp", "occDn", "occTotal", "occDouble", "localMoment", "eKinetic", "ePotential", "eTotal")]
+        assert np.allclose(got, g[f"meas{i}_obs"], rtol=1e-10, atol=1e-12)
+        assert np.max(np.abs(o.zcorr - g[f"meas{i}_zcorr"])) < 1e-8        # sums of products of G entries: absolute, at the scale of G
+        i += 1
+    assert np.array_equal([o.rng.rand01() for _ in range(4)], g["rng_next"])
+    if name == "hub_L4":        # known answer: half filling at mu = 0
+        assert abs(o.obs["occTotal"] - 1.0) < 1e-9
