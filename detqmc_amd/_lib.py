@@ -26,7 +26,7 @@ class dqmc_params(C.Structure):
     _fields_ = [("opdim", C.c_int32), ("L", C.c_int32), ("m", C.c_int32), ("s", C.c_int32),
                 ("delaySteps", C.c_int32), ("bc", C.c_int32), ("weakZflux", C.c_int32),
                 ("phi2bosons", C.c_int32), ("device", C.c_int32), ("stabilisation", C.c_int32),
-                ("cb_none", C.c_int32), ("reserved", C.c_int32),
+                ("cb_none", C.c_int32), ("model", C.c_int32),
                 ("dtau", C.c_double), ("r", C.c_double), ("c", C.c_double), ("u", C.c_double),
                 ("lambda_", C.c_double),
                 ("txhor", C.c_double), ("txver", C.c_double), ("tyhor", C.c_double), ("tyver", C.c_double),
@@ -97,6 +97,26 @@ class detsdw_control_data(C.Structure):
 # every symbol include/*.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
+class dethubbard_params(C.Structure):
+    _fields_ = [("L", C.c_int32), ("d", C.c_int32), ("m", C.c_int32), ("s", C.c_int32), ("checkerboard", C.c_int32),
+                ("device", C.c_int32), ("simindex", C.c_int32), ("rngSeed", C.c_uint32), ("stabilisation", C.c_int32),
+                ("reserved", C.c_int32), ("beta", C.c_double), ("dtau", C.c_double), ("t", C.c_double), ("U", C.c_double),
+                ("mu", C.c_double)]
+
+
+class dethubbard_observables(C.Structure):
+    _fields_ = [("occUp", C.c_double), ("occDn", C.c_double), ("occTotal", C.c_double), ("occDouble", C.c_double),
+                ("localMoment", C.c_double), ("eKinetic", C.c_double), ("ePotential", C.c_double), ("eTotal", C.c_double),
+                ("valid", C.c_int32), ("reserved", C.c_int32)]
+
+
+class dethubbard_info(C.Structure):
+    _fields_ = [("L", C.c_int32), ("N", C.c_int32), ("m", C.c_int32), ("s", C.c_int32), ("n", C.c_int32),
+                ("performedSweeps", C.c_int32), ("lastSweepDir", C.c_int32), ("currentTimeslice", C.c_int32),
+                ("beta", C.c_double), ("dtau", C.c_double), ("alpha", C.c_double), ("lastAccRatio", C.c_double),
+                ("rngDrawn", C.c_uint64)]
+
+
 SYMBOLS = [
     ("dqmc_create", C.c_int, [C.POINTER(dqmc_params), C.POINTER(_P)]),
     ("dqmc_create_batch", C.c_int, [C.POINTER(dqmc_params), C.c_int, C.POINTER(_P)]),
@@ -171,6 +191,19 @@ SYMBOLS = [
     ("detsdw_set_control_data", C.c_int, [_P, C.POINTER(detsdw_control_data)]),
     ("detsdw_replica_exchange_probability", C.c_double, [C.c_double] * 4),
     ("detsdw_rng_fill", C.c_int, [C.c_uint32, C.c_uint32, _DP, C.c_size_t]),
+    ("dethubbard_create", C.c_int, [C.POINTER(dethubbard_params), C.c_int, C.POINTER(_P)]),
+    ("dethubbard_destroy", None, [_P]),
+    ("dethubbard_last_error", C.c_char_p, []),
+    ("dethubbard_select_chain", C.c_int, [_P, C.c_int]),
+    ("dethubbard_sweep", C.c_int, [_P, C.c_int]),
+    ("dethubbard_sweep_thermalization", C.c_int, [_P]),
+    ("dethubbard_get_info", C.c_int, [_P, C.POINTER(dethubbard_info)]),
+    ("dethubbard_get_auxfield", C.c_int, [_P, _DP]),
+    ("dethubbard_get_green", C.c_int, [_P, _DP, _DP]),
+    ("dethubbard_get_observables", C.c_int, [_P, C.POINTER(dethubbard_observables)]),
+    ("dethubbard_get_zcorr", C.c_int, [_P, _DP]),
+    ("dethubbard_rng_rand01", C.c_double, [_P]),
+    ("dethubbard_ctx", _P, [_P]),
 ]
 
 _lib = None
@@ -196,5 +229,5 @@ def load():
 def check(rc, host=False):
     if rc != 0:
         lib = load()
-        msg = (lib.detsdw_last_error() if host else lib.dqmc_last_error()) or b""
+        msg = (lib.dethubbard_last_error() if host == "hubbard" else lib.detsdw_last_error() if host else lib.dqmc_last_error()) or b""
         raise DqmcError(rc, msg.decode("utf-8", "replace"))

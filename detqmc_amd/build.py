@@ -21,9 +21,11 @@ SOURCES = [
     "kernels_update.hip",
     "kernels_qr.hip",
     "kernels_measure.hip",
+    "kernels_hubbard.hip",
     "dqmc_context.hip",
     os.path.join("host", "dsfmt19937.cpp"),
     os.path.join("host", "detsdw.cpp"),
+    os.path.join("host", "dethubbard.cpp"),
 ]
 
 
@@ -38,7 +40,9 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "dqmc_internal.h"), os.path.join(CSRC, "host", "detsdw.h"),
                os.path.join(CSRC, "host", "dsfmt19937.h"),
-               os.path.join(HERE, "..", "include", "dqmc_hip.h"), os.path.join(HERE, "..", "include", "detsdw_host.h")]
+               os.path.join(CSRC, "host", "dethubbard.h"),
+               os.path.join(HERE, "..", "include", "dqmc_hip.h"), os.path.join(HERE, "..", "include", "detsdw_host.h"),
+               os.path.join(HERE, "..", "include", "dethubbard_host.h")]
     hdr_time = max(os.path.getmtime(h) for h in headers)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
     objs = []

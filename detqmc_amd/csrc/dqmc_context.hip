@@ -53,6 +53,7 @@ struct dqmc_ctx {
     double* macc = nullptr;                                   // fermionic measurement accumulators (kernels_measure.hip)
     size_t macc_n = 0;
     SvdWork sw{};
+    double hub_e_m2a = 1.0, hub_e_p2a = 1.0;  // Hubbard: exp(-+2 alpha) of weightRatioSingleFlip (dethubbard.cpp:866-867)
     int stab = 0;                       // DQMC_STAB_SVD / DQMC_STAB_QR
     QrWork qw{};
     int* qr_perm = nullptr;
@@ -363,6 +364,55 @@ static void build_dense_propK(const dqmc_params& p, const std::vector<int>& neig
     }
 }
 
+// Hubbard replica: blockdiag(P, P) and blockdiag(P^-1, P^-1), P = proptmat.
+//   direct (checkerboard = false): tmat = -mu 1 - t sum_<ij>, P = e^{-dtau tmat} by diagonalisation (setupPropTmat_direct,
+//     dethubbard.cpp:702-714 + computePropagator, detmodel.cpp:25-33), P^-1 = e^{+dtau tmat};
+//   checkerboard (dos Santos 2003, setupPropTmat_checkerboard :717-770): the ordered product
+//     (ch + sh kxa)(ch + sh kxb)(ch + sh kya)(ch + sh kyb), ch = cosh(dtau t), sh = sinh(dtau t), without a chemical
+//     potential -- the reference writes the same product expanded into its 16 terms; P^-1 = reversed order, sh -> -sh.
+// The reference inverts B numerically (arma::inv, dethubbard.h:318-337); the exact inverse agrees to rounding.
+static void build_hubbard_propK(const dqmc_params& p, const std::vector<int>& neigh, std::vector<hc>& out_minus, std::vector<hc>& out_plus) {
+    const int L = p.L, N = L * L, ng = 2 * N;
+    const double t = p.txhor, mu = p.mux;
+    std::vector<hc> Em, Ep;
+    if (p.cb_none) {
+        std::vector<hc> T((size_t)N * N, hc(0.0));
+        for (int i = 0; i < N; ++i) T[(size_t)i * N + i] = -mu;
+        for (int site = 0; site < N; ++site)
+            for (int dir = 0; dir < 4; ++dir) T[(size_t)neigh[dir * N + site] * N + site] -= t;
+        herm_exp_dense(N, T, -p.dtau, +p.dtau, Em, Ep);
+    } else {
+        const double ch = std::cosh(p.dtau * t), sh = std::sinh(p.dtau * t);
+        auto bond_matrix = [&](int dirn, int parity, double shv) {          // ch 1 + shv k, k = bonds (a, a + dir) from sub-board `parity`
+            std::vector<double> M((size_t)N * N, 0.0);
+            for (int i = 0; i < N; ++i) M[(size_t)i * N + i] = ch;
+            for (int y = 0; y < L; ++y)
+                for (int x = 0; x < L; ++x) {
+                    const int coord = dirn == 0 ? x : y;
+                    if ((coord & 1) != parity) continue;
+                    const int a = y * L + x, b = neigh[(dirn == 0 ? 0 : 2) * N + a];
+                    M[(size_t)a * N + b] += shv; M[(size_t)b * N + a] += shv;
+                }
+            return M;
+        };
+        auto mul = [&](const std::vector<double>& A, const std::vector<double>& B) {
+            std::vector<double> C((size_t)N * N, 0.0);
+            for (int i = 0; i < N; ++i) for (int k = 0; k < N; ++k) { const double a = A[(size_t)i * N + k]; if (a != 0.0) for (int j = 0; j < N; ++j) C[(size_t)i * N + j] += a * B[(size_t)k * N + j]; }
+            return C;
+        };
+        const std::vector<double> F = mul(mul(bond_matrix(0, 0, sh), bond_matrix(0, 1, sh)), mul(bond_matrix(1, 0, sh), bond_matrix(1, 1, sh)));
+        const std::vector<double> Fi = mul(mul(bond_matrix(1, 1, -sh), bond_matrix(1, 0, -sh)), mul(bond_matrix(0, 1, -sh), bond_matrix(0, 0, -sh)));
+        Em.assign((size_t)N * N, hc(0.0)); Ep.assign((size_t)N * N, hc(0.0));
+        for (size_t i = 0; i < (size_t)N * N; ++i) { Em[i] = F[i]; Ep[i] = Fi[i]; }
+    }
+    out_minus.assign((size_t)ng * ng, hc(0.0)); out_plus.assign((size_t)ng * ng, hc(0.0));
+    for (int b = 0; b < 2; ++b)
+        for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) {
+            out_minus[(size_t)(b * N + j) * ng + (b * N + i)] = Em[(size_t)i * N + j];
+            out_plus[(size_t)(b * N + j) * ng + (b * N + i)] = Ep[(size_t)i * N + j];
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // lifetime
 // ---------------------------------------------------------------------------------------------
@@ -394,6 +444,12 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     if (p->bc < 0 || p->bc > 3) return fail(DQMC_EINVAL, "bc");
     if (p->stabilisation != DQMC_STAB_SVD && p->stabilisation != DQMC_STAB_QR) return fail(DQMC_EINVAL, "stabilisation");
     if (!(p->dtau > 0)) return fail(DQMC_EINVAL, "dtau");
+    if (p->model != DQMC_MODEL_SDW && p->model != DQMC_MODEL_HUBBARD) return fail(DQMC_EINVAL, "model");
+    if (p->model == DQMC_MODEL_HUBBARD) {
+        if (p->opdim != 1 || p->weakZflux || p->bc != DQMC_BC_PBC || p->delaySteps != 1)
+            return fail(DQMC_EINVAL, "Hubbard replica: opdim must be 1, delaySteps 1, bc pbc, no flux");   // dethubbardparams.cpp:41-43
+        if (!(p->u >= 0)) return fail(DQMC_EINVAL, "Hubbard replica: U must be >= 0 (alpha = acosh(e^{dtau U / 2}))");
+    }
     const int ng = MSF * N;
     if (p->stabilisation == DQMC_STAB_SVD && ng > 2304) return fail(DQMC_EINVAL, "n_g > 2304 not supported by the Jacobi kernel instantiations");
     if (ng > 4096) return fail(DQMC_EINVAL, "n_g > 4096 not supported by the QR panel kernel instantiations");
@@ -452,7 +508,19 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     HIPCHK(copy_sync(c, d_pabcd_h, pabcd_h.data(), pabcd_h.size() * sizeof(double), hipMemcpyHostToDevice));
     hm.psites = d_psites; hm.neigh = d_neigh; hm.pmats = d_pmats; hm.pabcd = d_pabcd; hm.pm_real = p->weakZflux ? 0 : 1;
     hm.pmats_h = d_pmats_h; hm.pabcd_h = d_pabcd_h;
-    if (p->cb_none) {
+    if (p->model == DQMC_MODEL_HUBBARD) {
+        hm.hubbard = 1; hm.dense = 1;
+        hm.ov[0] = hm.ov[1] = hm.ovinv[0] = hm.ovinv[1] = 1.0;
+        const double alpha = std::acosh(std::exp(p->dtau * p->u * 0.5));              // dethubbard.cpp:55
+        hm.hub_exp_alpha[0] = std::exp(alpha); hm.hub_exp_alpha[1] = std::exp(-alpha);
+        c->hub_e_m2a = std::exp(-2.0 * alpha * 1.0); c->hub_e_p2a = std::exp(2.0 * alpha * 1.0);
+        std::vector<hc> em, ep;
+        build_hubbard_propK(*p, neigh, em, ep);
+        const size_t nn = (size_t)ng * ng;
+        A_(salloc(c, &c->propK[0], nn)); A_(salloc(c, &c->propK[1], nn)); A_(dalloc(c, &c->Tdense, nn));
+        HIPCHK(copy_sync(c, c->propK[0], em.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(c, c->propK[1], ep.data(), nn * sizeof(hc), hipMemcpyHostToDevice));
+    } else if (p->cb_none) {
         hm.dense = 1;
         hm.ov[0] = hm.ov[1] = hm.ovinv[0] = hm.ovinv[1] = 1.0;     // mu is part of K in setupPropK
         std::vector<hc> em, ep;
@@ -636,7 +704,11 @@ static void bmult_dev(dqmc_ctx* c, int side, int inverse, int k2, int k1, cplx* 
             launch_copy(c->lc, c->Tdense, A, n2);
         };
         if (hop_first) hop();
-        { ProfScope ps(c, FAM_BMULT, 1); launch_bmult(c->lc, nullptr, c->hm, side, inverse, k, kstep, 1, A, c->n_g); }
+        {
+            ProfScope ps(c, FAM_BMULT, 1);
+            if (c->hm.hubbard) launch_hubbard_vscale(c->lc, c->hm, side, inverse, k, A, c->n_g);     // diag(e^{+-alpha s_k}) per spin block
+            else launch_bmult(c->lc, nullptr, c->hm, side, inverse, k, kstep, 1, A, c->n_g);
+        }
         if (!hop_first) hop();
     }
 }
@@ -974,6 +1046,12 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     (void)hipSetDevice(c->p.device);
     if (k < 1 || k > c->m) return fail(DQMC_EINVAL, "updateInSlice: k out of range");
     if (c->currentTimeslice != k) return fail(DQMC_EINVAL, "updateInSlice: currentTimeslice != k");
+    if (c->hm.hubbard) {            // DetHubbard::updateInSlice (dethubbard.cpp:141-172): the whole slice in one launch
+        ProfScope ps(c, FAM_UPDATE, 1);
+        launch_hubbard_slice(c->lc, c->hm, c->us, c->uniforms, c->G, k, c->hub_e_m2a, c->hub_e_p2a);
+        HIPCHK(hipGetLastError());
+        return DQMC_OK;
+    }
     const int rounds = (c->N + c->D - 1) / c->D;
     const int WD = c->MSF * c->D;
     for (int r = 0; r < rounds; ++r) {
@@ -1166,6 +1244,7 @@ static void shift_green_dev(dqmc_ctx* c) {
 }
 extern "C" int dqmc_shift_green_symmetric_host(dqmc_ctx* c, dqmc_cplx* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    if (c->hm.hubbard) return fail(DQMC_EINVAL, "shiftGreenSymmetric belongs to the SDW model");
     (void)hipSetDevice(c->p.device);
     shift_green_dev(c);
     HIPCHK(hipStreamSynchronize(c->st));
@@ -1182,6 +1261,12 @@ extern "C" int dqmc_measure_reset(dqmc_ctx* c) {
 extern "C" int dqmc_measure_slice(dqmc_ctx* c) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
     (void)hipSetDevice(c->p.device);
+    if (c->hm.hubbard) {            // DetHubbard::measure (dethubbard.cpp:521-545): accumulator layout in kernels_hubbard.hip
+        ProfScope ps(c, FAM_OTHER, 1);
+        launch_hubbard_measure(c->lc, c->hm, c->G, c->macc);
+        HIPCHK(hipGetLastError());
+        return DQMC_OK;
+    }
     shift_green_dev(c);
     { ProfScope ps(c, FAM_OTHER, 1); launch_measure_accum(c->lc, c->hm, c->T1, c->macc); }
     HIPCHK(hipGetLastError());

@@ -67,6 +67,10 @@ struct DevModel {
     double* coshT;     // [m+1][N]
     double* sinhT;     // [m+1][N]
     const int* neigh;  // [4][N]  XPLUS, XMINUS, YPLUS, YMINUS (neighbortable.h:34-36)
+    // Hubbard replica (dqmc_params::model == DQMC_MODEL_HUBBARD): phi holds the Ising auxiliary field (+-1.0, opdim = 1),
+    // the hopping part is the dense propagator (dense = 1), the site-diagonal part is e^{+-alpha s} (kernels_hubbard.hip)
+    int hubbard;
+    double hub_exp_alpha[2];   // e^{+alpha}, e^{-alpha}, cosh(alpha) = e^{dtau U / 2} (dethubbard.cpp:55)
 };
 __device__ __forceinline__ DevModel chain_model(DevModel dm, size_t cs) {
     dm.phi = chain_ptr(dm.phi, cs); dm.coshT = chain_ptr(dm.coshT, cs); dm.sinhT = chain_ptr(dm.sinhT, cs);
@@ -137,6 +141,12 @@ void launch_update_decide(const Launch& lc, const DevModel* dm, const DevModel& 
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal);
 void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,
                           const cplx* W, cplx* X, cplx* Gr);
+
+// Hubbard replica (kernels_hubbard.hip)
+void launch_hubbard_vscale(const Launch& lc, const DevModel& hm, int side, int inverse, int k, cplx* A, int lda);
+void launch_hubbard_slice(const Launch& lc, const DevModel& hm, DevUpdateState* us, const double* uniforms, cplx* G, int k,
+                          double e_m2a, double e_p2a);
+void launch_hubbard_measure(const Launch& lc, const DevModel& hm, const cplx* G, double* acc);
 
 // misc elementwise
 void launch_cosh_sinh(const Launch& lc, const DevModel& hm);

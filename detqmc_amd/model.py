@@ -489,3 +489,97 @@ class DetSDWBatch:
             self.close()
         except Exception:
             pass
+
+
+@dataclass
+class HubbardParams:
+    """ModelParams<DetHubbard> (reference src/dethubbardparams.h:28-50)"""
+    L: int = 4
+    d: int = 2
+    beta: float = 0.0
+    m: int = 0
+    dtau: float = 0.1
+    s: int = 10
+    t: float = 1.0
+    U: float = 4.0
+    mu: float = 0.0
+    checkerboard: bool = False
+    rngSeed: int = 1020304050
+    simindex: int = 0
+    device: int = 0
+    stabilisation: str = "svd"
+
+
+class DetHubbard:
+    """The Hubbard replica of BASELINE config 1 (C++ host layer detqmc_amd/csrc/host/dethubbard.cpp): the reference's
+    DetHubbard (src/dethubbard.{h,cpp}) with both spin sectors in one block-diagonal Green's function on the GPU.
+    nchains > 1: independent replicas (simindex, simindex + 1, ...) in lockstep; `select(b)` picks the one the getters
+    talk to."""
+
+    def __init__(self, pars: HubbardParams, nchains=1):
+        self.lib = load()
+        self.pars = pars
+        p = _lib.dethubbard_params(L=pars.L, d=pars.d, m=pars.m, s=pars.s, checkerboard=int(pars.checkerboard), device=pars.device,
+                                   simindex=pars.simindex, rngSeed=pars.rngSeed, stabilisation=STABILISATION[pars.stabilisation],
+                                   beta=pars.beta, dtau=pars.dtau, t=pars.t, U=pars.U, mu=pars.mu)
+        h = C.c_void_p()
+        check(self.lib.dethubbard_create(C.byref(p), nchains, C.byref(h)), host="hubbard")
+        self.h = h
+        self.nchains = nchains
+
+    def close(self):
+        if self.h:
+            self.lib.dethubbard_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def select(self, b):
+        check(self.lib.dethubbard_select_chain(self.h, b), host="hubbard")
+
+    def sweep(self, takeMeasurements=False):
+        check(self.lib.dethubbard_sweep(self.h, int(takeMeasurements)), host="hubbard")
+
+    def sweepThermalization(self):
+        check(self.lib.dethubbard_sweep_thermalization(self.h), host="hubbard")
+
+    @property
+    def info(self):
+        i = _lib.dethubbard_info()
+        check(self.lib.dethubbard_get_info(self.h, C.byref(i)), host="hubbard")
+        return i
+
+    @property
+    def auxfield(self):
+        """(N, m+1) like the reference's MatInt auxfield, as +-1.0 (column 0 unused)"""
+        i = self.info
+        a = np.zeros((i.N, i.m + 1), order="F")
+        check(self.lib.dethubbard_get_auxfield(self.h, a.ctypes.data_as(_lib._DP)), host="hubbard")
+        return a
+
+    @property
+    def green(self):
+        """(gUp, gDn), N x N each"""
+        n = self.info.N
+        gu, gd = np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
+        check(self.lib.dethubbard_get_green(self.h, gu.ctypes.data_as(_lib._DP), gd.ctypes.data_as(_lib._DP)), host="hubbard")
+        return gu, gd
+
+    @property
+    def observables(self):
+        o = _lib.dethubbard_observables()
+        check(self.lib.dethubbard_get_observables(self.h, C.byref(o)), host="hubbard")
+        return o
+
+    @property
+    def zcorr(self):
+        out = np.zeros(self.info.N)
+        check(self.lib.dethubbard_get_zcorr(self.h, out.ctypes.data_as(_lib._DP)), host="hubbard")
+        return out
+
+    def rand01(self):
+        return self.lib.dethubbard_rng_rand01(self.h)

@@ -1,0 +1,71 @@
+/*
+ * dethubbard_host.h -- C API of the Hubbard replica (BASELINE config 1): the build's DetHubbard
+ * (reference src/dethubbard.{h,cpp}: DetModelGC<2, double, false>, discrete Hubbard-Stratonovich field, single
+ * spin-flip updates with rank-1 Sherman-Morrison Green's-function updates) on top of the kernel ABI (dqmc_hip.h,
+ * dqmc_params::model = DQMC_MODEL_HUBBARD).  Same layering as detsdw_host.h: the C++ host class
+ * (detqmc_amd/csrc/host/dethubbard.{h,cpp}) owns the RNG stream and the control flow of sweep_skeleton / sweepUp /
+ * sweepDown (src/detmodel.h:1266-1478) and calls ONLY the kernel ABI.
+ */
+#ifndef DETHUBBARD_HOST_H_
+#define DETHUBBARD_HOST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include "dqmc_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dethubbard_replica dethubbard_replica;
+
+/* ModelParams<DetHubbard> (src/dethubbardparams.h:28-50) + rngSeed / simindex of DetQMCParams */
+typedef struct dethubbard_params {
+    int32_t L;                   /* linear size; d = 2 (the only dimension this build supports) */
+    int32_t d;
+    int32_t m;                   /* give m > 0 OR beta > 0 (src/detmodelparams.h:97-110) */
+    int32_t s;
+    int32_t checkerboard;        /* 0: e^{-dtau T} by diagonalisation; 1: checkerboard product form (no chemical potential) */
+    int32_t device;
+    int32_t simindex;
+    uint32_t rngSeed;
+    int32_t stabilisation;       /* DQMC_STAB_SVD (as the reference) or DQMC_STAB_QR */
+    int32_t reserved;
+    double beta, dtau;
+    double t, U, mu;
+} dethubbard_params;
+
+/* obsScalar of DetHubbard (src/dethubbard.cpp:85-93), valid after dethubbard_sweep(r, 1) */
+typedef struct dethubbard_observables {
+    double occUp, occDn, occTotal, occDouble, localMoment, eKinetic, ePotential, eTotal;
+    int32_t valid, reserved;
+} dethubbard_observables;
+
+typedef struct dethubbard_info {
+    int32_t L, N, m, s, n, performedSweeps, lastSweepDir, currentTimeslice;
+    double beta, dtau, alpha, lastAccRatio;
+    uint64_t rngDrawn;
+} dethubbard_info;
+
+/* createReplica (src/dethubbard.cpp:37-47) + ctor (:49-118): parameter checks, random auxiliary field, propagator,
+ * UdV storage and G(beta).  nchains independent replicas (simindex, simindex + 1, ...) advance in lockstep. */
+int dethubbard_create(const dethubbard_params* p, int nchains, dethubbard_replica** out);
+void dethubbard_destroy(dethubbard_replica* r);
+const char* dethubbard_last_error(void);
+int dethubbard_select_chain(dethubbard_replica* r, int chain);
+/* DetHubbard::sweep / sweepThermalization (src/dethubbard.cpp:921-945) */
+int dethubbard_sweep(dethubbard_replica* r, int takeMeasurements);
+int dethubbard_sweep_thermalization(dethubbard_replica* r);
+int dethubbard_get_info(dethubbard_replica* r, dethubbard_info* out);
+/* auxfield(N, m + 1) column-major as doubles +-1 (column 0 unused), gUp / gDn N x N column-major */
+int dethubbard_get_auxfield(dethubbard_replica* r, double* out);
+int dethubbard_get_green(dethubbard_replica* r, double* gUp, double* gDn);
+int dethubbard_get_observables(dethubbard_replica* r, dethubbard_observables* out);
+int dethubbard_get_zcorr(dethubbard_replica* r, double* out /* [N] */);
+double dethubbard_rng_rand01(dethubbard_replica* r);
+dqmc_ctx* dethubbard_ctx(dethubbard_replica* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETHUBBARD_HOST_H_ */

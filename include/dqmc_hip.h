@@ -49,6 +49,7 @@ enum { DQMC_BC_PBC = 0, DQMC_BC_APBC_X = 1, DQMC_BC_APBC_Y = 2, DQMC_BC_APBC_XY 
 enum { DQMC_LEFT = 0, DQMC_RIGHT = 1 };
 enum { DQMC_UP = +1, DQMC_DOWN = -1 };
 enum { DQMC_STAB_SVD = 0, DQMC_STAB_QR = 1 };
+enum { DQMC_MODEL_SDW = 0, DQMC_MODEL_HUBBARD = 1 };
 
 /* ModelParamsDetSDW fields the kernels depend on (src/detsdwparams.h:24-120) */
 typedef struct dqmc_params {
@@ -64,7 +65,11 @@ typedef struct dqmc_params {
     int32_t stabilisation; /* DQMC_STAB_SVD (reference-exact UdV = SVD) or DQMC_STAB_QR (pre-pivoted Householder UDT) */
     int32_t cb_none;      /* 0: checkerboard break-up CB_ASSAAD_BERG (every shipped config); 1: checkerboard=false,
                              dense B_k = e^{-dtau V_k} e^{-dtau K} (computeBmatSDW, detsdwopdim.cpp:1309-1485) */
-    int32_t reserved;
+    int32_t model;        /* DQMC_MODEL_SDW (default) or DQMC_MODEL_HUBBARD: the reference's DetHubbard (src/dethubbard.{h,cpp}), both
+                             spin sectors in one block-diagonal 2N x 2N matrix.  Hubbard reads: L, m, s, dtau, txhor = t, u = U,
+                             mux = mu, cb_none = !checkerboard (propagator e^{-dtau T} by diagonalisation, or the checkerboard
+                             product form of dethubbard.cpp:717-770), stabilisation, device; opdim must be 1 (the field is the
+                             Ising auxiliary field, phi = +-1), delaySteps 1 */
     double dtau, r, c, u, lambda;
     double txhor, txver, tyhor, tyver;
     double mux, muy;

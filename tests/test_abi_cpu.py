@@ -23,13 +23,13 @@ def lib():
 def _declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:dqmc|detsdw)_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:dqmc|detsdw|dethubbard)_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
     from detqmc_amd._lib import SYMBOLS
     bound = {s[0] for s in SYMBOLS}
-    for hdr in ("dqmc_hip.h", "detsdw_host.h"):
+    for hdr in ("dqmc_hip.h", "detsdw_host.h", "dethubbard_host.h"):
         names = _declared(hdr)
         assert len(names) > 10
         for nm in names:
