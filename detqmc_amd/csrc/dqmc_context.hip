@@ -568,6 +568,8 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
         c->sw.rounds = d_rounds; c->sw.nrounds = nblk - 1; c->sw.nblk = nblk;
     }
     c->stab = p->stabilisation;
+    // test hook: a sweep budget the Jacobi SVD cannot meet makes the "SVD failed" path (udv.h:77-88 in the reference) reachable
+    if (getenv("DQMC_MAX_JACOBI_SWEEPS")) c->max_jacobi_sweeps = atoi(getenv("DQMC_MAX_JACOBI_SWEEPS"));
     if (c->stab == DQMC_STAB_QR) {
         const int np = (ng + 15) / 16;
         A_(dalloc(c, &c->qw.V, n2)); A_(dalloc(c, &c->qw.T, (size_t)np * 2 * 256));

@@ -281,8 +281,9 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
 #pragma unroll
         for (int a = 0; a < 2; ++a) { af[a] = an[a]; bf[a] = bn[a]; }
     }
-    // The tile of G is read only now, 16 x 16 at a time: holding it across the MFMA loop costs 64 VGPRs, i.e. the
-    // second workgroup per CU whose loads would overlap this one's MFMAs (scripts/micro/flush_tiles.hip: 75 -> 55 us).
+    // The tile of G is read only now, 16 x 16 at a time: holding it across the MFMA loop costs 64 VGPRs, i.e. resident
+    // workgroups per CU (3 at 143 VGPRs) whose loads overlap this one's MFMAs (scripts/micro/flush_tiles.hip: 75 -> 55 us;
+    // re-measured in round 2 with the 3M product: requesting the tile before the loop 197 -> 212 ms per 128-chain sweep).
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll

@@ -1092,3 +1092,25 @@ def test_replica_exchange_across_two_processes_with_real_chains(tmp_path):
     assert moved, "ladder too steep for any swap"
     assert ref["proposed"] == got[0]["proposed"] and ref["accepted"] == got[0]["accepted"]
     assert np.allclose(np.array(ref["routed"]), np.array(got[0]["routed"]), rtol=1e-14, atol=0)
+
+
+def test_decomposition_failure_is_reported_not_swallowed(monkeypatch):
+    """udvDecompose throws "SVD failed" in the reference (src/udv.h:77-88); here the Jacobi SVD reports DQMC_ENOCONV through the
+    C ABI when it cannot converge within its sweep budget (budget forced to 1 through the test hook DQMC_MAX_JACOBI_SWEEPS)."""
+    from detqmc_amd import DqmcError, KernelContext, DetSDW, SDWParams
+    monkeypatch.setenv("DQMC_MAX_JACOBI_SWEEPS", "1")
+    ctx = KernelContext(2, 6, 20, 10, 0.1, delaySteps=4, stabilisation="svd")
+    rng = np.random.default_rng(1)
+    M = rng.standard_normal((ctx.ng, ctx.ng)) + 1j * rng.standard_normal((ctx.ng, ctx.ng))
+    with pytest.raises(DqmcError) as e:
+        ctx.udvDecompose(M)
+    assert e.value.code == -3 and "SVD failed" in str(e.value)
+    ctx.close()
+    with pytest.raises(DqmcError) as e2:           # the host layer turns it into the reference's GeneralError
+        DetSDW(SDWParams(opdim=2, L=6, beta=2.0, s=10, stabilisation="svd"))
+    assert e2.value.code == -3
+    monkeypatch.delenv("DQMC_MAX_JACOBI_SWEEPS")
+    ctx = KernelContext(2, 6, 20, 10, 0.1, delaySteps=4, stabilisation="svd")
+    U, d, Vt, sweeps = ctx.udvDecompose(M)
+    assert sweeps > 1 and relerr((U * d[None, :]) @ Vt.conj().T, M) < 1e-12
+    ctx.close()
