@@ -324,7 +324,10 @@ def rooflines(rawprof, n, m, B, traffic):
             e["latency_bound"] = True
         t = (traffic or {}).get(name)
         if t:
+            # HBM bytes per launch from the PMC passes (their own run of this configuration) and, next to it, that run's
+            # own algorithmic bytes per launch: for the update kernels both depend on the acceptance of the run
             e["traffic"] = t["hbm_bytes_per_launch"]
+            e["traffic_over_algorithmic"] = t.get("traffic_over_algorithmic")
             e["traffic_note"] = t.get("note", "")
         return e
 
@@ -364,8 +367,8 @@ def rooflines(rawprof, n, m, B, traffic):
                        "read-modify-write of G once per delayed-update block and chain that accepted an update (+ the operand "
                        "panels), 8 n_g^2 MSF flop per accepted update on the matrix cores"))
     gms, gl = prof["gemm"]
-    roofs.append(entry("gemm", "k_zgemm<2,2>", gms, gl, 4 * 16.0 * n * n * B * gl, prof["gemm_flops"],
-                       "n_g^3 complex products on v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex step)"))
+    roofs.append(entry("gemm", "k_zgemm<2,2>", gms, gl, 3 * 16.0 * n * n * B * gl, prof["gemm_flops"],
+                       "n_g^3 complex products on v_mfma_f64_16x16x4_f64, 3 real MFMAs per complex step (3M), flops counted as 8 M N K; bytes: A and B read, C written once"))
     roofs.sort(key=lambda r: -r["device_ms"])
     tot_ms = sum(r["device_ms"] for r in roofs)
     tot_b = sum(r["algorithmic_bytes_per_launch"] * r["launches"] for r in roofs if not r.get("latency_bound"))

@@ -15,7 +15,8 @@ import sys
 
 src, B, D, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 FAMILY = [("k_flush", "flush"), ("k_qr_apply_reg", "qr_apply"), ("k_qr_apply", "qr_apply"), ("k_bmult_chain", "bmult"), ("k_update_gather", "gather"),
-          ("k_zgemm", "gemm"), ("k_update_decide", "decide"), ("k_qr_panel", "qr_panel"), ("k_trsm_block", "trsm"), ("k_lu_", "lu")]
+          ("k_zgemm<2, 2", "gemm"), ("k_zgemm<1, 1", "gemm_small"), ("k_update_decide", "decide"), ("k_qr_panel", "qr_panel"), ("k_trsm_block", "trsm"),
+          ("k_udt_init", "udt_init"), ("k_lu_", "lu")]
 
 
 def family(name):
@@ -64,11 +65,36 @@ for fam in sorted(set(fa) | set(wa)):
         e["lds"] = {"bank_conflict_cycles_per_lds_inst": l.get("SQ_LDS_BANK_CONFLICT", 0.0) / l["SQ_INSTS_LDS"],
                     "lds_insts_per_launch": l["SQ_INSTS_LDS"] / max(lc[fam].get("SQ_INSTS_LDS", 1), 1)}
     fams[fam] = e
+# algorithmic bytes per launch of the SAME run (what bench.py's rooflines count), from the counters scripts/probe_batch.py prints
+import re
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+cnt = None
+for name in ("fetch", "write"):
+    try:
+        mo = re.search(r"COUNTERS blocks_nonempty=(\d+) updates_accepted=(\d+) qr_calls=(\d+) chains=(\d+) sweeps_total=(\d+) n_g=(\d+)",
+                       open(os.path.join(src, name + ".log")).read())
+        if mo:
+            cnt = [int(x) for x in mo.groups()]
+            break
+    except OSError:
+        pass
+if cnt:
+    from bench import qr_apply_work
+    blocks, acc, qr_calls, chains, _, n = cnt
+    MSF = 2
+    alg = {"bmult": 2 * 16.0 * n * n * chains, "gemm": 3 * 16.0 * n * n * chains,
+           "flush": (2 * 16.0 * n * n * blocks + 2 * 16.0 * n * MSF * acc) / max(fams.get("flush", {}).get("dispatches", 1), 1),
+           "gather": 4 * 16.0 * n * MSF * acc / max(fams.get("gather", {}).get("dispatches", 1), 1),
+           "qr_apply": qr_apply_work(n)[0] * qr_calls * chains / max(fams.get("qr_apply", {}).get("dispatches", 1), 1)}
+    for fam, a in alg.items():
+        if fam in fams:
+            fams[fam]["algorithmic_bytes_per_launch_same_run"] = a
+            fams[fam]["traffic_over_algorithmic"] = fams[fam]["hbm_bytes_per_launch"] / a
 doc = {"workload": "DetSDW O(2) L=16 beta=10 (n_g=512), ONE context of %d lockstep chains, delaySteps %d, scripts/probe_batch.py 16 10 1 qr %d "
                    "(2 warm-up sweeps + 1 timed sweep, every dispatch counted)" % (B, D, B),
        "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE exact (MI355X_MICROARCH.md, HBM)",
        "families": fams}
 json.dump(doc, open(out, "w"), indent=1)
 for k, v in fams.items():
-    print("%-9s %6d dispatches  %8.1f MB/launch (read %.1f, write %.1f)%s" % (k, v["dispatches"], v["hbm_bytes_per_launch"] / 1e6, v["read_bytes_per_launch"] / 1e6,
-          v["write_bytes_per_launch"] / 1e6, "  wait_any %.2f active %.2f" % (v["sq"]["wait_any_frac"], v["sq"]["active_inst_any_frac"]) if "sq" in v else ""))
+    print("%-10s %6d dispatches  %8.1f MB/launch (read %.1f, write %.1f)%s%s" % (k, v["dispatches"], v["hbm_bytes_per_launch"] / 1e6, v["read_bytes_per_launch"] / 1e6,
+          v["write_bytes_per_launch"] / 1e6, ("  x%.2f of algorithmic" % v["traffic_over_algorithmic"]) if "traffic_over_algorithmic" in v else "", "  wait_any %.2f active %.2f" % (v["sq"]["wait_any_frac"], v["sq"]["active_inst_any_frac"]) if "sq" in v else ""))

@@ -28,4 +28,8 @@ for B in Bs:
     if prof:
         pr = ctx.profile_read()
         print("   ", {k: (round(v[0] / nsw, 1), v[1] // nsw) for k, v in pr.items() if isinstance(v, tuple)}, flush=True)
+    # counters since create (profiling was never switched on in a PMC run): work of the update kernels in THIS run
+    pr = ctx.profile_read()
+    print("COUNTERS blocks_nonempty=%d updates_accepted=%d qr_calls=%d chains=%d sweeps_total=%d n_g=%d" % (
+        pr["blocks_nonempty"], pr["updates_accepted"], pr["qr_calls"], pr["chains"], nsw + 2, batch.chain(0).info.n_g), flush=True)
     batch.close()
