@@ -85,6 +85,13 @@ CASES = {
     # one FULL Green's function at the headline size (closes the gap the sub-sampled checksums leave)
     "o2_L16_b10_fullG": dict(args=dict(opdim=2, L=16, beta=10, s=10, delaySteps=16, sweeps=1, sliceTrace=0, setupOnly=1),
                              keep=("sweep1_g", "sweep1_phi", "init_phi", "meta"), hash_fields=True),
+    # a19: the reference's immediate-update variants (updateInSlice_woodbury / _iterative, src/detsdwopdim.cpp:2493-3019)
+    "o2_L4_woodbury": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, updateMethod="woodbury", sliceTrace=0),
+                           keep=("meta", "sweep1_phi", "sweep2_phi", "sweep3_phi", "sweep3_g", "sweep3_phiDelta", "rng_next")),
+    # (updateMethod=iterative cannot serve as a fixture: the reference's updateInSlice_iterative aborts with heap corruption --
+    #  "malloc(): invalid size" -- in the first sweep of this very parameter set, IEEE build of oracle/ref_build)
+    "o3_L4_woodbury": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=2, updateMethod="woodbury", sliceTrace=0),
+                           keep=("meta", "sweep1_phi", "sweep2_phi", "sweep2_g", "sweep2_phiDelta", "rng_next")),
     # BASELINE config 1: the half-filled Hubbard model (src/dethubbard.cpp), plus checkerboard propagator, s not dividing m,
     # a larger lattice away from half filling
     "hub_L4": dict(harness="hubbard", args=dict(L=4, d=2, beta=2, dtau=0.1, s=10, t=1, U=4, mu=0, checkerboard=0, sweeps=4, measureSweeps=2)),

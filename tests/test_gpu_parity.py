@@ -1114,3 +1114,23 @@ def test_decomposition_failure_is_reported_not_swallowed(monkeypatch):
     U, d, Vt, sweeps = ctx.udvDecompose(M)
     assert sweeps > 1 and relerr((U * d[None, :]) @ Vt.conj().T, M) < 1e-12
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["o2_L4_woodbury", "o3_L4_woodbury"])
+@pytest.mark.parametrize("method", ["woodbury", "iterative"])
+def test_immediate_update_methods_vs_reference_woodbury_run(name, method):
+    """a19: the fixture is the reference run with updateMethod=woodbury (updateInSlice_woodbury, src/detsdwopdim.cpp:2885-3019;
+    its updateMethod=iterative aborts with heap corruption in this build of the reference, see oracle/make_golden.py).  Here both
+    immediate methods are the delayed kernels at delaySteps = 1; they must reproduce that run."""
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    assert g["params"]["updateMethod"] == "woodbury"
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr", updateMethod=method))
+    i = 1
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}"
+        i += 1
+    assert relerr(rep.g, g[f"sweep{i - 1}_g"]) < TOL and rep.info.phiDelta == g[f"sweep{i - 1}_phiDelta"][0]
+    assert np.array_equal([rep.rand01() for _ in range(4)], g["rng_next"])
+    rep.close()
