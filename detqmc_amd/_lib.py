@@ -152,6 +152,8 @@ SYMBOLS = [
     ("dqmc_backup", C.c_int, [_P]),
     ("dqmc_restore", C.c_int, [_P]),
     ("dqmc_exchange_action_host", C.c_int, [_P, _DP]),
+    ("dqmc_phi_action_all_host", C.c_int, [_P, _DP]),
+    ("dqmc_shift_fields_all_host", C.c_int, [_P, _DP]),
     ("dqmc_set_exchange_parameter", C.c_int, [_P, C.c_double]),
     ("dqmc_shift_green_symmetric_host", C.c_int, [_P, _P]),
     ("dqmc_measure_reset", C.c_int, [_P]),

@@ -75,6 +75,7 @@ struct dqmc_ctx {
     size_t uni_cap = 0;
     DevUpdateState* us = nullptr;
     double* scalar_out = nullptr;
+    double* shift_buf = nullptr;        // [nchains][opdim] displacements of a global shift move (shared buffer)
     int currentTimeslice = 0;
     // profiling
     bool prof = false;
@@ -585,6 +586,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     A_(dalloc(c, &c->uniforms, c->uni_cap));
     A_(dalloc(c, &c->us, 1));
     A_(dalloc(c, &c->scalar_out, 8));
+    A_(salloc(c, &c->shift_buf, (size_t)c->nb * 3));
     c->macc_n = measure_accum_doubles(N, p->L);
     A_(dalloc(c, &c->macc, c->macc_n));
     A_(arena_commit(c));                    // from here on the per-chain pointers are real (chain 0) addresses, zero filled
@@ -1291,6 +1293,26 @@ extern "C" int dqmc_exchange_action_host(dqmc_ctx* c, double* out) {
     double v;
     HIPCHK(copy_sync(c, &v, selp(c, c->scalar_out), sizeof(double), hipMemcpyDeviceToHost));
     *out = 0.5 * c->p.dtau * v;
+    return DQMC_OK;
+}
+
+// phiAction of every chain (detsdwopdim.cpp:4242-4300), computed on the device from the resident field: out[nchains]
+extern "C" int dqmc_phi_action_all_host(dqmc_ctx* c, double* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    { ProfScope ps(c, FAM_OTHER, 1); launch_phi_action(c->lc, c->hm, c->us, c->scalar_out); }
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(double), c->scalar_out, c->lc.cs, sizeof(double), (size_t)c->nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    return DQMC_OK;
+}
+// addGlobalRandomDisplacement for every chain: shifts[nchains][opdim]; also refreshes the cosh / sinh caches
+extern "C" int dqmc_shift_fields_all_host(dqmc_ctx* c, const double* shifts) {
+    if (!c || !shifts) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    HIPCHK(copy_sync(c, c->shift_buf, shifts, (size_t)c->nb * c->p.opdim * sizeof(double), hipMemcpyHostToDevice));
+    { ProfScope ps(c, FAM_OTHER, 2); launch_phi_shift(c->lc, c->hm, c->shift_buf); launch_cosh_sinh(c->lc, c->hm); }
+    HIPCHK(hipGetLastError());
     return DQMC_OK;
 }
 

@@ -156,6 +156,8 @@ void launch_add_diag(const Launch& lc, cplx* A, const double* d, int n);
 void launch_copy(const Launch& lc, const cplx* A, cplx* B, size_t count);
 void launch_copy_bytes(const Launch& lc, const void* src, void* dst, size_t bytes);   // same buffer of every chain
 void launch_phi_sq_sum(const Launch& lc, const DevModel& hm, double* out);
+void launch_phi_action(const Launch& lc, const DevModel& hm, const DevUpdateState* us, double* out);
+void launch_phi_shift(const Launch& lc, const DevModel& hm, const double* shifts /* shared buffer [nchains][opdim] */);
 // fermionic observables of one time slice accumulated from the shifted Green's function gs (kernels_measure.hip)
 // acc layout (doubles): [0] sum Re gs, [1] Re tr gs, [2] occDiffSq sum, [3] slices, then pairPlus[N], pairMinus[N],
 // SX[(2L-1)^2] (re, im), SY[(2L-1)^2] (re, im)

@@ -521,11 +521,27 @@ void DetSDW::attemptGlobalMove(Group& g, GlobalMoveKind kind) {
     const size_t nphi = (size_t)N_ * opdim_ * (m_ + 1);
     std::vector<double> prob_scalar(nb, 1.0), old_sv((size_t)nb * ng_), new_sv((size_t)nb * ng_), added(nb, 0.0);
     std::vector<dqmc_update_state> st(nb);
-    // ONE transfer each for the fields, the step sizes and the old log-determinant data of all chains of the group
-    g.fields.resize(nphi * nb);
-    check(dqmc_get_fields_all_host(ctx, g.fields.data()), "dqmc_get_fields_all_host");
     check(dqmc_get_update_states_all_host(ctx, st.data()), "dqmc_get_update_states_all_host");
     check(dqmc_get_sv_all_host(ctx, old_sv.data()), "dqmc_get_sv_all_host");
+    // The pure shift move never leaves the device: both bosonic actions are reductions over the resident field and the
+    // displacement is a constant per component; the host only draws the displacement (the chain's RNG stream, reference order).
+    const bool on_device = (kind == MoveShift);
+    if (on_device) {
+        std::vector<double> s_old(nb), s_new(nb), shifts((size_t)nb * opdim_);
+        check(dqmc_phi_action_all_host(ctx, s_old.data()), "phiAction");
+        check(dqmc_backup(ctx), "globalMoveStoreBackups");
+        for (int b = 0; b < nb; ++b) {
+            Chain& c = ch_[g.first + b];
+            c.phiDelta = st[b].phiDelta;
+            for (int dim = 0; dim < opdim_; ++dim) shifts[(size_t)b * opdim_ + dim] = c.rng.randRange(-c.phiDelta, +c.phiDelta);   // :3755-3763
+        }
+        check(dqmc_shift_fields_all_host(ctx, shifts.data()), "addGlobalRandomDisplacement");
+        check(dqmc_phi_action_all_host(ctx, s_new.data()), "phiAction");
+        for (int b = 0; b < nb; ++b) prob_scalar[b] = std::exp(-(s_new[b] - s_old[b]));
+    } else {
+    // ONE transfer each for the fields of all chains of the group
+    g.fields.resize(nphi * nb);
+    check(dqmc_get_fields_all_host(ctx, g.fields.data()), "dqmc_get_fields_all_host");
     check(dqmc_backup(ctx), "globalMoveStoreBackups");
     for (int b = 0; b < nb; ++b) {
         Chain& c = ch_[g.first + b];
@@ -544,6 +560,7 @@ void DetSDW::attemptGlobalMove(Group& g, GlobalMoveKind kind) {
         std::vector<double> proposed(nphi * nb);
         for (int b = 0; b < nb; ++b) std::memcpy(&proposed[nphi * b], ch_[g.first + b].phi.data(), nphi * sizeof(double));
         check(dqmc_set_fields_all_host(ctx, proposed.data()), "updateCoshSinhTermsPhi");
+    }
     }
     setupUdVStorage_and_calculateGreen(g);
     check(dqmc_get_sv_all_host(ctx, new_sv.data()), "dqmc_get_sv_all_host");
@@ -565,7 +582,7 @@ void DetSDW::attemptGlobalMove(Group& g, GlobalMoveKind kind) {
         } else {
             check(dqmc_select_chain(ctx, b), "dqmc_select_chain");
             check(dqmc_restore(ctx), "globalMoveRestoreBackups");
-            std::memcpy(c.phi.data(), &g.fields[nphi * b], nphi * sizeof(double));
+            if (!on_device) std::memcpy(c.phi.data(), &g.fields[nphi * b], nphi * sizeof(double));
         }
     }
 }

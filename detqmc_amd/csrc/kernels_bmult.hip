@@ -366,6 +366,56 @@ __global__ void k_phi_sq_sum(DevModel dm, double* out, size_t cs) {
     }
     if (threadIdx.x == 0) out[0] = red[0];
 }
+// phiAction (detsdwopdim.cpp:4242-4300): the bosonic action of the whole field, one workgroup per chain, fixed summation
+// order (per-thread partial sums over (slice, site) pairs in stride, then a tree) => reproducible.  r is the chain's own
+// exchange parameter (DevUpdateState::r).
+__global__ void k_phi_action(DevModel dm, const DevUpdateState* __restrict__ us, double* out, size_t cs) {
+    __shared__ double red[256];
+    dm = chain_model(dm, cs); CHAIN(us); CHAIN(out);
+    const int N = dm.N, L = dm.L, m = dm.m, OPD = dm.opdim;
+    const double dtau = dm.dtau, r = us->r, u = dm.u, c = dm.c;
+    double acc = 0.0;
+    for (int idx = threadIdx.x; idx < m * N; idx += 256) {
+        const int k = 1 + idx / N, site = idx % N;
+        const int kprev = (k > 1) ? k - 1 : m;
+        const int x = site % L, y = site / L;
+        const int xn = y * L + (x + 1) % L, yn = ((y + 1) % L) * L + x;
+        double phisq = 0.0, td2 = 0.0, xd2 = 0.0, yd2 = 0.0;
+        for (int d = 0; d < OPD; ++d) {
+            const double ph = dm.phi[((size_t)k * OPD + d) * N + site];
+            const double td = (ph - dm.phi[((size_t)kprev * OPD + d) * N + site]) / dtau;
+            const double xd = ph - dm.phi[((size_t)k * OPD + d) * N + xn];
+            const double yd = ph - dm.phi[((size_t)k * OPD + d) * N + yn];
+            td2 += td * td; xd2 += xd * xd; yd2 += yd * yd; phisq += ph * ph;
+        }
+        double a = 0.5 * dtau * r * phisq;
+        if (!dm.phi2bosons) a += (dtau / (2.0 * c * c)) * td2 + 0.5 * dtau * xd2 + 0.5 * dtau * yd2 + 0.25 * dtau * u * phisq * phisq;
+        acc += a;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+void launch_phi_action(const Launch& lc, const DevModel& hm, const DevUpdateState* us, double* out) {
+    hipLaunchKernelGGL(k_phi_action, dim3(1, 1, lc.nb), dim3(256), 0, lc.st, hm, us, out, lc.cs);
+}
+// addGlobalRandomDisplacement (detsdwopdim.cpp:3755-3763): every slice (incl. the unused slice 0) of component d shifted by
+// shifts[d], per chain
+__global__ void k_phi_shift(DevModel dm, const double* __restrict__ shifts, size_t cs) {
+    dm = chain_model(dm, cs);
+    const double* sh = shifts + (size_t)blockIdx.z * dm.opdim;
+    const int total = (dm.m + 1) * dm.opdim * dm.N;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+        dm.phi[idx] += sh[(idx / dm.N) % dm.opdim];
+}
+void launch_phi_shift(const Launch& lc, const DevModel& hm, const double* shifts) {
+    const int total = (hm.m + 1) * hm.opdim * hm.N;
+    hipLaunchKernelGGL(k_phi_shift, dim3((total + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, hm, shifts, lc.cs);
+}
 void launch_phi_sq_sum(const Launch& lc, const DevModel& hm, double* out) {
     hipLaunchKernelGGL(k_phi_sq_sum, dim3(1, 1, lc.nb), dim3(256), 0, lc.st, hm, out, lc.cs);
 }

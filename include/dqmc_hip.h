@@ -175,6 +175,10 @@ int dqmc_current_timeslice(dqmc_ctx* ctx);
  * UdV storage, copy fields */
 int dqmc_backup(dqmc_ctx* ctx);
 int dqmc_restore(dqmc_ctx* ctx);
+/* global shift move on the device (attemptGlobalShiftMove, detsdwopdim.cpp:3565-3644): phiAction (:4242-4300) of every chain from
+ * the resident field, out[nchains]; addGlobalRandomDisplacement (:3755-3763) of every chain, shifts[nchains][opdim] */
+int dqmc_phi_action_all_host(dqmc_ctx* ctx, double* out);
+int dqmc_shift_fields_all_host(dqmc_ctx* ctx, const double* shifts);
 /* 1/2 dtau sum phi^2 (get_exchange_action_contribution, detsdwopdim.cpp:5205-5216) */
 int dqmc_exchange_action_host(dqmc_ctx* ctx, double* out);
 
