@@ -450,7 +450,9 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
         // ---- pass 1: W = V^H C over this wave's slab; V in chunks of CH elements, the next chunk's loads in flight while
         //      the matrix cores work on the current one (explicit double buffer: left alone the compiler keeps ONE
         //      register quad for v and waits for every load right after issuing it) ----
-        q_v4d w_re = (q_v4d)(0.0), w_im = (q_v4d)(0.0);
+        // 3M complex products (kernels_gemm.hip): A = conj(v) = (v.x, -v.y), B = x:  w_re = P1 = v.x x.x,  w_p2 = P2 = -v.y x.y,
+        // w_im = P3 = (v.x - v.y)(x.x + x.y);  W = (P1 - P2, P3 - P1 - P2)
+        q_v4d w_re = (q_v4d)(0.0), w_im = (q_v4d)(0.0), w_p2 = (q_v4d)(0.0);
         constexpr int CH = (NE < 8) ? 4 : 8;
         cplx va[CH], vb[CH];
         auto loadv = [&](const cplx* base, int e0, cplx (&dst)[CH]) {
@@ -469,9 +471,8 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
                 const cplx v = src[i];
                 const cplx x = creg[e0 + i];                                                  // B(k, n = j)
                 w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.x, w_re, 0, 0, 0);
-                w_re = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.y, w_re, 0, 0, 0);
-                w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.y, w_im, 0, 0, 0);
-                w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, x.x, w_im, 0, 0, 0);
+                w_p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, x.y, w_p2, 0, 0, 0);
+                w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x - v.y, x.x + x.y, w_im, 0, 0, 0);
             }
         };
         const cplx* vbase = Vcol;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
             if (c + 3 * CH < NE) { QR_TIE(w_re, vbase); loadv(vbase, c + 3 * CH, vb); }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sPart[wave][l4 + 4 * r][l15] = make_double2(w_re[r], w_im[r]);   // D[m = l4 + 4r][n = l15]
+        for (int r = 0; r < 4; ++r) sPart[wave][l4 + 4 * r][l15] = make_double2(w_re[r] - w_p2[r], (w_im[r] - w_re[r]) - w_p2[r]);   // D[m = l4 + 4r][n = l15]
         __syncthreads();
         {
             cplx p0 = sPart[0][wi][wj], p1 = sPart[1][wi][wj], p2 = sPart[2][wi][wj], p3 = sPart[3][wi][wj];
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
             sW[wi][wj] = a2;
         }
         __syncthreads();
-        // ---- pass 2: C tile (16 rows x 16 columns) += V W2, accumulated straight into the registers that hold C ----
+        // ---- pass 2: C tile (16 rows x 16 columns) += V W2 (3M: three zero-initialised accumulators, combined into C) ----
         cplx w2[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) w2[ks] = sW[ks * 4 + l4][l15];           // B(k, n = column)
@@ -521,21 +522,25 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
                 dst[ks] = (vrow < rw && k < nb) ? tv : make_double2(0.0, 0.0);
             }
         };
-        q_v4d d_re, d_im;
-        auto upd = [&](int t, const cplx (&vf)[4]) {
+        double w2s[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { d_re[r] = creg[4 * t + r].x; d_im[r] = creg[4 * t + r].y; }
+        for (int ks = 0; ks < 4; ++ks) w2s[ks] = w2[ks].x + w2[ks].y;
+        q_v4d d_re, d_im, d_p2;
+        auto upd = [&](int t, const cplx (&vf)[4]) {
+            d_re = (q_v4d)(0.0); d_im = (q_v4d)(0.0); d_p2 = (q_v4d)(0.0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].x, d_re, 0, 0, 0);
-                d_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-vf[ks].y, w2[ks].y, d_re, 0, 0, 0);
-                d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x, w2[ks].y, d_im, 0, 0, 0);
-                d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].y, w2[ks].x, d_im, 0, 0, 0);
+                d_p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].y, w2[ks].y, d_p2, 0, 0, 0);
+                d_im = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[ks].x + vf[ks].y, w2s[ks], d_im, 0, 0, 0);
             }
         };
         auto put = [&](int t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) creg[4 * t + r] = make_double2(d_re[r], d_im[r]);   // D[m = l4 + 4r][n = l15]
+            for (int r = 0; r < 4; ++r) {                                                    // D[m = l4 + 4r][n = l15]
+                creg[4 * t + r].x += d_re[r] - d_p2[r];
+                creg[4 * t + r].y += (d_im[r] - d_re[r]) - d_p2[r];
+            }
         };
         const cplx* pbase = Vp;
         loadvf(pbase, 0, vfa);

@@ -738,9 +738,10 @@ __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpd
     const int c0 = wave * 16;
     if (c0 >= nI) return;
     const int l15 = lane & 15, l4 = lane >> 4;
-    u_v4d acc_re[2], acc_im[2];
+    // 3M complex product as in k_zgemm (kernels_gemm.hip): acc_re = P1 = w_r g_r, acc_p2 = P2 = w_i g_i, acc_im = P3 = (w_r + w_i)(g_r + g_i)
+    u_v4d acc_re[2], acc_im[2], acc_p2[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) { acc_re[a] = (u_v4d)(0.0); acc_im[a] = (u_v4d)(0.0); }
+    for (int a = 0; a < 2; ++a) { acc_re[a] = (u_v4d)(0.0); acc_im[a] = (u_v4d)(0.0); acc_p2[a] = (u_v4d)(0.0); }
 #pragma unroll 2
     for (int k0 = 0; k0 < nI; k0 += 4) {
         const int gk = k0 + l4;
@@ -758,9 +759,8 @@ __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpd
             const int r = r0 + a * 16 + l15;
             const cplx g = (kok && r < ng) ? gl[a] : make_double2(0.0, 0.0);
             acc_re[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, g.x, acc_re[a], 0, 0, 0);
-            acc_re[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w.y, g.y, acc_re[a], 0, 0, 0);
-            acc_im[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, g.x, acc_im[a], 0, 0, 0);
-            acc_im[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, g.y, acc_im[a], 0, 0, 0);
+            acc_p2[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, g.y, acc_p2[a], 0, 0, 0);
+            acc_im[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x + w.y, g.x + g.y, acc_im[a], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -768,7 +768,8 @@ __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpd
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int c = c0 + l4 + 4 * rr, r = r0 + a * 16 + l15;      // D[m = l4 + 4 rr][n = l15]
-            if (c < nI && r < ng) X[(size_t)c * ng + r] = make_double2(acc_re[a][rr], acc_im[a][rr]);
+            const double p1 = acc_re[a][rr], p2 = acc_p2[a][rr];
+            if (c < nI && r < ng) X[(size_t)c * ng + r] = make_double2(p1 - p2, (acc_im[a][rr] - p1) - p2);
         }
 }
 
