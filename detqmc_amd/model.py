@@ -230,6 +230,31 @@ class KernelContext:
     def set_exchange_parameter(self, r):
         check(self.lib.dqmc_set_exchange_parameter(self.h, r))
 
+    # one transfer / one launch for ALL chains of a batched context
+    def phi_action_all(self):
+        out = np.zeros(self.nchains_total())
+        check(self.lib.dqmc_phi_action_all_host(self.h, out.ctypes.data_as(_lib._DP)))
+        return out
+
+    def shift_fields_all(self, shifts):
+        a = np.ascontiguousarray(shifts, dtype=np.float64)
+        check(self.lib.dqmc_shift_fields_all_host(self.h, a.ctypes.data_as(_lib._DP)))
+
+    def get_fields_all(self):
+        """(nchains, m+1, N, OPDIM)"""
+        nb = self.nchains_total()
+        a = np.zeros((nb, self.m + 1, self.opdim, self.N))
+        check(self.lib.dqmc_get_fields_all_host(self.h, a.ctypes.data_as(_lib._DP)))
+        return np.transpose(a, (0, 1, 3, 2)).copy()
+
+    def sv_all(self):
+        a = np.zeros((self.nchains_total(), self.ng))
+        check(self.lib.dqmc_get_sv_all_host(self.h, a.ctypes.data_as(_lib._DP)))
+        return a
+
+    def nchains_total(self):
+        return self.lib.dqmc_num_chains(self.h)
+
     def synchronize(self):
         check(self.lib.dqmc_synchronize(self.h))
 

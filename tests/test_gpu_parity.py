@@ -1134,3 +1134,38 @@ def test_immediate_update_methods_vs_reference_woodbury_run(name, method):
     assert relerr(rep.g, g[f"sweep{i - 1}_g"]) < TOL and rep.info.phiDelta == g[f"sweep{i - 1}_phiDelta"][0]
     assert np.array_equal([rep.rand01() for _ in range(4)], g["rng_next"])
     rep.close()
+
+
+def test_device_phi_action_and_batched_transfers_vs_oracle():
+    """phiAction (src/detsdwopdim.cpp:4242-4300) as a device reduction, the global displacement kernel and the one-transfer
+    accessors of a batched context, against the oracle on the same fields (O(2) and O(3), every chain its own r)"""
+    import dataclasses
+    from detqmc_amd import DetSDWBatch
+    from detsdw_oracle import DetSDWOracle
+    for name in ("o2_L6_seed", "o3_L4"):
+        g = load_golden(name)
+        p0 = _sdw_params(g["params"], stabilisation="qr")
+        plist = [dataclasses.replace(p0, simindex=p0.simindex + b, r=p0.r - 0.3 * b) for b in range(3)]
+        batch = DetSDWBatch(plist, sub_batches=1)
+        ctx = batch.kernel_context
+        oras = []
+        for b, p in enumerate(plist):
+            op = oracle_params(g["params"])
+            op.simindex, op.r = p.simindex, p.r
+            oras.append(DetSDWOracle(op))
+        fields = ctx.get_fields_all()
+        for b, o in enumerate(oras):
+            assert np.array_equal(fields[b][1:], o.phi[1:]), (name, b)
+        act = ctx.phi_action_all()
+        want = np.array([o.phiAction() for o in oras])
+        assert np.all(np.abs(act - want) <= 1e-12 * np.abs(want)), (name, act, want)
+        assert relerr(ctx.sv_all()[1], batch.chain(1).g_inv_sv) == 0
+        shifts = np.array([[0.1 * (b + 1) * (d + 1) for d in range(p0.opdim)] for b in range(3)])
+        ctx.shift_fields_all(shifts)
+        for b, o in enumerate(oras):
+            o.phi = o.phi + shifts[b][None, None, :]
+            assert np.array_equal(batch.chain(b).phi, o.phi), (name, b)        # every slice incl. the unused slice 0
+        act2 = ctx.phi_action_all()
+        want2 = np.array([o.phiAction() for o in oras])
+        assert np.all(np.abs(act2 - want2) <= 1e-12 * np.abs(want2))
+        batch.close()
