@@ -36,6 +36,9 @@
 #include "observable.h"
 #include "rngwrapper.h"
 #include "tools.h"
+#include "detmodel.h"           // the primary template get_replica_exchange_probability<Model> (src/detmodel.h:97-108)
+#include "detsdwsystemconfig.h"
+#include "detsdwsystemconfigfilehandle.h"
 #include "detsdw_host.h"        // -I <repo>/include
 
 class DetSDWGpu {
@@ -150,6 +153,36 @@ public:
         detsdw_control_data cd;
         std::memcpy(&cd, buffer.data(), sizeof(cd));
         call(detsdw_set_control_data(h_, &cd), "set_control_data");
+    }
+
+    // ---- what DetQMCPT<Model> needs to save system configurations per control parameter (src/detqmcpt.h:183-200, 665-760):
+    //      the reference's own container / file-handle types, filled from the device field ----
+    typedef DetSDW_SystemConfig SystemConfig;
+    typedef DetSDW_SystemConfig_FileHandle SystemConfig_FileHandle;
+    DetSDW_SystemConfig getCurrentSystemConfiguration() {
+        arma::Cube<num> phi(pars_.N, pars_.opdim, pars_.m + 1);                // reference layout == ABI layout
+        call(detsdw_get_phi(h_, phi.memptr()), "detsdw_get_phi");
+        return DetSDW_SystemConfig(pars_, phi);
+    }
+    DetSDW_SystemConfig_FileHandle prepareSystemConfigurationStreamFileHandle(bool binaryStream, bool textStream,
+                                                                              const std::string& directory = ".") {
+        namespace fs = boost::filesystem;
+        if (!(binaryStream || textStream)) throw_GeneralError("binaryStream or textStream must be sepcified to create file handle");
+        DetSDW_SystemConfig_FileHandle fh;
+        typedef DetSDW_SystemConfig_FileHandle::OfstreamPointer OfstreamPointer;
+        if (binaryStream) {
+            const fs::path p = fs::path(directory) / fs::path("configs-phi.binarystream");
+            fh.phi_output_binary = OfstreamPointer(new std::ofstream(p.c_str(), std::ios::binary | std::ios::app));
+            if (fh.phi_output_binary->fail()) std::cerr << "Could not open file " << p.string() << " for writing.\n";
+        }
+        if (textStream) {
+            const fs::path p = fs::path(directory) / fs::path("configs-phi.textstream");
+            fh.phi_output_text = OfstreamPointer(new std::ofstream(p.c_str(), std::ios::app));
+            if (fh.phi_output_text->fail()) std::cerr << "Could not open file " << p.string() << " for writing.\n";
+            fh.phi_output_text->precision(14);
+            fh.phi_output_text->setf(std::ios::scientific, std::ios::floatfield);
+        }
+        return fh;
     }
 
     // ---- serialisation: DetQMC::saveContents / loadContents hand over their archive (src/detqmc.h:121-135).  The
@@ -309,4 +342,11 @@ inline void createReplica(std::unique_ptr<DetSDWGpu>& replica_out, RngWrapper& r
         throw_ParameterWrong_message("DetSDWGpu: the CPU self-check logs (logSV, checkAndLog*, ...) are not available");
     if (!(pars.specified.count("mux") && pars.specified.count("muy"))) { pars.mux = pars.mu; pars.muy = pars.mu; }
     replica_out = std::unique_ptr<DetSDWGpu>(new DetSDWGpu(rng, pars));
+}
+
+// get_replica_exchange_probability<Model> (src/detmodel.h:97-108) must be specialised per model; the reference does it for
+// DetSDW<CB, OPDIM> (src/detsdwopdim.cpp:5251-5326, Hukushima & Nemoto 1996)
+template<>
+inline num get_replica_exchange_probability<DetSDWGpu>(num parameter_1, num action_contribution_1, num parameter_2, num action_contribution_2) {
+    return detsdw_replica_exchange_probability(parameter_1, action_contribution_1, parameter_2, action_contribution_2);
 }

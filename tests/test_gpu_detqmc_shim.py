@@ -91,3 +91,70 @@ def test_detqmc_driver_resumes_from_its_state_file(tmp_path):
         b = np.array([float(r[0]) for r in _numbers(os.path.join(exp, fn))])
         assert a.shape == b.shape, fn
         assert np.all(np.abs(a - b) <= 1e-9 * np.maximum(np.abs(b), 1e-3)), fn
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's REPLICA-EXCHANGE driver DetQMCPT<> (Boost.MPI, one rank per replica) over the GPU-backed model
+# ------------------------------------------------------------------------------------------------
+PT_EXE = os.path.join(ROOT, "oracle", "_ref", "detqmcptsdwgpu")
+PT_CASE = os.path.join(ROOT, "tests", "golden", "detqmcpt_run_o2_L4")
+MPIEXEC = "/opt/conda/bin/mpiexec"          # the MPICH of this image (same image on the GPU box)
+
+
+def _mpilib():
+    """the three MPICH libraries are reached through symlinks (oracle/ref_build/Makefile, target mpilib): /opt/conda/lib
+    must not enter the library path, its older libstdc++ would shadow the one the ROCm runtime needs"""
+    d = os.path.join(ROOT, "oracle", "_ref", "mpilib")
+    os.makedirs(d, exist_ok=True)
+    for lib in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):
+        dst = os.path.join(d, lib)
+        if not os.path.exists(dst):
+            if os.path.islink(dst):
+                os.remove(dst)
+            os.symlink(os.path.join("/opt/conda/lib", lib), dst)
+
+
+def test_detqmcpt_driver_with_gpu_model_over_mpi_writes_the_reference_output_tree(tmp_path):
+    """mpiexec -n 4 detqmcptsdwgpu: DetQMCPT<DetSDWGpu, ModelParamsDetSDW> -- the reference's own replicaExchangeStep,
+    per-control-parameter observable handlers, exchange statistics and per-parameter configuration streams, every replica on
+    the GPU (4 processes, one card) -- against the output tree the reference's CPU program (mpiexec -n 4 detqmcptsdwo2_ref)
+    wrote for the same configuration file: p<cpi>_r<value>/{results*.values, *.series, configs-phi.binarystream},
+    exchange-{parameters,acceptance,diffusion}.values."""
+    assert os.path.exists(PT_EXE), "oracle/_ref/detqmcptsdwgpu missing: run `make -C oracle/ref_build detqmcptsdwgpu` in the build container"
+    assert os.path.exists(MPIEXEC), "MPICH launcher of the image not found"
+    _mpilib()
+    shutil.copy(os.path.join(PT_CASE, "simulation.conf"), tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([MPIEXEC, "-n", "4", PT_EXE, "-c", "simulation.conf"], cwd=str(tmp_path), capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "Measurements finished" in out.stdout
+    exp = os.path.join(PT_CASE, "expected")
+    nfiles = 0
+    for dirpath, _, files in os.walk(exp):
+        rel = os.path.relpath(dirpath, exp)
+        for fn in sorted(files):
+            want, got = os.path.join(dirpath, fn), os.path.join(str(tmp_path), rel, fn)
+            assert os.path.exists(got), "the GPU-backed replica-exchange run did not write " + os.path.join(rel, fn)
+            nfiles += 1
+            if fn.endswith(".binarystream"):
+                assert open(got, "rb").read() == open(want, "rb").read(), os.path.join(rel, fn) + ": field configurations differ"
+                continue
+            assert _header(got) == _header(want), os.path.join(rel, fn) + ": metadata header differs"
+            if fn.endswith(".infoheader"):
+                continue
+            a, b = _numbers(got), _numbers(want)
+            assert len(a) == len(b), fn
+            for ra, rb in zip(a, b):
+                assert len(ra) == len(rb), fn
+                for j, (x, y) in enumerate(zip(ra, rb)):
+                    try:
+                        fx, fy = float(x), float(y)
+                    except ValueError:
+                        assert x == y, fn
+                        continue
+                    tol = 1e-5 if (fn.startswith("results") and j == len(ra) - 1) else 1e-9
+                    assert abs(fx - fy) <= tol * max(abs(fy), 1e-3), (rel, fn, ra, rb)
+    assert nfiles == 4 * 16 + 3
+    for p in range(4):
+        assert os.path.exists(tmp_path / ("simulation.%d.state" % p))
