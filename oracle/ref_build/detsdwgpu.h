@@ -78,10 +78,16 @@ public:
     std::vector<KeyValueObservable> getKeyValueObservables() { return obsKeyValue_; }
 
     void sweep(bool takeMeasurements) {
+        rngBeforeSweep();
         call(detsdw_sweep(h_, takeMeasurements ? 1 : 0), "sweep");
+        rngAfterSweep();
         if (takeMeasurements) refreshObservables();
     }
-    void sweepThermalization() { call(detsdw_sweep_thermalization(h_), "sweepThermalization"); }
+    void sweepThermalization() {
+        rngBeforeSweep();
+        call(detsdw_sweep_thermalization(h_), "sweepThermalization");
+        rngAfterSweep();
+    }
     // greenUpdate=simple recomputes G from scratch in every slice (src/detmodel.h:1480-1489): debugging aid, not accelerated
     void sweepSimple(bool) { throw_GeneralError("DetSDWGpu: greenUpdate=simple is not supported, use greenUpdate=stabilized"); }
     void sweepSimpleThermalization() { sweepSimple(false); }
@@ -203,6 +209,7 @@ public:
         TempFile tf;
         { std::ofstream out(tf.path, std::ios::binary); out.write(blob.data(), (std::streamsize)blob.size()); }
         call(detsdw_load_state(h_, tf.path.c_str()), "detsdw_load_state");
+        shadow_ = *rng_;                // the driver has just deserialised its wrapper: both streams are at the saved position
     }
 
 private:
@@ -225,7 +232,36 @@ private:
         RngProbe& operator<<(const std::string& s) { state = s; return *this; }
     };
 
-    DetSDWGpu(RngWrapper& rng, const ModelParamsDetSDW& pars) : pars_(pars) {
+    // ---- ONE random stream, two owners.  In the reference the replica draws from the RngWrapper its driver owns, and DetQMCPT
+    //      takes the replica-exchange decisions of rank 0 from that same object (src/detqmcpt.h:1041).  The library owns a
+    //      bit-identical copy of the stream (the device consumes pre-drawn windows of it), so the two are kept at the same
+    //      position: before a sweep the library's stream skips what the driver drew in between, after a sweep the driver's
+    //      wrapper (and a shadow copy that tells us where it was) skips what the replica consumed. ----
+    static bool samePosition(const RngWrapper& a, const RngWrapper& b) {
+        RngWrapper x = a, y = b;
+        for (int i = 0; i < 3; ++i) if (x.rand01() != y.rand01()) return false;
+        return true;
+    }
+    uint64_t libraryDrawn() const {
+        detsdw_info i;
+        call(detsdw_get_info(h_, &i), "detsdw_get_info");
+        return i.rngDrawn;
+    }
+    void rngBeforeSweep() {
+        int skipped = 0;
+        while (!samePosition(*rng_, shadow_)) {                  // the driver drew from the wrapper since the last sweep
+            (void)shadow_.rand01();
+            (void)detsdw_rng_rand01(h_);
+            if (++skipped > 100000) throw_GeneralError("DetSDWGpu: lost track of the shared random stream");
+        }
+        drawnBefore_ = libraryDrawn();
+    }
+    void rngAfterSweep() {
+        const uint64_t used = libraryDrawn() - drawnBefore_;
+        for (uint64_t i = 0; i < used; ++i) { (void)rng_->rand01(); (void)shadow_.rand01(); }
+    }
+
+    DetSDWGpu(RngWrapper& rng, const ModelParamsDetSDW& pars) : pars_(pars), rng_(&rng) {
         // The replica draws from ITS OWN copy of the stream (the device consumes pre-drawn windows of it).  DetQMC hands
         // over the RngWrapper it has just seeded with (rngSeed, simindex + 1) (src/detqmc.h:181): read the pair back
         // through the wrapper's serialisation hook and insist the stream is still at its start.
@@ -271,6 +307,10 @@ private:
         p.repeatWolffPerSweep = (int32_t)pars.repeatWolffPerSweep;
         p.fermionMeasurements = pars.turnoffFermionMeasurements ? 0 : 1;
         if (detsdw_create(&p, &h_) != DQMC_OK) throw_GeneralError(std::string("detsdw_create: ") + detsdw_last_error());
+        // the constructor consumed the draws of setupRandomField: bring the driver's wrapper to the same position
+        shadow_ = rng;
+        drawnBefore_ = 0;
+        rngAfterSweep();
 
         // the observables DetSDW registers (src/detsdwopdim.cpp:268-333), same names, same order
         using std::cref;
@@ -322,6 +362,9 @@ private:
     }
 
     ModelParamsDetSDW pars_;
+    RngWrapper* rng_;                   // the driver's wrapper (DetQMC::rng / DetQMCPT::rng)
+    RngWrapper shadow_;                 // where the wrapper was when we last looked
+    uint64_t drawnBefore_ = 0;
     detsdw_replica* h_ = nullptr;
     std::vector<ScalarObservable> obsScalar_;
     std::vector<VectorObservable> obsVector_;
