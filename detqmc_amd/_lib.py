@@ -204,6 +204,8 @@ SYMBOLS = [
     ("dethubbard_get_green", C.c_int, [_P, _DP, _DP]),
     ("dethubbard_get_observables", C.c_int, [_P, C.POINTER(dethubbard_observables)]),
     ("dethubbard_get_zcorr", C.c_int, [_P, _DP]),
+    ("dethubbard_save_state", C.c_int, [_P, C.c_char_p]),
+    ("dethubbard_load_state", C.c_int, [_P, C.c_char_p]),
     ("dethubbard_rng_rand01", C.c_double, [_P]),
     ("dethubbard_ctx", _P, [_P]),
 ]

@@ -7,6 +7,7 @@
 // All numerics go through the C ABI in include/dqmc_hip.h.
 #include "dethubbard.h"
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace detqmc {
@@ -164,6 +165,58 @@ void DetHubbard::getGreen(double* gUp, double* gDn, int b) {
         }
 }
 
+// ---- checkpoint / resume ----
+namespace {
+const char kHubMagic[8] = {'D', 'Q', 'M', 'C', 'H', 'U', 'B', '1'};
+struct HubFile { std::FILE* f; ~HubFile() { if (f) std::fclose(f); } };
+void hwr(std::FILE* f, const void* p, size_t n) { if (std::fwrite(p, 1, n, f) != n) throw GeneralError(DQMC_EINVAL, "checkpoint: write error"); }
+void hrd(std::FILE* f, void* p, size_t n) { if (std::fread(p, 1, n, f) != n) throw GeneralError(DQMC_EINVAL, "checkpoint: truncated file"); }
+}  // namespace
+
+void DetHubbard::saveState(const std::string& path) {
+    HubFile hf{std::fopen(path.c_str(), "wb")};
+    if (!hf.f) throw GeneralError(DQMC_EINVAL, "Could not open file " + path + " for writing");
+    const int32_t hdr[6] = {(int32_t)ch_.size(), p_.L, m_, s_, performedSweeps_, (int32_t)lastSweepDir_};
+    hwr(hf.f, kHubMagic, 8); hwr(hf.f, hdr, sizeof(hdr));
+    for (int b = 0; b < (int)ch_.size(); ++b) {
+        Chain& c = ch_[b];
+        check(dqmc_select_chain(ctx_, b), "dqmc_select_chain");
+        check(dqmc_get_fields_host(ctx_, c.aux.data(), nullptr, nullptr), "dqmc_get_fields_host");
+        const std::vector<uint64_t> rng = c.rng.serialize();
+        const uint64_t nr = rng.size(), na = c.aux.size();
+        hwr(hf.f, &nr, 8); hwr(hf.f, rng.data(), nr * 8);
+        hwr(hf.f, &na, 8); hwr(hf.f, c.aux.data(), na * 8);
+    }
+}
+
+void DetHubbard::loadState(const std::string& path) {
+    HubFile hf{std::fopen(path.c_str(), "rb")};
+    if (!hf.f) throw GeneralError(DQMC_EINVAL, "Could not open file " + path + " for reading");
+    char magic[8]; int32_t hdr[6];
+    hrd(hf.f, magic, 8); hrd(hf.f, hdr, sizeof(hdr));
+    if (std::memcmp(magic, kHubMagic, 8) != 0) throw GeneralError(DQMC_EINVAL, "checkpoint: not a detqmc_amd Hubbard state file");
+    if (hdr[0] != (int32_t)ch_.size() || hdr[1] != p_.L || hdr[2] != m_ || hdr[3] != s_)
+        throw GeneralError(DQMC_EINVAL, "checkpoint: written for a different replica set-up");
+    std::vector<double> all(ch_.size() * (size_t)(m_ + 1) * N_);
+    for (size_t b = 0; b < ch_.size(); ++b) {
+        Chain& c = ch_[b];
+        uint64_t nr = 0, na = 0;
+        hrd(hf.f, &nr, 8);
+        if (nr < DSFMT19937::state_words() + 3 || nr > (1u << 26)) throw GeneralError(DQMC_EINVAL, "checkpoint: bad RNG record");
+        std::vector<uint64_t> rng(nr);
+        hrd(hf.f, rng.data(), nr * 8);
+        hrd(hf.f, &na, 8);
+        if (na != c.aux.size()) throw GeneralError(DQMC_EINVAL, "checkpoint: field size mismatch");
+        hrd(hf.f, c.aux.data(), na * 8);
+        c.rng.deserialize(rng);
+        std::memcpy(&all[b * c.aux.size()], c.aux.data(), na * 8);
+    }
+    check(dqmc_set_fields_all_host(ctx_, all.data()), "dqmc_set_fields_all_host");
+    check(dqmc_udv_setup(ctx_), "setupUdVStorage_and_calculateGreen");       // dethubbard.h:345-350
+    performedSweeps_ = hdr[4];
+    lastSweepDir_ = Up;
+}
+
 }  // namespace detqmc
 
 // ---------------------------------------------------------------------------------------------
@@ -199,5 +252,13 @@ extern "C" int dethubbard_get_auxfield(dethubbard_replica* r, double* out) { HGU
 extern "C" int dethubbard_get_green(dethubbard_replica* r, double* gUp, double* gDn) { HGUARD(r->impl->getGreen(gUp, gDn, r->sel)) }
 extern "C" int dethubbard_get_observables(dethubbard_replica* r, dethubbard_observables* out) { HGUARD(r->impl->getObservables(*out, r->sel)) }
 extern "C" int dethubbard_get_zcorr(dethubbard_replica* r, double* out) { HGUARD(r->impl->getZcorr(out, r->sel)) }
+extern "C" int dethubbard_save_state(dethubbard_replica* r, const char* path) {
+    if (!path) { g_hub_err = "null path"; return DQMC_EINVAL; }
+    HGUARD(r->impl->saveState(path))
+}
+extern "C" int dethubbard_load_state(dethubbard_replica* r, const char* path) {
+    if (!path) { g_hub_err = "null path"; return DQMC_EINVAL; }
+    HGUARD(r->impl->loadState(path))
+}
 extern "C" double dethubbard_rng_rand01(dethubbard_replica* r) { return r ? r->impl->rand01(r->sel) : -1.0; }
 extern "C" dqmc_ctx* dethubbard_ctx(dethubbard_replica* r) { return r ? r->impl->ctx() : nullptr; }

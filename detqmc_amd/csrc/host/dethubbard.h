@@ -23,6 +23,8 @@ public:
     void getGreen(double* gUp, double* gDn, int b);
     void getObservables(dethubbard_observables& out, int b) const { out = ch_[b].obs; }
     void getZcorr(double* out, int b) const;
+    void saveState(const std::string& path);
+    void loadState(const std::string& path);
     double rand01(int b) { return ch_[b].rng.rand01(); }
     dqmc_ctx* ctx() { return ctx_; }
 

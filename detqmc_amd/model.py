@@ -608,3 +608,9 @@ class DetHubbard:
 
     def rand01(self):
         return self.lib.dethubbard_rng_rand01(self.h)
+
+    def save_state(self, path):
+        check(self.lib.dethubbard_save_state(self.h, str(path).encode()), host="hubbard")
+
+    def load_state(self, path):
+        check(self.lib.dethubbard_load_state(self.h, str(path).encode()), host="hubbard")

@@ -62,6 +62,11 @@ int dethubbard_get_auxfield(dethubbard_replica* r, double* out);
 int dethubbard_get_green(dethubbard_replica* r, double* gUp, double* gDn);
 int dethubbard_get_observables(dethubbard_replica* r, dethubbard_observables* out);
 int dethubbard_get_zcorr(dethubbard_replica* r, double* out /* [N] */);
+/* Checkpoint / resume (what DetQMC::saveState keeps for the replica: auxfield, src/dethubbard.h:352-358, plus the position of
+ * the random stream); dethubbard_load_state needs a replica created with the same parameters and rebuilds UdV storage and G(beta)
+ * like the reference's loadContents does (src/dethubbard.h:345-350) */
+int dethubbard_save_state(dethubbard_replica* r, const char* path);
+int dethubbard_load_state(dethubbard_replica* r, const char* path);
 double dethubbard_rng_rand01(dethubbard_replica* r);
 dqmc_ctx* dethubbard_ctx(dethubbard_replica* r);
 

@@ -106,7 +106,7 @@ def _mpilib():
     must not enter the library path, its older libstdc++ would shadow the one the ROCm runtime needs"""
     d = os.path.join(ROOT, "oracle", "_ref", "mpilib")
     os.makedirs(d, exist_ok=True)
-    for lib in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):
+    for lib in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0", "libmkl_rt.so.1"):
         dst = os.path.join(d, lib)
         if not os.path.exists(dst):
             if os.path.islink(dst):
@@ -158,3 +158,59 @@ def test_detqmcpt_driver_with_gpu_model_over_mpi_writes_the_reference_output_tre
     assert nfiles == 4 * 16 + 3
     for p in range(4):
         assert os.path.exists(tmp_path / ("simulation.%d.state" % p))
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 1: the reference's DetQMC<> driver over the GPU-backed Hubbard model
+# ------------------------------------------------------------------------------------------------
+def test_detqmc_driver_with_gpu_hubbard_model_writes_the_reference_output_tree(tmp_path):
+    """detqmchubbardgpu = DetQMC<DetHubbardGpu, ModelParams<DetHubbard>> (oracle/ref_build/dethubbardgpu.h) with the reference's
+    option parser (src/maindetqmchubbard.cpp), against the output of the reference's own detqmchubbard program for the same
+    configuration file; then a resume from simulation.state (saveContents / loadContents through the boost archive)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "detqmchubbardgpu")
+    case = os.path.join(ROOT, "tests", "golden", "detqmc_run_hubbard_L4")
+    assert os.path.exists(exe), "oracle/_ref/detqmchubbardgpu missing: run `make -C oracle/ref_build detqmchubbardgpu` in the build container"
+    _mpilib()
+    d = os.path.join(ROOT, "oracle", "_ref", "mpilib", "libmkl_rt.so.1")
+    if not os.path.exists(d):
+        os.symlink("/opt/conda/lib/libmkl_rt.so.1", d)
+
+    def run(workdir, *extra):
+        out = subprocess.run([exe, "-c", "simulation.conf"] + list(extra), cwd=str(workdir), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return out.stdout
+
+    def compare(workdir, series_only=False):
+        exp = os.path.join(case, "expected")
+        for fn in sorted(os.listdir(exp)):
+            if series_only and not fn.endswith(".series"):
+                continue
+            got = os.path.join(str(workdir), fn)
+            assert os.path.exists(got), fn
+            if not series_only:
+                assert _header(got) == _header(os.path.join(exp, fn)), fn + ": metadata header differs"
+            a, b = _numbers(got), _numbers(os.path.join(exp, fn))
+            assert len(a) == len(b), fn
+            for ra, rb in zip(a, b):
+                for j, (x, y) in enumerate(zip(ra, rb)):
+                    try:
+                        fx, fy = float(x), float(y)
+                    except ValueError:
+                        assert x == y, fn
+                        continue
+                    tol = 1e-4 if (fn.startswith("results") and j == len(ra) - 1) else 1e-9
+                    assert abs(fx - fy) <= tol * max(abs(fy), 1e-3), (fn, ra, rb)
+
+    a = tmp_path / "full"
+    a.mkdir()
+    shutil.copy(os.path.join(case, "simulation.conf"), a)
+    log = run(a)
+    assert "Measurements finished" in log
+    compare(a)
+    b = tmp_path / "resumed"
+    b.mkdir()
+    shutil.copy(os.path.join(case, "simulation.conf"), b)
+    run(b, "--sweeps", "20")
+    log = run(b, "--sweeps", "40")
+    assert "State of previous simulation has been loaded" in log
+    compare(b, series_only=True)
