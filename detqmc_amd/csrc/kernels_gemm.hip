@@ -216,8 +216,9 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
 // memory into registers; two workgroups per CU so that one's loads overlap the other's MFMAs.
 // Fragment convention as in k_zgemm (operand roles swapped so that the stores coalesce).
 // ---------------------------------------------------------------------------------------------
-template<bool M3>
-__global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, int ldx, const cplx* __restrict__ Gr, int ldg,
+// FULL: n is a multiple of 32 -- every wave's 32 x 32 tile lies inside G or outside of it, no clamps or guards
+template<bool M3, bool FULL>
+__global__ __launch_bounds__(256, FULL ? 3 : 2) void k_flush(const cplx* __restrict__ X, int ldx, const cplx* __restrict__ Gr, int ldg,
                                                   cplx* __restrict__ G, int ldc, int n, int Kmax, const int* __restrict__ Kdev,
                                                   int Kmul, size_t cs, int nb) {
     const int tn = (n + 63) / 64;
@@ -243,21 +244,17 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int gi = i0 + a * 16 + l15;
-            const cplx t = X[(size_t)gkc * ldx + min(gi, n - 1)];
-            a_[a] = (gk < K && gi < n) ? t : make_double2(0.0, 0.0);
+            const cplx t = X[(size_t)gkc * ldx + (FULL ? gi : min(gi, n - 1))];
+            a_[a] = (gk < K && (FULL || gi < n)) ? t : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int gj = j0 + b * 16 + l15;
-            const cplx t = Gr[(size_t)min(gj, n - 1) * ldg + gkc];
-            b_[b] = (gk < K && gj < n) ? t : make_double2(0.0, 0.0);
+            const cplx t = Gr[(size_t)(FULL ? gj : min(gj, n - 1)) * ldg + gkc];
+            b_[b] = (gk < K && (FULL || gj < n)) ? t : make_double2(0.0, 0.0);
         }
     };
-    cplx af[2], bf[2];
-    loadab(0, af, bf);
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        cplx an[2], bn[2];
-        loadab(k0 + 4, an, bn);                  // past the end: clamped address, masked to zero, never used
+    auto mac = [&](const cplx (&af)[2], const cplx (&bf)[2]) {
         double asum[2], bsum[2];
         if (M3) {
 #pragma unroll
@@ -278,31 +275,78 @@ __global__ __launch_bounds__(256, 2) void k_flush(const cplx* __restrict__ X, in
                     acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
                 }
             }
+    };
+    // two k-steps per trip, the fragments of the trip after next requested before the MFMAs of this one (a second k-step past K
+    // multiplies zeros: K = MSF j is even, at most one idle step per tile)
+    cplx a0[2], b0[2], a1[2], b1[2];
+    loadab(0, a0, b0);
+    loadab(4, a1, b1);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        cplx a2[2], b2[2], a3[2], b3[2];
+        loadab(k0 + 8, a2, b2);
+        mac(a0, b0);
+        loadab(k0 + 12, a3, b3);
+        if (k0 + 4 < K) mac(a1, b1);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) { af[a] = an[a]; bf[a] = bn[a]; }
+        for (int a = 0; a < 2; ++a) { a0[a] = a2[a]; b0[a] = b2[a]; a1[a] = a3[a]; b1[a] = b3[a]; }
     }
-    // The tile of G is read only now, 16 x 16 at a time: holding it across the MFMA loop costs 64 VGPRs, i.e. resident
-    // workgroups per CU (3 at 143 VGPRs) whose loads overlap this one's MFMAs (scripts/micro/flush_tiles.hip: 75 -> 55 us;
-    // re-measured in round 2 with the 3M product: requesting the tile before the loop 197 -> 212 ms per 128-chain sweep).
+    // 3M: the three accumulators are combined first (96 -> 64 registers), which makes room for the tile of G
+    if (M3) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            cplx c[4];
-            const int gi = i0 + a * 16 + l15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gj = j0 + b * 16 + l4 + 4 * r;
-                c[r] = G[(size_t)min(gj, n - 1) * ldc + min(gi, n - 1)];
+            for (int b = 0; b < 2; ++b) {
+                acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+                acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
             }
+    }
+    // The tile of G is requested only now -- holding it across the MFMA loop costs 64 VGPRs, i.e. the third resident workgroup
+    // per CU whose loads overlap this one's MFMAs (scripts/micro/flush_tiles.hip: 75 -> 55 us; round 2: 197 -> 212 ms per
+    // 128-chain sweep when it was tried again) -- but then ALL 16 loads of the 32 x 32 tile go out together (one memory round trip
+    // per wave instead of four), as nontemporal accesses: G is streamed once per launch and must not evict the X / Gr panels of its
+    // chain from the L2 (scripts/micro/flush_r2.hip, 128 chains: 258 -> 218 us at K ~ 30, 357 -> 308 us at K = 64).
+    if constexpr (FULL) {
+        cplx c[2][2][4];
+        cplx* base = G + (size_t)(j0 + l4) * ldc + i0 + l15;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gj = j0 + b * 16 + l4 + 4 * r;
-                double re = acc_re[a][b][r], im = acc_im[a][b][r];
-                if (M3) { const double p1 = re, p2 = acc_p2[a][b][r]; re = p1 - p2; im = (im - p1) - p2; }
-                if (gi < n && gj < n) G[(size_t)gj * ldc + gi] = make_double2(c[r].x + re, c[r].y + im);
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                    c[a][b][r].x = __builtin_nontemporal_load(&p->x); c[a][b][r].y = __builtin_nontemporal_load(&p->y);
+                }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                    __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                    __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y);
+                }
+    } else {
+        // ragged edge (n not a multiple of 32): 16 x 16 at a time, clamped loads and guarded stores
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                cplx c[4];
+                const int gi = i0 + a * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gj = j0 + b * 16 + l4 + 4 * r;
+                    c[r] = G[(size_t)min(gj, n - 1) * ldc + min(gi, n - 1)];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gj = j0 + b * 16 + l4 + 4 * r;
+                    if (gi < n && gj < n) G[(size_t)gj * ldc + gi] = make_double2(c[r].x + acc_re[a][b][r], c[r].y + acc_im[a][b][r]);
+                }
             }
-        }
+    }
 }
 
 // developer knob: DQMC_GEMM_4M=1 runs the 4-MFMA complex product (A/B measurements, rounding cross-checks)
@@ -315,8 +359,12 @@ void launch_flush(const Launch& lc, const cplx* X, int ldx, const cplx* Gr, int 
                   const int* Kdev, int Kmul) {
     const int tn = (n + 63) / 64;
     const dim3 grid = (lc.nb % 8 == 0) ? dim3(tn * tn * lc.nb, 1, 1) : dim3(tn * tn, 1, lc.nb);
-    if (use_4m()) hipLaunchKernelGGL(k_flush<false>, grid, dim3(256), 0, lc.st, X, ldx, Gr, ldg, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb);
-    else          hipLaunchKernelGGL(k_flush<true>, grid, dim3(256), 0, lc.st, X, ldx, Gr, ldg, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb);
+    static const bool force_ragged = getenv("DQMC_FLUSH_RAGGED") && atoi(getenv("DQMC_FLUSH_RAGGED")) != 0;   // developer knob (A/B)
+    const bool full = n % 32 == 0 && !force_ragged;
+#define FLUSH_LAUNCH(M3_, FULL_) hipLaunchKernelGGL((k_flush<M3_, FULL_>), grid, dim3(256), 0, lc.st, X, ldx, Gr, ldg, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb)
+    if (use_4m()) { if (full) FLUSH_LAUNCH(false, true); else FLUSH_LAUNCH(false, false); }
+    else          { if (full) FLUSH_LAUNCH(true, true);  else FLUSH_LAUNCH(true, false); }
+#undef FLUSH_LAUNCH
 }
 
 void launch_gemm(const Launch& lc, const GemmArgs& a) {
