@@ -20,6 +20,16 @@ template<class T> __device__ __forceinline__ T* chain_ptr(T* p, size_t cs) {
     return p ? (T*)((char*)p + (size_t)blockIdx.z * cs) : p;
 }
 #define CHAIN(p) p = chain_ptr(p, cs)
+// streaming (nontemporal) access to a matrix element: for operands a kernel touches exactly once per launch, so that they do not
+// evict the panels / tables the same kernel re-reads from the L2 (one global_load/store_dwordx4 with the nt bit)
+__device__ __forceinline__ cplx nt_load(const cplx* p) {
+    cplx t;
+    t.x = __builtin_nontemporal_load(&p->x); t.y = __builtin_nontemporal_load(&p->y);
+    return t;
+}
+__device__ __forceinline__ void nt_store(cplx* p, const cplx& v) {
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+}
 // XCD-aware launch shape for the wide MFMA kernels: consecutive workgroup ids go round-robin over the 8 XCDs (each with
 // its own L2), so with a 1-D grid and   xcd = id % 8,  chain = 8 * (id / 8 / tiles) + xcd,  tile = (id / 8) % tiles
 // all tiles of one chain run on ONE XCD and share the operand panels in that L2 instead of fetching them 8 times.

@@ -76,22 +76,40 @@ __global__ __launch_bounds__(512) void k_bmult_chain(DevModel dm, cplx* __restri
     // ---- stage in ----
     // (the same digit-wise stepping as for the work items further down: no division per element)
     const int rv0 = tid % nvec, re0 = tid / nvec, rvd = nth % nvec, red = nth / nvec;
+    // SB elements per thread are requested before the first of them is written to LDS (left as `sm[idx] = src[idx]` the loop
+    // compiles to load, s_waitcnt vmcnt(0), ds_write per element: eight dependent trips to HBM per tile); nontemporal: A is
+    // streamed through once, the tables of the passes below stay in the L2
+    constexpr int SB = 8;
     if (!RIGHT) {
-        if (lda == ng) {                      // the nv columns are one contiguous run
-            const cplx* src = A + (size_t)v0 * lda;
-            for (int idx = tid; idx < nv * ng; idx += nth) sm[idx] = src[idx];
-        } else {
-            for (int idx = tid; idx < nv * ng; idx += nth) {
-                int v = idx / ng, e = idx - v * ng;
-                sm[v * ng + e] = A[(size_t)(v0 + v) * lda + e];
+        const int total = nv * ng;
+        const cplx* src = A + (size_t)v0 * lda;
+        for (int base = tid; base < total; base += SB * nth) {
+            cplx r[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = min(base + u * nth, total - 1);
+                size_t off = idx;                                        // lda == ng: the nv columns are one contiguous run
+                if (lda != ng) { const int v = idx / ng; off = (size_t)v * lda + (idx - v * ng); }
+                r[u] = nt_load(src + off);
             }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) { const int idx = base + u * nth; if (idx < total) sm[idx] = r[u]; }
         }
     } else {
         int v = rv0, e = re0;
-        for (int idx = tid; idx < nvec * ng; idx += nth) {
-            if (v < nv) sm[e * rstride + v] = A[(size_t)e * lda + (v0 + v)];
-            v += rvd; e += red;
-            if (v >= nvec) { v -= nvec; e += 1; }
+        const int total = nvec * ng;
+        for (int base = tid; base < total; base += SB * nth) {
+            cplx r[SB];
+            int la[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                la[u] = (base + u * nth < total && v < nv) ? e * rstride + v : -1;
+                r[u] = nt_load(A + (size_t)min(e, ng - 1) * lda + (v0 + min(v, nv - 1)));
+                v += rvd; e += red;
+                if (v >= nvec) { v -= nvec; e += 1; }
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) if (la[u] >= 0) sm[la[u]] = r[u];
         }
     }
     __syncthreads();
@@ -222,19 +240,16 @@ __global__ __launch_bounds__(512) void k_bmult_chain(DevModel dm, cplx* __restri
 
     // ---- stage out ----
     if (!RIGHT) {
-        if (lda == ng) {
-            cplx* dst = A + (size_t)v0 * lda;
-            for (int idx = tid; idx < nv * ng; idx += nth) dst[idx] = sm[idx];
-        } else {
-            for (int idx = tid; idx < nv * ng; idx += nth) {
-                int v = idx / ng, e = idx - v * ng;
-                A[(size_t)(v0 + v) * lda + e] = sm[v * ng + e];
-            }
+        cplx* dst = A + (size_t)v0 * lda;
+        for (int idx = tid; idx < nv * ng; idx += nth) {
+            size_t off = idx;
+            if (lda != ng) { const int v = idx / ng; off = (size_t)v * lda + (idx - v * ng); }
+            nt_store(dst + off, sm[idx]);
         }
     } else {
         int v = rv0, e = re0;
         for (int idx = tid; idx < nvec * ng; idx += nth) {
-            if (v < nv) A[(size_t)e * lda + (v0 + v)] = sm[e * rstride + v];
+            if (v < nv) nt_store(A + (size_t)e * lda + (v0 + v), sm[e * rstride + v]);
             v += rvd; e += red;
             if (v >= nvec) { v -= nvec; e += 1; }
         }

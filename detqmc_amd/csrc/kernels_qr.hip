@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int row = slab + 4 * e + l4;
-        const cplx t = Ccol[min(row, rlast)];
+        const cplx t = nt_load(Ccol + min(row, rlast));       // C is streamed through once; the reflector panels stay in the L2
         creg[e] = (cok && row < rows) ? t : make_double2(0.0, 0.0);
     }
     // Up to four block reflectors are applied one after the other while C stays in registers (the later ones are the
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int row = slab + 4 * e + l4;
-        if (cok && row < rows) Ccol[row] = creg[e];
+        if (cok && row < rows) nt_store(Ccol + row, creg[e]);
     }
 }
 
