@@ -347,12 +347,13 @@ def rooflines(rawprof, n, m, B, traffic):
     else:
         qb, qf = qr_apply_work(n)
         calls = max(prof["qr_calls"], 1)
-        # the Green's-function factorisation applies Q^H to a full matrix instead of forming Q: same launch shapes
+        # qr_calls = chain (UDT) factorisations: factor + explicit Q.  (A Green's function that still goes through the Householder
+        # route, n_g > 512, applies Q^H to a full matrix instead of forming Q: same launch shapes.)
         roofs.append(entry("qr_apply", "k_qr_apply_reg", prof["decomp_round_ms"], max(prof["decomp_rounds"], 1), qb * calls * B, qf * calls * B,
                            "block reflectors of up to 4 panels applied to the trailing matrix / to Q with the columns in registers: "
                            "one read + one write per launch, 2 x 8 rows 16 ncols flop per reflector"))
         rest_ms = max(prof["decomp"][0] - prof["decomp_round_ms"], 0.0)
-        roofs.append(entry("qr_rest", "k_qr_panel, triangular solve, pivoting glue", rest_ms, max(prof["decomp"][1] - prof["decomp_rounds"], 1),
+        roofs.append(entry("qr_rest", "k_qr_panel, LU of the Green's function (k_lu_panel, k_lu_rowswap_trsm, K = 16 updates), triangular solves, glue", rest_ms, max(prof["decomp"][1] - prof["decomp_rounds"], 1),
                            0.0, 0.0, "panel factorisations (a chain of dependent reductions: latency bound) and the small kernels "
                            "around the QR; no roofline claimed", latency_bound=True))
     bl = prof["bmult"][1]
@@ -588,7 +589,7 @@ def main():
             res["device_ms_by_family"] = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()
                                           if isinstance(v, tuple) and k != "jacobi"}
             res["decompositions"] = {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
-                                     "max_sweeps": prof["svd_sweeps_max"], "qr_calls": prof["qr_calls"]}
+                                     "max_sweeps": prof["svd_sweeps_max"], "qr_calls": prof["qr_calls"], "lu_calls": prof.get("lu_calls", 0)}
         if cpu is not None:
             res.update(cpu.finish())
         print(json.dumps(res), flush=True)

@@ -46,7 +46,7 @@ class dqmc_profile(C.Structure):
                 ("svd_calls", C.c_uint64), ("svd_sweeps_total", C.c_uint64), ("svd_sweeps_max", C.c_uint64),
                 ("qr_calls", C.c_uint64), ("gemm_flops", C.c_double), ("decomp_round_ms", C.c_double),
                 ("decomp_rounds", C.c_uint64), ("blocks_nonempty", C.c_uint64), ("chains", C.c_uint64),
-                ("updates_accepted", C.c_uint64)]
+                ("updates_accepted", C.c_uint64), ("lu_calls", C.c_uint64)]
 
 
 class detsdw_params(C.Structure):

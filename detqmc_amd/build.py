@@ -20,6 +20,7 @@ SOURCES = [
     "kernels_svd.hip",
     "kernels_update.hip",
     "kernels_qr.hip",
+    "kernels_lu.hip",
     "kernels_measure.hip",
     "kernels_hubbard.hip",
     "dqmc_context.hip",

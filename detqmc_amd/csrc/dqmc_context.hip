@@ -57,6 +57,8 @@ struct dqmc_ctx {
     int stab = 0;                       // DQMC_STAB_SVD / DQMC_STAB_QR
     QrWork qw{};
     int* qr_perm = nullptr;
+    int* lu_swaps = nullptr;
+    uint64_t lu_calls = 0;         // gather lists of the LU panels (kernels_lu.hip)
     int* qr_perm_inv = nullptr;      // inverse of qr_perm and 1/d of the last lazy UDT (triangular chaining product)
     double* qr_dinv = nullptr;
     double *rmax_inv = nullptr, *rmin = nullptr, *lmax_inv = nullptr, *lmin = nullptr;
@@ -575,7 +577,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
         const int np = (ng + 15) / 16;
         A_(dalloc(c, &c->qw.V, n2)); A_(dalloc(c, &c->qw.T, (size_t)np * 2 * 256));
         A_(dalloc(c, &c->qw.W, (size_t)16 * ng)); A_(dalloc(c, &c->qw.W2, (size_t)16 * ng)); A_(dalloc(c, &c->qw.Rneg, (size_t)32 * ng));
-        A_(dalloc(c, &c->qr_perm, (size_t)ng)); A_(dalloc(c, &c->qr_perm_inv, (size_t)ng)); A_(dalloc(c, &c->qr_dinv, (size_t)ng));
+        A_(dalloc(c, &c->qr_perm, (size_t)ng)); A_(dalloc(c, &c->lu_swaps, (size_t)LU_SWAP_INTS)); A_(dalloc(c, &c->qr_perm_inv, (size_t)ng)); A_(dalloc(c, &c->qr_dinv, (size_t)ng));
         A_(dalloc(c, &c->rmax_inv, (size_t)ng)); A_(dalloc(c, &c->rmin, (size_t)ng));
         A_(dalloc(c, &c->lmax_inv, (size_t)ng)); A_(dalloc(c, &c->lmin, (size_t)ng));
     }
@@ -816,6 +818,25 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
     }
     gemm_dev(c, 1, 0, R.U, L.Vt, c->T2, nullptr, 0, c->rmax_inv, c->lmax_inv, 0);
     gemm_dev(c, 1, 0, R.Vt, L.U, c->T2, nullptr, 0, c->rmin, c->lmin, 1);
+    // Z^-1 from an LU factorisation with partial pivoting (kernels_lu.hip; n_g <= 512): P Z = L U, so
+    //   G = [(V_l Dlmax^-1) U^-1] [L^-1 P Drmax^-1 U_r^H] = T3 T1^H  with  T1 = (U_r Drmax^-1 P^T) L^-H,
+    // both brackets as right-hand triangular solves.  DQMC_GREEN_QR=1 keeps the Householder route below (A/B, larger n_g).
+    static const bool force_qr = getenv("DQMC_GREEN_QR") && atoi(getenv("DQMC_GREEN_QR")) != 0;
+    if (n <= 512 && !force_qr) {
+        {
+            ProfScope ps(c, FAM_JACOBI, 0);
+            int launches = run_lu(c->lc, n, c->T2, c->qr_perm, c->lu_swaps);                  // T2 = L \ U, qr_perm = row permutation
+            launch_permute_scale_cols(c->lc, L.Vt, c->lmax_inv, nullptr, n, c->T3);
+            launches += run_trsm_right_upper(c->lc, n, c->T2, c->T3, c->qw);                  // T3 = (V_l Dlmax^-1) U^-1
+            launch_logdet_vector(c->lc, c->T2, c->rmax_inv, c->lmax_inv, n, c->sv);           // |det Z| = prod |U_kk|
+            launch_gather_scale_cols(c->lc, R.U, c->rmax_inv, c->qr_perm, n, c->T1);          // T1 = (U_r Drmax^-1) P^T
+            launches += run_trsm_right_upper(c->lc, n, c->T2, c->T1, c->qw, 1, 1);            // T1 <- T1 (L^H)^-1
+            c->fam_launches[FAM_JACOBI] += launches + 3;
+            c->lu_calls += 1;
+        }
+        gemm_dev(c, 0, 1, c->T3, c->T1, c->G);                                                // G = T3 T1^H
+        return DQMC_OK;
+    }
     {
         ProfScope ps(c, FAM_JACOBI, 0);
         launch_scaled_norms_rank(c->lc, c->T2, n, nullptr, nullptr, 0, n, c->sw.norms, c->qr_perm, c->sw.rnorms);
@@ -1344,7 +1365,7 @@ extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
     prof_collect(c);
     c->prof = on != 0;
     for (int i = 0; i < FAM_COUNT; ++i) { c->fam_ms[i] = 0; c->fam_launches[i] = 0; }
-    c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0; c->qr_calls = 0; c->gemm_flops = 0.0;
+    c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0; c->qr_calls = 0; c->lu_calls = 0; c->gemm_flops = 0.0;
     const unsigned long long zero[2] = {0, 0};
     for (int b = 0; b < c->nb; ++b)
         HIPCHK(copy_sync(c, (char*)chainp(c, c->us, b) + offsetof(DevUpdateState, blocks_nonempty), zero, sizeof(zero), hipMemcpyHostToDevice));
@@ -1360,6 +1381,7 @@ extern "C" int dqmc_profile_read(dqmc_ctx* c, dqmc_profile* out) {
     if (c->stab == DQMC_STAB_SVD) out->ms[DQMC_FAM_DECOMP] = c->fam_ms[FAM_ROUNDS];
     out->svd_calls = c->svd_calls; out->svd_sweeps_total = c->svd_sweeps_total; out->svd_sweeps_max = (uint64_t)c->svd_sweeps_max;
     out->qr_calls = c->qr_calls;
+    out->lu_calls = c->lu_calls;
     out->gemm_flops = c->gemm_flops;
     out->decomp_round_ms = c->fam_ms[FAM_ROUNDS];
     out->decomp_rounds = c->fam_launches[FAM_ROUNDS];

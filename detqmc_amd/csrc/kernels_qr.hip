@@ -749,13 +749,20 @@ int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans)
 //   for each column block J (32 wide):  C_J -= Y_{<J} R_{<J,J}  (GEMM);  C_J <- C_J R_JJ^-1  (one thread per row)
 // ---------------------------------------------------------------------------------------------
 #define TRSM_NB 32
+// trans: the triangular matrix is the conjugate transpose of the stored LOWER triangle; unit: its diagonal is 1 (not read)
 __global__ __launch_bounds__(256) void k_trsm_block(cplx* __restrict__ C, int ldc, const cplx* __restrict__ R, int ldr,
-                                                     int n, int j0, int nb, size_t cs) {
+                                                     int n, int j0, int nb, int trans, int unit, size_t cs) {
     __shared__ cplx sR[TRSM_NB][TRSM_NB + 1];
     CHAIN(C); CHAIN(R);
     for (int i = threadIdx.x; i < TRSM_NB * TRSM_NB; i += 256) {
         int r = i % TRSM_NB, c = i / TRSM_NB;
-        sR[r][c] = (r < nb && c < nb && r <= c) ? R[(size_t)(j0 + c) * ldr + (j0 + r)] : make_double2(0.0, 0.0);
+        cplx v = make_double2(0.0, 0.0);
+        if (r < nb && c < nb && r <= c) {
+            if (unit && r == c) v = make_double2(1.0, 0.0);
+            else if (trans) { const cplx t = R[(size_t)(j0 + r) * ldr + (j0 + c)]; v = make_double2(t.x, -t.y); }
+            else v = R[(size_t)(j0 + c) * ldr + (j0 + r)];
+        }
+        sR[r][c] = v;
     }
     __syncthreads();
     int row = blockIdx.x * 256 + threadIdx.x;
@@ -794,19 +801,21 @@ __global__ void k_negate_copy_block(const cplx* __restrict__ R, int ldr, int row
     }
 }
 
-int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w) {
+int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w, int trans, int unit) {
     int launches = 0;
     for (int j0 = 0; j0 < n; j0 += TRSM_NB) {
         const int nb = (n - j0 < TRSM_NB) ? (n - j0) : TRSM_NB;
         if (j0 > 0) {
             // C_J -= Y_{<J} R_{<J,J}
             GemmArgs g = GemmArgs();
-            g.A = C; g.lda = n; g.opA = 0; g.B = R + (size_t)j0 * n; g.ldb = n; g.opB = 0; g.C = C + (size_t)j0 * n; g.ldc = n;
+            g.A = C; g.lda = n; g.opA = 0; g.C = C + (size_t)j0 * n; g.ldc = n;
+            if (trans) { g.B = R + j0; g.ldb = n; g.opB = 1; }                     // (L^H)[<J, J] = conj(L[J, <J])^T
+            else       { g.B = R + (size_t)j0 * n; g.ldb = n; g.opB = 0; }
             g.M = n; g.N = nb; g.K = j0; g.Kmul = 1; g.accumulate = 1; g.negate = 1;
             launch_gemm(lc, g);
             launches += 1;
         }
-        hipLaunchKernelGGL(k_trsm_block, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, C, n, R, n, n, j0, nb, lc.cs);
+        hipLaunchKernelGGL(k_trsm_block, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, C, n, R, n, n, j0, nb, trans, unit, lc.cs);
         ++launches;
     }
     return launches;
@@ -872,7 +881,7 @@ __global__ void k_permute_scale_cols(const cplx* __restrict__ X, const double* c
         int i = (int)(idx % n), j = (int)(idx / n);
         cplx v = X[idx];
         double sc = colscale ? colscale[j] : 1.0;
-        Y[(size_t)perm[j] * n + i] = make_double2(v.x * sc, v.y * sc);
+        Y[(size_t)(perm ? perm[j] : j) * n + i] = make_double2(v.x * sc, v.y * sc);
     }
 }
 

@@ -271,7 +271,7 @@ class KernelContext:
                    svd_sweeps_max=int(pr.svd_sweeps_max), qr_calls=int(pr.qr_calls), gemm_flops=pr.gemm_flops,
                    decomp_round_ms=pr.decomp_round_ms, decomp_rounds=int(pr.decomp_rounds),
                    blocks_nonempty=int(pr.blocks_nonempty), chains=int(pr.chains),
-                   updates_accepted=int(pr.updates_accepted))
+                   updates_accepted=int(pr.updates_accepted), lu_calls=int(pr.lu_calls))
         return out
 
 

@@ -214,6 +214,8 @@ typedef struct dqmc_profile {
     uint64_t blocks_nonempty;   /* delayed-update blocks that really flushed, summed over all chains, since dqmc_profile_enable */
     uint64_t chains;            /* chains every launch of this context carries */
     uint64_t updates_accepted;  /* accepted local updates, summed over all chains, since dqmc_profile_enable (flush flops = 8 n_g^2 MSF each) */
+    uint64_t lu_calls;          /* QR mode: Green's functions whose inner inverse came from the LU factorisation (n_g <= 512); qr_calls then
+                                   counts the chain factorisations (UDT) only */
 } dqmc_profile;
 int dqmc_profile_enable(dqmc_ctx* ctx, int on);
 int dqmc_profile_read(dqmc_ctx* ctx, dqmc_profile* out);
