@@ -746,7 +746,7 @@ int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans)
 
 // ---------------------------------------------------------------------------------------------
 // right-hand triangular solve  Y R = C  (R upper triangular n x n), in place on C, blocked by NB:
-//   for each column block J (32 wide):  C_J -= Y_{<J} R_{<J,J}  (GEMM);  C_J <- C_J R_JJ^-1  (one thread per row)
+//   diagonal blocks (32 wide):  C_J <- C_J R_JJ^-1  (one thread per row);  everything else: GEMMs (trsm_rec below)
 // ---------------------------------------------------------------------------------------------
 #define TRSM_NB 32
 // trans: the triangular matrix is the conjugate transpose of the stored LOWER triangle; unit: its diagonal is 1 (not read)
@@ -801,24 +801,29 @@ __global__ void k_negate_copy_block(const cplx* __restrict__ R, int ldr, int row
     }
 }
 
-int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w, int trans, int unit) {
-    int launches = 0;
-    for (int j0 = 0; j0 < n; j0 += TRSM_NB) {
-        const int nb = (n - j0 < TRSM_NB) ? (n - j0) : TRSM_NB;
-        if (j0 > 0) {
-            // C_J -= Y_{<J} R_{<J,J}
-            GemmArgs g = GemmArgs();
-            g.A = C; g.lda = n; g.opA = 0; g.C = C + (size_t)j0 * n; g.ldc = n;
-            if (trans) { g.B = R + j0; g.ldb = n; g.opB = 1; }                     // (L^H)[<J, J] = conj(L[J, <J])^T
-            else       { g.B = R + (size_t)j0 * n; g.ldb = n; g.opB = 0; }
-            g.M = n; g.N = nb; g.K = j0; g.Kmul = 1; g.accumulate = 1; g.negate = 1;
-            launch_gemm(lc, g);
-            launches += 1;
-        }
-        hipLaunchKernelGGL(k_trsm_block, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, C, n, R, n, n, j0, nb, trans, unit, lc.cs);
-        ++launches;
+// recursive halving: the solve for columns [j0, j0 + len) once everything left of j0 has been subtracted.  The updates are then
+// ONE product per level and half (N = K = 256, 128, 64, 32 at n = 512) instead of fifteen with N = 32 and K up to 480: the same
+// multiply-adds on 64 x 64 tiles, which read half the operand bytes of the 32 x 32 ones.
+static int trsm_rec(const Launch& lc, int n, const cplx* R, cplx* C, int j0, int len, int trans, int unit) {
+    if (len <= TRSM_NB) {
+        hipLaunchKernelGGL(k_trsm_block, dim3((n + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, C, n, R, n, n, j0, len, trans, unit, lc.cs);
+        return 1;
     }
-    return launches;
+    const int h = ((len / 2 + TRSM_NB - 1) / TRSM_NB) * TRSM_NB;
+    int launches = trsm_rec(lc, n, R, C, j0, h, trans, unit);
+    // C[:, j0 + h .. j0 + len) -= Y[:, j0 .. j0 + h) R[j0 .. j0 + h, j0 + h .. j0 + len)
+    GemmArgs g = GemmArgs();
+    g.A = C + (size_t)j0 * n; g.lda = n; g.opA = 0; g.C = C + (size_t)(j0 + h) * n; g.ldc = n;
+    if (trans) { g.B = R + (size_t)j0 * n + (j0 + h); g.ldb = n; g.opB = 1; }          // (L^H)[J1, J2] = conj(L[J2, J1])^T
+    else       { g.B = R + (size_t)(j0 + h) * n + j0; g.ldb = n; g.opB = 0; }
+    g.M = n; g.N = len - h; g.K = h; g.Kmul = 1; g.accumulate = 1; g.negate = 1;
+    launch_gemm(lc, g);
+    launches += 1;
+    return launches + trsm_rec(lc, n, R, C, j0 + h, len - h, trans, unit);
+}
+int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w, int trans, int unit) {
+    (void)w;
+    return trsm_rec(lc, n, R, C, 0, n, trans, unit);
 }
 
 // ---------------------------------------------------------------------------------------------
