@@ -180,7 +180,7 @@ struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; const SvdProfHo
 int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit (Q == nullptr: reflectors only)
 int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans);       // C <- Q C or Q^H C with the reflectors of the last run_qr
 int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w, int trans = 0, int unit = 0);   // C <- C R^-1 (trans: R = (stored lower triangle)^H; unit: unit diagonal)
-#define LU_SWAP_INTS 64
+#define LU_SWAP_INTS 128
 int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps);                                 // P A = L U in place (n <= 512, else -1), kernels_lu.hip
 void launch_gather_scale_cols(const Launch& lc, const cplx* X, const double* cs, const int* perm, int n, cplx* Y);   // Y[:, j] = X[:, perm[j]] cs[perm[j]]
 void launch_udt_init(const Launch& lc, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,

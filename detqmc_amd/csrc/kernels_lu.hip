@@ -8,17 +8,19 @@
 //
 //   P Z = L U,  P = the sequential row interchanges ipiv (LAPACK zgetrf convention), in place: unit lower L below the diagonal.
 //
-// Right-looking, panel width 16:
-//   k_lu_panel          one workgroup per chain factors a (rows x 16) panel held in registers: per column an arg-max reduction,
-//                       the interchange through LDS, the scaling and the rank-1 update of the rest of the panel.  Thread 0 also
-//                       keeps the row permutation and boils the 16 interchanges down to ONE gather list (which old row ends
-//                       up where) so that nobody has to replay them one after the other.
-//   k_lu_rowswap_trsm   one thread per column outside the panel: gathers the <= 32 rows involved (all loads in flight together),
-//                       solves with the unit lower 16 x 16 block for the columns right of the panel, stores.
-//   k_zgemm             trailing update A22 -= L21 U12 (K = 16).
+// Right-looking, panel width 32:
+//   k_lu_panel          one workgroup per chain factors a (rows x 32) panel held in registers (one row per thread): per column an
+//                       arg-max reduction, the interchange through LDS, the scaling and the rank-1 update of the rest of the panel.
+//                       Thread 0 also keeps the row permutation and boils the 32 interchanges down to ONE gather list (which old
+//                       row ends up where) so that nobody has to replay them one after the other.
+//   k_lu_rowswap_trsm   32 lanes per column outside the panel: lane r loads top row r (512 contiguous bytes per column) and one
+//                       displaced row, the gather is two lane shuffles, the unit lower 32 x 32 solve for the columns right of
+//                       the panel a forward substitution across the 32 lanes.
+//   k_zgemm             trailing update A22 -= L21 U12 (K = 32: half the read-modify-write traffic of 16-wide panels, which is
+//                       what bounds this product).
 #include "dqmc_internal.h"
 
-#define LU_NB 16
+#define LU_NB 32
 
 template<int C>
 struct LuPanelStep {
@@ -32,10 +34,10 @@ struct LuPanelStep<LU_NB> {
     template<class S> __device__ static __forceinline__ void run(S&) {}
 };
 
-template<int RPT, int NT>
+template<int NT>
 struct LuPanelState {
     static constexpr int NW = NT / 64;
-    cplx a[RPT][LU_NB];          // rows tid + r NT (relative to the panel's first row)
+    cplx a[LU_NB];               // row tid (relative to the panel's first row)
     double* redv;                // [NW] per-wave maximum
     int* redi;                   // [NW] its row
     cplx* sPiv;                  // [NB] the pivot row (columns of the panel)
@@ -49,11 +51,9 @@ struct LuPanelState {
         // ---- pivot search: largest |a|^2 in column C at or below the diagonal, smallest row on ties ----
         double best = -1.0;
         int bidx = 0x7fffffff;
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int row = tid + r * NT;
-            const double m = a[r][C].x * a[r][C].x + a[r][C].y * a[r][C].y;
-            if (row >= C && row < rows && (m > best)) { best = m; bidx = row; }
+        {
+            const double m = a[C].x * a[C].x + a[C].y * a[C].y;
+            if (tid >= C && tid < rows && m > best) { best = m; bidx = tid; }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -72,73 +72,62 @@ struct LuPanelState {
             if (ob > best || (ob == best && oi < p)) { best = ob; p = oi; }
         }
         if (p < C || p >= rows) p = C;                       // column of NaNs: leave the row where it is
-        // ---- interchange rows C and p (all 16 columns of the panel) through LDS ----
-        const int pt = p % NT, pr = p / NT;
-        if (tid == pt) {
+        // ---- interchange rows C and p (all columns of the panel) through LDS ----
+        if (tid == p) {
 #pragma unroll
-            for (int c = 0; c < LU_NB; ++c) {
-                cplx v = a[0][c];
-#pragma unroll
-                for (int r = 1; r < RPT; ++r) if (pr == r) v = a[r][c];
-                sPiv[c] = v;
-            }
+            for (int c = 0; c < LU_NB; ++c) sPiv[c] = a[c];
         }
         if (tid == C) {
+            if (p != C) {
 #pragma unroll
-            for (int c = 0; c < LU_NB; ++c) sRow[c] = a[0][c];
+                for (int c = 0; c < LU_NB; ++c) sRow[c] = a[c];
+            }
             sP[C] = p;
         }
         __syncthreads();
-        if (p != C) {
-            if (tid == pt) {
+        // (LDS reads in groups of 8 with a scheduling fence in between: left alone the compiler requests all 32 values of a row at
+        //  once and needs a second set of 128 registers for them)
+#define LU_FENCE() __builtin_amdgcn_sched_barrier(0)
+        if (p != C && (tid == p || tid == C)) {
+            const cplx* src = (tid == C) ? sPiv : sRow;
 #pragma unroll
-                for (int c = 0; c < LU_NB; ++c) {
-                    const cplx v = sRow[c];
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) if (pr == r) a[r][c] = v;
-                }
-            }
-            if (tid == C) {
-#pragma unroll
-                for (int c = 0; c < LU_NB; ++c) a[0][c] = sPiv[c];
+            for (int c = 0; c < LU_NB; ++c) {
+                a[c] = src[c];
+                if ((c & 7) == 7) LU_FENCE();
             }
         }
-        // ---- multipliers and rank-1 update of the rest of the panel ----
+        // ---- multipliers and rank-1 update of the rest of the panel (pivot row: broadcast reads from LDS) ----
         const cplx piv = sPiv[C];
         const double dn = piv.x * piv.x + piv.y * piv.y;
         const cplx inv = dn > 0.0 ? make_double2(piv.x / dn, -piv.y / dn) : make_double2(0.0, 0.0);
-        cplx prow[LU_NB];
+        if (tid > C && tid < rows) {
+            const cplx x = a[C];
+            const cplx l = make_double2(x.x * inv.x - x.y * inv.y, x.x * inv.y + x.y * inv.x);
+            a[C] = l;
 #pragma unroll
-        for (int c = 0; c < LU_NB; ++c) prow[c] = sPiv[c];
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int row = tid + r * NT;
-            if (row > C && row < rows) {
-                const cplx x = a[r][C];
-                const cplx l = make_double2(x.x * inv.x - x.y * inv.y, x.x * inv.y + x.y * inv.x);
-                a[r][C] = l;
-#pragma unroll
-                for (int c = C + 1; c < LU_NB; ++c) {
-                    a[r][c].x -= l.x * prow[c].x - l.y * prow[c].y;
-                    a[r][c].y -= l.x * prow[c].y + l.y * prow[c].x;
-                }
+            for (int c = C + 1; c < LU_NB; ++c) {
+                const cplx u = sPiv[c];
+                a[c].x -= l.x * u.x - l.y * u.y;
+                a[c].y -= l.x * u.y + l.y * u.x;
+                if ((c & 7) == 7) LU_FENCE();
             }
         }
     }
 };
 
-// gather list of a panel (per chain, LU_SWAP_INTS ints): [0] = number of displaced rows below the top block (<= 16),
-// [1 .. 16] = source row of top row c, [17 .. 32] = destination rows of the displaced ones, [33 .. 48] = their source rows
-// (all row numbers global)
-template<int RPT, int NT>
+// gather list of a panel (per chain, LU_SWAP_INTS ints).  Slots 0 .. 31 are the top rows of the panel, slots 32 .. 32 + ndisp - 1
+// the rows below them that an interchange touched:  [0] = ndisp (<= 32), [1 + c] = slot whose OLD content ends up in top row c,
+// [33 + e] = row of displaced slot e (global), [65 + e] = slot whose old content ends up there.
+template<int NT>
 __global__ __launch_bounds__(NT) void k_lu_panel(cplx* __restrict__ A, int lda, int n, int j0, int* __restrict__ perm,
                                                   int* __restrict__ swaps, size_t cs) {
     __shared__ double redv[NT / 64];
     __shared__ int redi[NT / 64];
     __shared__ cplx sPiv[LU_NB], sRow[LU_NB];
     __shared__ int sP[LU_NB];
+    __shared__ int rowof[2 * LU_NB], content[2 * LU_NB];          // thread 0's bookkeeping of the interchanges (epilogue)
     CHAIN(A); CHAIN(perm); CHAIN(swaps);
-    LuPanelState<RPT, NT> s;
+    LuPanelState<NT> s;
     s.redv = redv; s.redi = redi; s.sPiv = sPiv; s.sRow = sRow; s.sP = sP;
     s.tid = threadIdx.x; s.lane = threadIdx.x & 63; s.wave = threadIdx.x >> 6;
     s.rows = n - j0;
@@ -146,31 +135,21 @@ __global__ __launch_bounds__(NT) void k_lu_panel(cplx* __restrict__ A, int lda, 
     if (j0 == 0)
         for (int i = threadIdx.x; i < n; i += NT) perm[i] = i;
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int row = s.tid + r * NT;
-#pragma unroll
-        for (int c = 0; c < LU_NB; ++c) {
-            const cplx t = A[(size_t)(j0 + min(c, s.ncols - 1)) * lda + (j0 + min(row, s.rows - 1))];
-            s.a[r][c] = (row < s.rows && c < s.ncols) ? t : make_double2(0.0, 0.0);
-        }
+    for (int c = 0; c < LU_NB; ++c) {
+        const cplx t = A[(size_t)(j0 + min(c, s.ncols - 1)) * lda + (j0 + min(s.tid, s.rows - 1))];
+        s.a[c] = (s.tid < s.rows && c < s.ncols) ? t : make_double2(0.0, 0.0);
     }
     if (threadIdx.x < LU_NB) sP[threadIdx.x] = threadIdx.x;
     __syncthreads();
     LuPanelStep<0>::run(s);
+    if (s.tid < s.rows) {
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int row = s.tid + r * NT;
-        if (row < s.rows) {
-#pragma unroll
-            for (int c = 0; c < LU_NB; ++c)
-                if (c < s.ncols) A[(size_t)(j0 + c) * lda + (j0 + row)] = s.a[r][c];
-        }
+        for (int c = 0; c < LU_NB; ++c)
+            if (c < s.ncols) A[(size_t)(j0 + c) * lda + (j0 + s.tid)] = s.a[c];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // net effect of the interchanges on the rows outside this panel's columns: content[slot] = the row whose OLD content
-        // sits in slot's row after all interchanges; slots 0..15 = the top rows, further slots = displaced rows
-        int rowof[2 * LU_NB], content[2 * LU_NB];
+        // net effect of the interchanges on the rows: content[slot] = the slot whose OLD content sits in slot's row afterwards
         int nslot = LU_NB;
         for (int c = 0; c < LU_NB; ++c) { rowof[c] = c; content[c] = c; }
         for (int c = 0; c < s.ncols; ++c) {
@@ -180,22 +159,28 @@ __global__ __launch_bounds__(NT) void k_lu_panel(cplx* __restrict__ A, int lda, 
             if (p < LU_NB) slot = p;
             else {
                 for (int e = LU_NB; e < nslot; ++e) if (rowof[e] == p) slot = e;
-                if (slot < 0) { slot = nslot++; rowof[slot] = p; content[slot] = p; }
+                if (slot < 0) { slot = nslot++; rowof[slot] = p; content[slot] = slot; }
             }
             const int t = content[c]; content[c] = content[slot]; content[slot] = t;
             const int q0 = perm[j0 + c]; perm[j0 + c] = perm[j0 + p]; perm[j0 + p] = q0;
         }
         swaps[0] = nslot - LU_NB;
-        for (int c = 0; c < LU_NB; ++c) swaps[1 + c] = j0 + content[c];
-        for (int e = LU_NB; e < 2 * LU_NB; ++e) {
-            swaps[1 + e] = j0 + (e < nslot ? rowof[e] : 0);
-            swaps[1 + LU_NB + e] = j0 + (e < nslot ? content[e] : 0);
+        for (int c = 0; c < LU_NB; ++c) swaps[1 + c] = content[c];
+        for (int e = 0; e < LU_NB; ++e) {
+            const bool used = LU_NB + e < nslot;
+            swaps[1 + LU_NB + e] = j0 + (used ? rowof[LU_NB + e] : 0);
+            swaps[1 + 2 * LU_NB + e] = used ? content[LU_NB + e] : 0;
         }
     }
 }
 
+// complex value of lane `src` of this lane's group of 32
+__device__ __forceinline__ cplx lu_shfl32(cplx v, int src) {
+    return make_double2(__shfl(v.x, src, 32), __shfl(v.y, src, 32));
+}
+
 // Every column outside the panel [j0, j0 + nbw): apply the panel's row interchanges; columns right of the panel also get
-// U12 = L11^-1 A12 (unit lower 16 x 16 block of the panel).  One thread per column.
+// U12 = L11^-1 A12 (unit lower block of the panel).  32 lanes per column, 8 columns per workgroup.
 __global__ __launch_bounds__(256) void k_lu_rowswap_trsm(cplx* __restrict__ A, int lda, int n, int j0, int nbw,
                                                           const int* __restrict__ swaps, size_t cs) {
     __shared__ cplx sL[LU_NB][LU_NB + 1];
@@ -207,37 +192,39 @@ __global__ __launch_bounds__(256) void k_lu_rowswap_trsm(cplx* __restrict__ A, i
         sL[r][c] = (r > c && r < nbw && c < nbw) ? A[(size_t)(j0 + c) * lda + (j0 + r)] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    const int ci = blockIdx.x * 256 + threadIdx.x;
-    if (ci >= n - nbw) return;
-    const int col = ci < j0 ? ci : ci + nbw;
+    const int r = threadIdx.x & 31;
+    const int ci = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = ci < n - nbw;                             // whole groups of 32 lanes are live or not
+    const int col = live ? (ci < j0 ? ci : ci + nbw) : 0;
     cplx* Ac = A + (size_t)col * lda;
     const int ndisp = sS[0];
-    cplx top[LU_NB], ext[LU_NB];
-#pragma unroll
-    for (int c = 0; c < LU_NB; ++c) top[c] = Ac[sS[1 + c]];
-#pragma unroll
-    for (int e = 0; e < LU_NB; ++e) ext[e] = Ac[sS[1 + 2 * LU_NB + e]];       // unused slots read row j0 (valid), never stored
+    // old contents: lane r holds top row r and displaced row r (clamped addresses; nothing is stored that is not live)
+    const cplx vtop = Ac[j0 + min(r, nbw - 1)];
+    const int drow = sS[1 + LU_NB + r];
+    const cplx vext = Ac[r < ndisp ? drow : j0];
+    // gather: what ends up in top row r and in displaced row r
+    const int st = sS[1 + r], se = sS[1 + 2 * LU_NB + r];
+    cplx ntop, next;
+    {
+        const cplx a0 = lu_shfl32(vtop, st & 31), a1 = lu_shfl32(vext, st & 31);
+        ntop = st < LU_NB ? a0 : a1;
+        const cplx b0 = lu_shfl32(vtop, se & 31), b1 = lu_shfl32(vext, se & 31);
+        next = se < LU_NB ? b0 : b1;
+    }
     if (col >= j0 + nbw) {
+        // forward substitution with the unit lower block: after step k lanes > k have subtracted L[r][k] u_k
 #pragma unroll
-        for (int c = 1; c < LU_NB; ++c) {
-            cplx acc = top[c];
-#pragma unroll
-            for (int k = 0; k < LU_NB; ++k) {
-                if (k < c) {
-                    const cplx l = sL[c][k];
-                    acc.x -= l.x * top[k].x - l.y * top[k].y;
-                    acc.y -= l.x * top[k].y + l.y * top[k].x;
-                }
-            }
-            top[c] = acc;
+        for (int k = 0; k < LU_NB - 1; ++k) {
+            const cplx uk = lu_shfl32(ntop, k);
+            const cplx l = sL[r][k];                               // zero for r <= k
+            ntop.x -= l.x * uk.x - l.y * uk.y;
+            ntop.y -= l.x * uk.y + l.y * uk.x;
         }
     }
-#pragma unroll
-    for (int c = 0; c < LU_NB; ++c)
-        if (c < nbw) Ac[j0 + c] = top[c];
-#pragma unroll
-    for (int e = 0; e < LU_NB; ++e)
-        if (e < ndisp) Ac[sS[1 + LU_NB + e]] = ext[e];
+    if (live) {
+        if (r < nbw) Ac[j0 + r] = ntop;
+        if (r < ndisp) Ac[drow] = next;
+    }
 }
 
 // Y[:, j] = X[:, perm[j]] * colscale[perm[j]]
@@ -265,11 +252,12 @@ int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps) {
     for (int j0 = 0; j0 < n; j0 += LU_NB) {
         const int nbw = (n - j0 < LU_NB) ? (n - j0) : LU_NB;
         const int rows = n - j0;
-        if (rows <= 256) hipLaunchKernelGGL((k_lu_panel<1, 256>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, perm, swaps, lc.cs);
-        else             hipLaunchKernelGGL((k_lu_panel<2, 256>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, perm, swaps, lc.cs);
+        if (rows <= 64)       hipLaunchKernelGGL((k_lu_panel<64>), dim3(1, 1, lc.nb), dim3(64), 0, lc.st, A, n, n, j0, perm, swaps, lc.cs);
+        else if (rows <= 256) hipLaunchKernelGGL((k_lu_panel<256>), dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, perm, swaps, lc.cs);
+        else                  hipLaunchKernelGGL((k_lu_panel<512>), dim3(1, 1, lc.nb), dim3(512), 0, lc.st, A, n, n, j0, perm, swaps, lc.cs);
         ++launches;
         if (n - nbw > 0) {
-            hipLaunchKernelGGL(k_lu_rowswap_trsm, dim3((n - nbw + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, nbw, swaps, lc.cs);
+            hipLaunchKernelGGL(k_lu_rowswap_trsm, dim3((n - nbw + 7) / 8, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, nbw, swaps, lc.cs);
             ++launches;
         }
         const int rest = n - j0 - nbw;
