@@ -122,6 +122,8 @@ struct GemmArgs {
     int sharedA, sharedB;       // operand is one matrix for all chains (not shifted by the chain stride)
     const int* a_kgather;       // opA == 0 only: column k of op(A) is column a_kgather[k] of A
     int b_lower;                // op(B) is lower triangular (entries with k < j are zero): the k loop of a column tile starts at its first column
+    int tag;                    // 1: a product inside a factorisation (LU trailing update, triangular solve) -- same code, its own kernel
+                                // name (template argument), so that profiles keep it apart from the model's n_g^3 products
 };
 void launch_gemm(const Launch& lc, const GemmArgs& a);
 // G += X Gr, K = min(Kmax, *Kdev * Kmul): the delayed-update flush as a register-only read-modify-write stream

@@ -24,7 +24,7 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template<int TM, int TN, bool M3>
+template<int TM, int TN, bool M3, int TAG>
 __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb) {   // 2 workgroups per CU: <= 256 registers
     constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16;
     constexpr int NA = BM * BK / 256, NB_ = BN * BK / 256;      // elements of the A / B tile staged per thread
@@ -367,18 +367,23 @@ void launch_flush(const Launch& lc, const cplx* X, int ldx, const cplx* Gr, int 
 #undef FLUSH_LAUNCH
 }
 
-void launch_gemm(const Launch& lc, const GemmArgs& a) {
+template<int TAG>
+static void launch_gemm_tagged(const Launch& lc, const GemmArgs& a) {
     // fill the chip: 64x64 tiles only when they still give >= 256 workgroups
     long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * lc.nb;
     if (tiles64 >= 256 && a.N > 32 && a.M > 32) {
         const int t = ((a.M + 63) / 64) * ((a.N + 63) / 64);
         const dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
-        if (use_4m()) hipLaunchKernelGGL((k_zgemm<2, 2, false>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
-        else          hipLaunchKernelGGL((k_zgemm<2, 2, true>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        if (use_4m()) hipLaunchKernelGGL((k_zgemm<2, 2, false, TAG>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        else          hipLaunchKernelGGL((k_zgemm<2, 2, true, TAG>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
     } else {
         const int t = ((a.M + 31) / 32) * ((a.N + 31) / 32);
         const dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
-        if (use_4m()) hipLaunchKernelGGL((k_zgemm<1, 1, false>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
-        else          hipLaunchKernelGGL((k_zgemm<1, 1, true>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        if (use_4m()) hipLaunchKernelGGL((k_zgemm<1, 1, false, TAG>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        else          hipLaunchKernelGGL((k_zgemm<1, 1, true, TAG>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
     }
+}
+void launch_gemm(const Launch& lc, const GemmArgs& a) {
+    if (a.tag) launch_gemm_tagged<1>(lc, a);
+    else       launch_gemm_tagged<0>(lc, a);
 }

@@ -22,6 +22,15 @@
 
 #define LU_NB 32
 
+// max with the lane(s) a DPP control selects; lanes the control leaves out contribute 0 (the keys are non-negative)
+template<int CTRL, int ROWMASK>
+__device__ __forceinline__ double lu_dpp_max(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    return fmax(v, __hiloint2double(hi2, lo2));
+}
+
 template<int C>
 struct LuPanelStep {
     template<class S> __device__ static __forceinline__ void run(S& s) {
@@ -37,70 +46,61 @@ struct LuPanelStep<LU_NB> {
 template<int NT>
 struct LuPanelState {
     static constexpr int NW = NT / 64;
-    cplx a[LU_NB];               // row tid (relative to the panel's first row)
-    double* redv;                // [NW] per-wave maximum
-    int* redi;                   // [NW] its row
+    cplx a[LU_NB];               // one row of the panel; WHICH row (relative to the panel's first row) is `myrow`
+    int myrow;                   // an interchange renames rows instead of moving registers: the thread that holds the pivot row
+                                 // becomes row C, the thread that was row C takes the pivot's old place
+    double* redv;                // [NW] per-wave maximum key
     cplx* sPiv;                  // [NB] the pivot row (columns of the panel)
-    cplx* sRow;                  // [NB] row C before the interchange
+    int* sPrev;                  // the pivot row's place before the interchange
     int* sP;                     // [NB] pivot row of every column (relative to the panel's first row)
     int tid, lane, wave, rows, ncols;
 
     template<int C>
     __device__ __forceinline__ void column() {
         if (C >= ncols) return;
-        // ---- pivot search: largest |a|^2 in column C at or below the diagonal, smallest row on ties ----
-        double best = -1.0;
-        int bidx = 0x7fffffff;
+        // ---- pivot search: largest |a|^2 in column C among the rows at or below the diagonal.  ONE max-reduction of a 64-bit key:
+        //      the bit pattern of a non-negative double orders like its value, so the low 9 mantissa bits carry 511 - thread (a pivot
+        //      within 2^-43 of the largest candidate is as good as the largest).  DPP steps inside the wave, LDS across waves. ----
+        double key = 0.0;
         {
             const double m = a[C].x * a[C].x + a[C].y * a[C].y;
-            if (tid >= C && tid < rows && m > best) { best = m; bidx = tid; }
+            const unsigned long long bits = ((unsigned long long)__double_as_longlong(m) & ~0x1FFull) | (unsigned long long)(511 - tid);
+            if (myrow >= C && myrow < rows && m == m) key = __longlong_as_double((long long)bits);
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ob = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bidx, off, 64);
-            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-        }
-        if (lane == 0) { redv[wave] = best; redi[wave] = bidx; }
+        key = lu_dpp_max<0x111, 0xf>(key);      // row_shr:1
+        key = lu_dpp_max<0x112, 0xf>(key);      // row_shr:2
+        key = lu_dpp_max<0x114, 0xf>(key);      // row_shr:4
+        key = lu_dpp_max<0x118, 0xf>(key);      // row_shr:8 -> lane 15 of every row of 16
+        key = lu_dpp_max<0x142, 0xa>(key);      // row_bcast:15
+        key = lu_dpp_max<0x143, 0xc>(key);      // row_bcast:31 -> lane 63
+        if (lane == 63) redv[wave] = key;
         __syncthreads();
-        best = redv[0];
-        int p = redi[0];
+        double best = redv[0];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) {
-            const double ob = redv[w];
-            const int oi = redi[w];
-            if (ob > best || (ob == best && oi < p)) { best = ob; p = oi; }
-        }
-        if (p < C || p >= rows) p = C;                       // column of NaNs: leave the row where it is
-        // ---- interchange rows C and p (all columns of the panel) through LDS ----
-        if (tid == p) {
+        for (int w = 1; w < NW; ++w) best = fmax(best, redv[w]);
+        // the thread that holds the pivot row; a column without a usable entry (all NaN): the thread that is row C already
+        const bool none = best == 0.0 && (__double_as_longlong(best) == 0);
+        const int pt = 511 - (int)((unsigned long long)__double_as_longlong(best) & 0x1FFull);
+        const bool mine = none ? (myrow == C) : (tid == pt);
+        if (mine) {
 #pragma unroll
-            for (int c = 0; c < LU_NB; ++c) sPiv[c] = a[c];
-        }
-        if (tid == C) {
-            if (p != C) {
-#pragma unroll
-                for (int c = 0; c < LU_NB; ++c) sRow[c] = a[c];
-            }
-            sP[C] = p;
+            for (int c = C; c < LU_NB; ++c) sPiv[c] = a[c];
+            *sPrev = myrow;
+            sP[C] = myrow;
         }
         __syncthreads();
-        // (LDS reads in groups of 8 with a scheduling fence in between: left alone the compiler requests all 32 values of a row at
-        //  once and needs a second set of 128 registers for them)
+        {
+            const int prev = *sPrev;
+            if (mine) myrow = C;
+            else if (myrow == C) myrow = prev;
+        }
+        // ---- multipliers and rank-1 update of the rest of the panel (pivot row: broadcast reads from LDS, in groups of 8 with a
+        //      scheduling fence in between: left alone the compiler requests the whole row at once and needs 128 more registers) ----
 #define LU_FENCE() __builtin_amdgcn_sched_barrier(0)
-        if (p != C && (tid == p || tid == C)) {
-            const cplx* src = (tid == C) ? sPiv : sRow;
-#pragma unroll
-            for (int c = 0; c < LU_NB; ++c) {
-                a[c] = src[c];
-                if ((c & 7) == 7) LU_FENCE();
-            }
-        }
-        // ---- multipliers and rank-1 update of the rest of the panel (pivot row: broadcast reads from LDS) ----
         const cplx piv = sPiv[C];
         const double dn = piv.x * piv.x + piv.y * piv.y;
         const cplx inv = dn > 0.0 ? make_double2(piv.x / dn, -piv.y / dn) : make_double2(0.0, 0.0);
-        if (tid > C && tid < rows) {
+        if (myrow > C && myrow < rows) {
             const cplx x = a[C];
             const cplx l = make_double2(x.x * inv.x - x.y * inv.y, x.x * inv.y + x.y * inv.x);
             a[C] = l;
@@ -122,13 +122,13 @@ template<int NT>
 __global__ __launch_bounds__(NT) void k_lu_panel(cplx* __restrict__ A, int lda, int n, int j0, int* __restrict__ perm,
                                                   int* __restrict__ swaps, size_t cs) {
     __shared__ double redv[NT / 64];
-    __shared__ int redi[NT / 64];
-    __shared__ cplx sPiv[LU_NB], sRow[LU_NB];
-    __shared__ int sP[LU_NB];
+    __shared__ cplx sPiv[LU_NB];
+    __shared__ int sP[LU_NB], sPrev;
     __shared__ int rowof[2 * LU_NB], content[2 * LU_NB];          // thread 0's bookkeeping of the interchanges (epilogue)
     CHAIN(A); CHAIN(perm); CHAIN(swaps);
     LuPanelState<NT> s;
-    s.redv = redv; s.redi = redi; s.sPiv = sPiv; s.sRow = sRow; s.sP = sP;
+    s.redv = redv; s.sPiv = sPiv; s.sPrev = &sPrev; s.sP = sP;
+    s.myrow = threadIdx.x;
     s.tid = threadIdx.x; s.lane = threadIdx.x & 63; s.wave = threadIdx.x >> 6;
     s.rows = n - j0;
     s.ncols = (n - j0 < LU_NB) ? (n - j0) : LU_NB;
@@ -142,10 +142,10 @@ __global__ __launch_bounds__(NT) void k_lu_panel(cplx* __restrict__ A, int lda, 
     if (threadIdx.x < LU_NB) sP[threadIdx.x] = threadIdx.x;
     __syncthreads();
     LuPanelStep<0>::run(s);
-    if (s.tid < s.rows) {
+    if (s.myrow < s.rows) {
 #pragma unroll
         for (int c = 0; c < LU_NB; ++c)
-            if (c < s.ncols) A[(size_t)(j0 + c) * lda + (j0 + s.tid)] = s.a[c];
+            if (c < s.ncols) A[(size_t)(j0 + c) * lda + (j0 + s.myrow)] = s.a[c];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -266,7 +266,7 @@ int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps) {
             g.A = A + (size_t)j0 * n + (j0 + nbw); g.lda = n; g.opA = 0;                 // L21
             g.B = A + (size_t)(j0 + nbw) * n + j0; g.ldb = n; g.opB = 0;                 // U12
             g.C = A + (size_t)(j0 + nbw) * n + (j0 + nbw); g.ldc = n;
-            g.M = rest; g.N = rest; g.K = nbw; g.Kmul = 1; g.accumulate = 1; g.negate = 1;
+            g.M = rest; g.N = rest; g.K = nbw; g.Kmul = 1; g.accumulate = 1; g.negate = 1; g.tag = 1;
             launch_gemm(lc, g);
             ++launches;
         }

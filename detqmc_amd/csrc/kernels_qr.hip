@@ -816,7 +816,7 @@ static int trsm_rec(const Launch& lc, int n, const cplx* R, cplx* C, int j0, int
     g.A = C + (size_t)j0 * n; g.lda = n; g.opA = 0; g.C = C + (size_t)(j0 + h) * n; g.ldc = n;
     if (trans) { g.B = R + (size_t)j0 * n + (j0 + h); g.ldb = n; g.opB = 1; }          // (L^H)[J1, J2] = conj(L[J2, J1])^T
     else       { g.B = R + (size_t)(j0 + h) * n + j0; g.ldb = n; g.opB = 0; }
-    g.M = n; g.N = len - h; g.K = h; g.Kmul = 1; g.accumulate = 1; g.negate = 1;
+    g.M = n; g.N = len - h; g.K = h; g.Kmul = 1; g.accumulate = 1; g.negate = 1; g.tag = 1;
     launch_gemm(lc, g);
     launches += 1;
     return launches + trsm_rec(lc, n, R, C, j0 + h, len - h, trans, unit);

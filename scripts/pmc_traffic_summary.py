@@ -20,6 +20,8 @@ FAMILY = [("k_flush", "flush"), ("k_qr_apply_reg", "qr_apply"), ("k_qr_apply", "
 
 
 def family(name):
+    if "k_zgemm<" in name and name.split("(")[0].rstrip().endswith(", 1>"):
+        return "gemm_in_factorisation"          # TAG = 1: LU trailing updates and triangular solves (kernels_gemm.hip)
     for key, fam in FAMILY:
         if key in name:
             return fam
