@@ -48,6 +48,11 @@ if os.environ.get("DQMC_BENCH_GLOBAL_SHIFT"):
     WORKLOAD.update(globalShift=True, globalUpdateInterval=int(os.environ["DQMC_BENCH_GLOBAL_SHIFT"]))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
+# What the instruction sustains on the box with nothing else going on (scripts/micro/mfma_peak.hip, 2-4 waves per SIMD, 2.4 GHz
+# shader clock, 200 back-to-back launches): one v_mfma_f64_16x16x4_f64 per ~99 cycles and SIMD = 47.5 TFLOP/s.  Reported next to
+# the roofline (which stays priced against the 78.6 of the guide); the kernels issue 3 real MFMAs per complex 16x16x4 step (3M),
+# so their MFMA-instruction rate is 6/8 of the `achieved` figure, which counts 8 flop per complex multiply-add.
+MFMA_F64_SUSTAINED_TF = 47.5
 DEFAULT_BATCH = 512            # chains per worker process (detsdw_create_batch), spread over DEFAULT_SUB kernel contexts
 DEFAULT_SUB = 4                # kernel contexts (sub-batches, one host thread + HIP stream each) per process: the latency-bound
                                # kernels of one context overlap the streaming / MFMA kernels of the others
@@ -322,6 +327,9 @@ def rooflines(rawprof, n, m, B, traffic):
              "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches, "device_ms": ms, "chains_per_launch": B, "note": note}
         if latency_bound:
             e["latency_bound"] = True
+        if mf:
+            e["mfma_instruction_TFLOPps"] = 0.75 * tfs                      # 3M: 6 of the 8 counted flop are issued
+            e["frac_of_sustained_mfma"] = 0.75 * tfs / MFMA_F64_SUSTAINED_TF
         t = (traffic or {}).get(name)
         if t:
             # HBM bytes per launch from the PMC passes (their own run of this configuration) and, next to it, that run's
@@ -580,12 +588,15 @@ def main():
             res["roofline_other_kernels"] = roofs[1:]
             res["roofline_whole_step"] = whole
             res["roofline_selection"] = ("largest device time among the kernel families a roof can bound; the decision kernel (%.0f ms) and the QR "
-                                         "panel / glue kernels (%.0f ms) are latency bound (one workgroup per chain) and listed under "
+                                         "panel / LU / glue kernels (%.0f ms) are latency bound (one workgroup per chain) and listed under "
                                          "roofline_other_kernels with latency_bound = true" % (
                                              sum(r["device_ms"] for r in roofs if r["family"] == "decide"),
                                              sum(r["device_ms"] for r in roofs if r["family"] == "qr_rest")))
             res["roofline_conditions"] = ("HIP events on the context's own stream, ONE context (%d chains) alone on the GPU, %d steps right "
                                           "after the timed region (%.1f sweeps/s with the event records)" % (Bc, a.steps, Bc * a.steps / solo["dt_profiled"]))
+            res["mfma_f64_sustained"] = {"TFLOPps": MFMA_F64_SUSTAINED_TF, "frac_of_peak": MFMA_F64_SUSTAINED_TF / MFMA_F64_PEAK_TF,
+                                         "note": "v_mfma_f64_16x16x4_f64 issued back to back with nothing else going on, 2-4 waves per SIMD, measured "
+                                                 "on this pool's MI355X (scripts/micro/mfma_peak.hip); roofline fractions stay priced against the guide's peak"}
             res["device_ms_by_family"] = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()
                                           if isinstance(v, tuple) and k != "jacobi"}
             res["decompositions"] = {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
