@@ -1169,3 +1169,29 @@ def test_device_phi_action_and_batched_transfers_vs_oracle():
         want2 = np.array([o.phiAction() for o in oras])
         assert np.all(np.abs(act2 - want2) <= 1e-12 * np.abs(want2))
         batch.close()
+
+
+def test_lu_and_householder_green_functions_walk_the_same_chains(tmp_path):
+    """greenFromUdV in QR mode inverts its scale-split matrix by LU with partial pivoting (kernels_lu.hip, n_g <= 512);
+    DQMC_GREEN_QR=1 keeps the Householder route of round 1 (and n_g > 512 uses it).  Both must give the chains the fixtures pin:
+    same fields, same global-move decisions (log det from diag U resp. diag R), same G -- the switch is read once per process, so two
+    child processes run scripts/check_lu_vs_qr.py (L = 8 with n_g = 128 = four 32-wide panels, L = 6 with n_g = 72: a ragged last one)."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "check_lu_vs_qr.py")
+    for L, beta, sweeps in ((8, 10.0, 6), (6, 20.0, 4)):
+        outs = []
+        for force_qr in (False, True):
+            env = dict(os.environ)
+            env.pop("DQMC_GREEN_QR", None)
+            if force_qr:
+                env["DQMC_GREEN_QR"] = "1"
+            r = subprocess.run([sys.executable, script, str(L), str(beta), str(sweeps), "4"], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            f = tmp_path / ("L%d_%s.txt" % (L, "qr" if force_qr else "lu"))
+            f.write_text(r.stdout)
+            outs.append(str(f))
+        r = subprocess.run([sys.executable, script, "--compare"] + outs, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        assert "same chains" in r.stdout
