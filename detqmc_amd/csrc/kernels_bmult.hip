@@ -146,6 +146,103 @@ __global__ __launch_bounds__(512) void k_bmult_chain(DevModel dm, cplx* __restri
                 const int npass = shift ? 2 : 3;
                 for (int pass = 0; pass < npass; ++pass) {
                     const int sub = shift ? (pass == 0 ? 1 : 0) : ((pass == 1) ? 0 : 1);
+                    // The site-local e^{-+dtau V} mix is FUSED into the plaquette pass next to it (the first pass when V acts first,
+                    // the last one otherwise): a work item then holds all MSF band entries of its four sites, so the mix happens in
+                    // registers between the LDS read and the LDS write of that pass -- one LDS round trip and one barrier per slice
+                    // less (the kernel's compute phase is bound by the LDS pipe: 4 reads + 4 writes of 16 B per element and slice
+                    // before, SQ_INSTS_LDS / SQ_LDS_BANK_CONFLICT in profiles/r02_pmc_traffic_b128_d32.json).  Per element the
+                    // arithmetic and its order are those of the separate stages.
+                    if (!shift && pass == (PASSES_FIRST ? npass - 1 : 0)) {
+                        const int fitems = nv * P;
+                        const double* ph = dm.phi + (size_t)k * dm.opdim * N;
+                        for (int idx = tid; idx < fitems; idx += nth) {
+                            int p, v;
+                            if (RIGHT) { v = idx % nv; p = idx / nv; } else { p = idx % P; v = idx / P; }
+                            int site[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) site[q] = dm.psites[(sub * 4 + q) * P + p];
+                            cplx x[MSF][4];
+#pragma unroll
+                            for (int b = 0; b < MSF; ++b)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) x[b][q] = sm[addr(v, b * N + site[q])];
+                            auto vmix = [&]() {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int i = site[q];
+                                    const double c = dm.coshT[(size_t)k * N + i], xs = dm.sinhT[(size_t)k * N + i];
+                                    const double p0 = ph[i];
+                                    const double p1 = dm.opdim > 1 ? ph[N + i] : 0.0;
+                                    const double p2 = dm.opdim > 2 ? ph[2 * N + i] : 0.0;
+                                    cplx V[MSF][MSF];
+                                    build_V<MSF>(V, vsign, c, xs, p0, p1, p2);
+                                    cplx in[MSF], out[MSF];
+#pragma unroll
+                                    for (int b = 0; b < MSF; ++b) in[b] = x[b][q];
+                                    if (PASSES_FIRST) {
+#pragma unroll
+                                        for (int b = 0; b < MSF; ++b) in[b] = cscale(in[b], INV ? dm.ovinv[b & 1] : dm.ov[b & 1]);
+                                    }
+#pragma unroll
+                                    for (int o = 0; o < MSF; ++o) {
+                                        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                                        for (int b = 0; b < MSF; ++b) {
+                                            const cplx vv = RIGHT ? V[b][o] : V[o][b];
+                                            acc = cfma(vv, in[b], acc);
+                                        }
+                                        if (!PASSES_FIRST) acc = cscale(acc, INV ? dm.ovinv[o & 1] : dm.ov[o & 1]);
+                                        out[o] = acc;
+                                    }
+#pragma unroll
+                                    for (int b = 0; b < MSF; ++b) x[b][q] = out[b];
+                                }
+                            };
+                            if (!PASSES_FIRST) vmix();
+#pragma unroll
+                            for (int b = 0; b < MSF; ++b) {
+                                const int tbl = ((b & 1) * 2 + signIdx) * 2 + sub;
+                                cplx y[4];
+                                if (dm.pm_real) {
+                                    double co[4];
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) co[q] = abcd_tab[(tbl * 4 + q) * P + p];
+#pragma unroll
+                                    for (int a = 0; a < 4; ++a) {
+                                        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) {
+                                            const double m = co[a ^ q];
+                                            acc.x = fma(m, x[b][q].x, acc.x);
+                                            acc.y = fma(m, x[b][q].y, acc.y);
+                                        }
+                                        y[a] = acc;
+                                    }
+                                } else {
+                                    const cplx* mat = mat_tab + (size_t)tbl * 16 * P + p;
+#pragma unroll
+                                    for (int a = 0; a < 4; ++a) {
+                                        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) {
+                                            const cplx mm = RIGHT ? mat[(size_t)(q * 4 + a) * P] : mat[(size_t)(a * 4 + q) * P];
+                                            acc = cfma(mm, x[b][q], acc);
+                                        }
+                                        y[a] = acc;
+                                    }
+                                }
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) x[b][q] = y[q];
+                            }
+                            if (PASSES_FIRST) vmix();
+#pragma unroll
+                            for (int b = 0; b < MSF; ++b)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) sm[addr(v, b * N + site[q])] = x[b][q];
+                        }
+                        __syncthreads();
+                        continue;
+                    }
                     const int items = nv * MSF * P;
                     int d0 = pl0[0], d1 = pl0[1], d2 = pl0[2];
                     for (int idx = tid; idx < items; idx += nth) {
@@ -198,7 +295,9 @@ __global__ __launch_bounds__(512) void k_bmult_chain(DevModel dm, cplx* __restri
                 }
             } else {
                 // potential part: per-site MSF x MSF mix (+ chemical potential factor of the band index
-                // that faces the hopping part)
+                // that faces the hopping part).  Checkerboard: fused into the neighbouring plaquette pass above; this stage
+                // only runs next to a dense propagator (CB_NONE).
+                if (!dm.dense) continue;
                 const int items = nv * N;
                 const double* ph = dm.phi + (size_t)k * dm.opdim * N;
                 int i = si0, v = sv0, inext, vnext;
@@ -267,7 +366,11 @@ void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, 
     static const int env_r = getenv("DQMC_BMULT_NVEC_R") ? atoi(getenv("DQMC_BMULT_NVEC_R")) : 0;
     int nvec;
     if (side == DQMC_LEFT) {
-        nvec = env_l ? env_l : ng / 256;                 // aim at >= 256 workgroups
+        // aim at >= 256 workgroups, but give every thread a work item in the fused plaquette + V pass (nv P items, P = N / 4):
+        // L = 16: 4 columns per workgroup (single-slice launch of 128 chains 248 -> 219 us with the fused pass; 2 columns: 268)
+        const int per_pass = (256 + hm.P - 1) / hm.P;
+        nvec = env_l ? env_l : std::max(ng / 256, per_pass);
+        if (nvec > ng) nvec = ng;
     } else {
         // row tiles of 8 rows: every global transaction of the strided row access is a FULL 128-byte line.  With 4-row
         // tiles (64-byte pieces) the other half of each line belongs to the neighbouring workgroup, which runs on another
