@@ -22,6 +22,15 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
                                        std::to_string(__LINE__) + ")");                                  \
     } while (0)
 
+// DQMC_SYNC_CHECK=1 (debug mode): every entry point that only enqueues work waits for its stream before it returns and
+// every kernel family scope waits when it closes, so an asynchronous GPU fault is reported by the call -- and the kernel
+// family -- that caused it.  Without it the enqueue-only entry points see a fault whenever the runtime notices it, i.e.
+// possibly one or more calls later (the message says so).  Results are identical either way.
+static bool sync_check_on() {
+    static const bool on = getenv("DQMC_SYNC_CHECK") && atoi(getenv("DQMC_SYNC_CHECK")) != 0;
+    return on;
+}
+
 struct UdVSlot { cplx* U; double* d; cplx* Vt; };
 
 enum { FAM_BMULT = DQMC_FAM_BMULT, FAM_GEMM = DQMC_FAM_GEMM, FAM_JACOBI = DQMC_FAM_DECOMP, FAM_UPDATE = DQMC_FAM_DECIDE,
@@ -88,7 +97,21 @@ struct dqmc_ctx {
     double fam_ms[FAM_COUNT] = {0};
     uint64_t fam_launches[FAM_COUNT] = {0};
     double gemm_flops = 0.0;
+    std::string fault;                  // DQMC_SYNC_CHECK: first kernel family whose work came back with an error
 };
+static const char* const kFamName[FAM_COUNT] = {"k_bmult_chain / site-local V", "k_zgemm (n_g^3 products)", "decomposition (QR / LU / Jacobi, triangular solves)",
+                                                "k_update_decide / k_hubbard_slice", "small kernels (copies, scales, set-up)", "k_update_gather", "k_flush", "rounds"};
+// end of an entry point that only enqueued work
+static int finish(dqmc_ctx* c, const char* entry) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && sync_check_on()) e = hipStreamSynchronize(c->st);
+    if (e == hipSuccess && c->fault.empty()) return DQMC_OK;
+    std::string msg = std::string(entry) + ": " + (e != hipSuccess ? hipGetErrorString(e) : "GPU fault");
+    if (!c->fault.empty()) msg += " in " + c->fault;
+    msg += sync_check_on() ? " [DQMC_SYNC_CHECK: raised by work this call enqueued]"
+                           : " [asynchronous: may stem from an earlier call; rerun with DQMC_SYNC_CHECK=1 to name the call and kernel family]";
+    return fail(DQMC_EHIP, msg);
+}
 
 // shared (chain independent) device memory
 template<class T>
@@ -151,6 +174,11 @@ struct ProfScope {
         c->ev_used += 2;
     }
     ~ProfScope() {
+        if (sync_check_on() && c->fault.empty()) {
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+            if (e != hipSuccess) c->fault = std::string(kFamName[fam]) + " (" + hipGetErrorString(e) + ")";
+        }
         if (idx < 0) return;
         (void)hipEventRecord(c->ev_pool[idx + 1], c->st);
         --c->prof_depth;
@@ -482,7 +510,9 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     memset(&hm, 0, sizeof(hm));
     hm.opdim = p->opdim; hm.MSF = MSF; hm.L = p->L; hm.N = N; hm.ng = ng; hm.m = p->m; hm.s = p->s; hm.n = c->n;
     hm.D = p->delaySteps; hm.P = N / 4; hm.phi2bosons = p->phi2bosons;
-    hm.dbg = getenv("DQMC_DBG") ? atoi(getenv("DQMC_DBG")) : 0;
+#ifdef DQMC_DECIDE_TIMING
+    hm.dbg = (getenv("DQMC_DECIDE_TIMING") && atoi(getenv("DQMC_DECIDE_TIMING"))) ? 8 : 0;   // phase timers of k_update_decide; never changes a result
+#endif
     hm.dtau = p->dtau; hm.r = p->r; hm.c = p->c; hm.u = p->u; hm.lambda = p->lambda;
     hm.ov[0] = std::exp(p->dtau * p->mux); hm.ov[1] = std::exp(p->dtau * p->muy);
     hm.ovinv[0] = std::exp(-p->dtau * p->mux); hm.ovinv[1] = std::exp(-p->dtau * p->muy);
@@ -947,8 +977,7 @@ extern "C" int dqmc_udv_setup(dqmc_ctx* c) {
     }
     if ((rc = green_from_eye(c, c->storage[n], KIND_R))) return rc;
     c->currentTimeslice = m;
-    HIPCHK(hipGetLastError());
-    return DQMC_OK;
+    return finish(c, "dqmc_udv_setup");
 }
 
 extern "C" int dqmc_reset_storage0(dqmc_ctx* c) {
@@ -983,8 +1012,7 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
         if (rc) return rc;
         std::swap(c->storage[l - 1], c->spare);          // storage[l-1] = UdV_L
         c->currentTimeslice = s * (l - 1);
-        HIPCHK(hipGetLastError());
-        return DQMC_OK;
+        return finish(c, "dqmc_advance");
     } else if (dir == DQMC_UP) {
         if (l < 0 || l > n - 1) return fail(DQMC_EINVAL, "advanceUp: l out of range");
         const int k_l = s * l, k_lp1 = (l < n - 1) ? s * (l + 1) : m;
@@ -999,8 +1027,7 @@ extern "C" int dqmc_advance(dqmc_ctx* c, int dir, int l) {
         if (rc) return rc;
         std::swap(c->storage[l + 1], c->spare);
         c->currentTimeslice = k_lp1;
-        HIPCHK(hipGetLastError());
-        return DQMC_OK;
+        return finish(c, "dqmc_advance");
     }
     return fail(DQMC_EINVAL, "dir must be DQMC_UP or DQMC_DOWN");
 }
@@ -1021,8 +1048,7 @@ extern "C" int dqmc_wrap(dqmc_ctx* c, int dir, int k) {
         bmult_dev(c, DQMC_LEFT, 1, k, k - 1, c->G);
         c->currentTimeslice = k - 1;
     } else return fail(DQMC_EINVAL, "dir must be DQMC_UP or DQMC_DOWN");
-    HIPCHK(hipGetLastError());
-    return DQMC_OK;
+    return finish(c, "dqmc_wrap");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1074,8 +1100,7 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     if (c->hm.hubbard) {            // DetHubbard::updateInSlice (dethubbard.cpp:141-172): the whole slice in one launch
         ProfScope ps(c, FAM_UPDATE, 1);
         launch_hubbard_slice(c->lc, c->hm, c->us, c->uniforms, c->G, k, c->hub_e_m2a, c->hub_e_p2a);
-        HIPCHK(hipGetLastError());
-        return DQMC_OK;
+        return finish(c, "dqmc_update_slice");
     }
     const int rounds = (c->N + c->D - 1) / c->D;
     const int WD = c->MSF * c->D;
@@ -1091,14 +1116,14 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
         ProfScope ps(c, FAM_FLUSH, 1);
         launch_flush(c->lc, c->X, c->n_g, c->Gr, WD, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
     }
-    HIPCHK(hipGetLastError());      // a rejected launch (bad configuration) must not pass silently
-    return DQMC_OK;
+    return finish(c, "dqmc_update_slice");
 }
 
 extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     HIPCHK(hipStreamSynchronize(c->st));
+#ifdef DQMC_DECIDE_TIMING
     if (c->hm.dbg & 8) {     // developer phase timers of the decision kernel
         DevUpdateState h;
         HIPCHK(copy_sync(c, &h, selp(c, c->us), sizeof(h), hipMemcpyDeviceToHost));
@@ -1106,6 +1131,7 @@ extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
         for (int i = 0; i < 10; ++i) fprintf(stderr, " t%d=%llu", i, h.dbg_cycles[i]);
         fprintf(stderr, "\n");
     }
+#endif
     HIPCHK(copy_sync(c, out, &selp(c, c->us)->pub, sizeof(*out), hipMemcpyDeviceToHost));
     if (out->error) return fail(out->error, "device ran out of pre-drawn uniforms");
     return DQMC_OK;
@@ -1131,8 +1157,7 @@ extern "C" int dqmc_bmult_host(dqmc_ctx* c, int side, int inverse, int k2, int k
     bmult_dev(c, side, inverse, k2, k1, c->T1);
     HIPCHK(hipMemcpyAsync(A, selp(c, c->T1), n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipGetLastError());
-    return DQMC_OK;
+    return finish(c, "dqmc_bmult_host");
 }
 
 extern "C" int dqmc_udv_decompose_host(dqmc_ctx* c, const dqmc_cplx* M, dqmc_cplx* U, double* d, dqmc_cplx* V_t,
@@ -1163,8 +1188,7 @@ extern "C" int dqmc_gemm_host(dqmc_ctx* c, int opA, int opB, const dqmc_cplx* A,
     gemm_dev(c, opA, opB, c->T1, c->T2, c->T3);
     HIPCHK(hipMemcpyAsync(C, selp(c, c->T3), n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipGetLastError());
-    return DQMC_OK;
+    return finish(c, "dqmc_gemm_host");
 }
 
 extern "C" int dqmc_get_green_host(dqmc_ctx* c, dqmc_cplx* out) {
@@ -1228,7 +1252,7 @@ extern "C" int dqmc_backup(dqmc_ctx* c) {
     launch_copy_bytes(c->lc, c->coshT, c->cosh_bak, ncs * sizeof(double));
     launch_copy_bytes(c->lc, c->sinhT, c->sinh_bak, ncs * sizeof(double));
     swap_state(c);
-    return DQMC_OK;
+    return finish(c, "dqmc_backup");
 }
 extern "C" int dqmc_restore(dqmc_ctx* c) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
@@ -1248,7 +1272,7 @@ extern "C" int dqmc_restore(dqmc_ctx* c) {
     }
 #undef CP_
     c->currentTimeslice = c->m;
-    return DQMC_OK;
+    return finish(c, "dqmc_restore");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1289,13 +1313,11 @@ extern "C" int dqmc_measure_slice(dqmc_ctx* c) {
     if (c->hm.hubbard) {            // DetHubbard::measure (dethubbard.cpp:521-545): accumulator layout in kernels_hubbard.hip
         ProfScope ps(c, FAM_OTHER, 1);
         launch_hubbard_measure(c->lc, c->hm, c->G, c->macc);
-        HIPCHK(hipGetLastError());
-        return DQMC_OK;
+        return finish(c, "dqmc_measure_slice");
     }
     shift_green_dev(c);
     { ProfScope ps(c, FAM_OTHER, 1); launch_measure_accum(c->lc, c->hm, c->T1, c->macc); }
-    HIPCHK(hipGetLastError());
-    return DQMC_OK;
+    return finish(c, "dqmc_measure_slice");
 }
 extern "C" size_t dqmc_measure_accum_size(dqmc_ctx* c) { return c ? c->macc_n : 0; }
 extern "C" int dqmc_measure_read_host(dqmc_ctx* c, double* out) {
@@ -1324,8 +1346,7 @@ extern "C" int dqmc_phi_action_all_host(dqmc_ctx* c, double* out) {
     { ProfScope ps(c, FAM_OTHER, 1); launch_phi_action(c->lc, c->hm, c->us, c->scalar_out); }
     HIPCHK(hipMemcpy2DAsync(out, sizeof(double), c->scalar_out, c->lc.cs, sizeof(double), (size_t)c->nb, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipGetLastError());
-    return DQMC_OK;
+    return finish(c, "dqmc_phi_action_all_host");
 }
 // addGlobalRandomDisplacement for every chain: shifts[nchains][opdim]; also refreshes the cosh / sinh caches
 extern "C" int dqmc_shift_fields_all_host(dqmc_ctx* c, const double* shifts) {
@@ -1333,8 +1354,7 @@ extern "C" int dqmc_shift_fields_all_host(dqmc_ctx* c, const double* shifts) {
     (void)hipSetDevice(c->p.device);
     HIPCHK(copy_sync(c, c->shift_buf, shifts, (size_t)c->nb * c->p.opdim * sizeof(double), hipMemcpyHostToDevice));
     { ProfScope ps(c, FAM_OTHER, 2); launch_phi_shift(c->lc, c->hm, c->shift_buf); launch_cosh_sinh(c->lc, c->hm); }
-    HIPCHK(hipGetLastError());
-    return DQMC_OK;
+    return finish(c, "dqmc_shift_fields_all_host");
 }
 
 extern "C" int dqmc_set_exchange_parameter(dqmc_ctx* c, double r) {

@@ -52,7 +52,7 @@ __device__ __forceinline__ void xcd_chain_tile(int tiles, int nb, int& chain, in
 struct DevModel {
     int opdim, MSF, L, N, ng, m, s, n, D, P;   // P = plaquettes per subgroup = N/4
     int phi2bosons;
-    int dbg;           // developer timing experiments only (DQMC_DBG env var); 0 in production
+    int dbg;           // bit 3: phase timers of k_update_decide; only ever set in builds with -DDQMC_DECIDE_TIMING (always 0 otherwise)
     int dense;         // CB_NONE: the hopping part is a dense GEMM done by the host loop, the chain kernel
                        // only applies e^{+-dtau V}; ov/ovinv are 1 (mu sits inside propK)
     double dtau, r, c, u, lambda;   // r: chain 0's value at create time only -- kernels read DevUpdateState::r
@@ -97,7 +97,7 @@ struct DevUpdateState {
     int block_sites[DQMC_MAX_WDIM];
     unsigned long long blocks_nonempty;  // delayed-update blocks that accepted at least one update (-> real flushes)
     unsigned long long updates_accepted; // accepted local updates (sum of the block ranks j); must follow blocks_nonempty
-    unsigned long long dbg_cycles[16];   // developer phase timers of the decision kernel (DQMC_DBG & 8)
+    unsigned long long dbg_cycles[16];   // developer phase timers of the decision kernel (-DDQMC_DECIDE_TIMING builds only)
 };
 
 // ---- launchers (implemented in the kernels_*.hip files) ---------------------------------------

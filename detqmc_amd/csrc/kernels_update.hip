@@ -21,8 +21,10 @@
 //   disappear.  After the block, X = G[:,I] W and Gr = G[I,:] - E_I are formed by a parallel gather
 //   kernel and G += X Gr is one MFMA GEMM (kernels_gemm.hip).
 //
-// The decision kernel is ONE wavefront: the chain of decisions is strictly sequential, all
-// cross-lane traffic is wave shuffles / a tiny LDS scratch, and no workgroup barrier is ever needed.
+// The decision kernel is ONE workgroup of four wavefronts per chain: the chain of decisions is strictly sequential; per
+// proposal there are two workgroup barriers (wave 0 does the scalar Metropolis arithmetic while waves 1-3 form p = W v and
+// q = u W), cross-lane sums are DPP row reductions.  Nothing in the environment changes what this kernel computes: the
+// only developer switch left is the phase timer, and it exists only in builds with -DDQMC_DECIDE_TIMING.
 #include "dqmc_internal.h"
 #include <mutex>
 
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         }
     };
 
-    // developer phase timers (build with -DDQMC_DECIDE_TIMING, run with DQMC_DBG=8): cycles between TICK marks,
+    // developer phase timers (build with -DDQMC_DECIDE_TIMING, run with DQMC_DECIDE_TIMING=1): cycles between TICK marks,
     // accumulated over the launch.  Compiled out by default -- the counters cost ~26 SGPRs in a kernel that is
     // already short of them.
 #ifdef DQMC_DECIDE_TIMING
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         TICK(1);
         // ---- C: start the loads of the NEXT candidate now; they complete while this decision is computed ----
         const bool have_next = (site + 1 < N);
-        if (have_next && !(dm.dbg & 1)) fetch(pre, pu, pv, site + 1, site, cur + OPDIM, nI);
+        if (have_next) fetch(pre, pu, pv, site + 1, site, cur + OPDIM, nI);
         // ---- the waves split the work between the two barriers: wave 0 does the scalar Metropolis arithmetic of this
         //      proposal (D) and hands delta, exp(-dS), the acceptance uniform and G[c,c] to the others through LDS; waves
         //      1-3 meanwhile form p and q (E).  Neither waits for the other before barrier 2. ----
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         if (tid >= 64) {
             // ---- E: p = W v and, speculatively (needed only on acceptance), q = u W.  Work item = one dot product
             //      split over a quad of lanes; items [0, nI MSF) are p(i, b), items [nI MSF, 2 nI MSF) are q(a, i). ----
-            const int nitems = (dm.dbg & 2) ? 0 : 2 * nI * MSF;
+            const int nitems = 2 * nI * MSF;
             for (int t = tid - 64; t < 4 * nitems; t += 192) {
                 int item = t >> 2, part = t & 3;
                 cplx acc = make_double2(0.0, 0.0);
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 double nrm = sqrt(nn);
                 double arg = dm.lambda * dm.dtau * nrm;
                 // the wave evaluates ONE exp sequence: lane 0 on -dS, the other lanes on arg
-                double ex = (dm.dbg & 4) ? 1.0 + (lane == 0 ? -dsphi : arg) : exp(lane == 0 ? -dsphi : arg);
+                double ex = exp(lane == 0 ? -dsphi : arg);
                 int lo = __builtin_amdgcn_readlane(__double2loint(ex), 0), hi = __builtin_amdgcn_readlane(__double2hiint(ex), 0);
                 probSPhi = __hiloint2double(hi, lo);
                 lo = __builtin_amdgcn_readlane(__double2loint(ex), 1); hi = __builtin_amdgcn_readlane(__double2hiint(ex), 1);
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 }
             // block bordering of W straight from p and q in LDS (pF is formed on the fly: no staging, no barrier):
             //   W11 += (p F) q ;  W12 = p F ;  W21 = F q ;  W22 = F
-            for (int t = tid; t < ((dm.dbg & 2) ? 0 : nI * nI); t += 256) {
+            for (int t = tid; t < nI * nI; t += 256) {
                 int i = t / nI, i2 = t - i * nI;
                 cplx pi[MSF];
 #pragma unroll

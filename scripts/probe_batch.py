@@ -32,6 +32,6 @@ for B in Bs:
     pr = ctx.profile_read()
     print("COUNTERS blocks_nonempty=%d updates_accepted=%d qr_calls=%d chains=%d sweeps_total=%d n_g=%d" % (
         pr["blocks_nonempty"], pr["updates_accepted"], pr["qr_calls"], pr["chains"], nsw + 2, batch.chain(0).info.n_g), flush=True)
-    if int(os.environ.get("DQMC_DBG", "0")) & 8:
+    if int(os.environ.get("DQMC_DECIDE_TIMING", "0")):
         ctx.update_state()          # prints the decision kernel's phase timers (library built with -DDQMC_DECIDE_TIMING)
     batch.close()

@@ -1195,3 +1195,23 @@ def test_lu_and_householder_green_functions_walk_the_same_chains(tmp_path):
         r = subprocess.run([sys.executable, script, "--compare"] + outs, capture_output=True, text=True, timeout=60)
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
         assert "same chains" in r.stdout
+
+
+def test_environment_cannot_change_the_markov_chain():
+    """No environment variable may change what the decision kernel computes.  Rounds 1-2 shipped timing experiments behind
+    DQMC_DBG (bit 2 skipped the p = W v / q = u W products and the bordering update, bit 4 replaced exp by 1 + x); they are gone,
+    and the one developer switch left (phase timers, DQMC_DECIDE_TIMING) exists only in -DDQMC_DECIDE_TIMING builds.  A child
+    process with those variables set must leave slice_phi_m / slice_g of the reference fixtures untouched (updateInSlice,
+    /root/reference/src/detsdwopdim.cpp:3023-3175) -- and so must DQMC_SYNC_CHECK=1, the debug mode that waits for the stream
+    at the end of every entry point."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("DQMC_TEST_CHILD"):
+        pytest.skip("already inside the child process")
+    env = dict(os.environ, DQMC_DBG="6", DQMC_DECIDE_TIMING="1", DQMC_SYNC_CHECK="1", DQMC_TEST_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_update_slice_vs_reference and (o2_L8_b5 or o3_L4 or o2_L4_flux)"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout, r.stdout[-1000:]
