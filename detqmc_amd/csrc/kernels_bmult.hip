@@ -12,7 +12,8 @@
 // independently, a RIGHT multiply on every row.  One workgroup stages a few whole vectors
 // (columns resp. rows) in LDS, applies the whole chain of slices k to them there -- the s slices of
 // a UdV chain cost ONE read and ONE write of A instead of s -- and streams them back.  Column
-// vectors are contiguous in the column-major matrix; row vectors are staged as 64-byte pieces.
+// vectors are contiguous in the column-major matrix; row vectors are staged as tiles of 8 rows (one full 128-byte line of every column,
+// fewer rows when 9 rows of n_g complex numbers do not fit the 144 KiB LDS budget).
 #include "dqmc_internal.h"
 #include <algorithm>
 #include <cstdlib>

@@ -215,17 +215,19 @@ def control_parameter_subdir(cpi, name, value):
     return "p%d_%s%s" % (cpi, name, num_to_string(float(value)))
 
 
-def _write_data_map(path, header_lines, metas, key_name, rows):
-    """DataMapWriter::writeToFile (src/datamapwriter.h:116-160): '## text' lines, '# key = value' metadata (every
-    MetadataMap sorted by key, the maps in the order given), then key <tab> value [<tab> error] with 15 digits, scientific"""
+def _write_data_map(path, items, rows):
+    """DataMapWriter::writeToFile (src/datamapwriter.h:116-160): header items in the order the reference adds them -- ("text", line)
+    -> '## line', ("meta", map) -> '# key = value' sorted by key, ("kv", key, value) -> '# key = value' -- then
+    key <tab> value [<tab> error] with 15 digits, scientific"""
     with open(path, "w") as f:
-        f.write("## %s\n" % header_lines[0])
-        for meta in metas:
-            for k in sorted(meta):
-                f.write("# %s = %s\n" % (k, meta[k]))
-        f.write("# key = %s\n" % key_name)
-        for line in header_lines[1:]:
-            f.write("## %s\n" % line)
+        for it in items:
+            if it[0] == "text":
+                f.write("## %s\n" % it[1])
+            elif it[0] == "meta":
+                for k in sorted(it[1]):
+                    f.write("# %s = %s\n" % (k, it[1][k]))
+            else:
+                f.write("# %s = %s\n" % (it[1], it[2]))
         for row in rows:
             key = row[0]
             f.write((("%d" % key) if isinstance(key, (int, np.integer)) else ("%.15e" % key) if isinstance(key, float) else str(key)))
@@ -243,7 +245,8 @@ class ObservableRouterPT:
     scalar_names / vector_specs = [(name, length)] fix the payload layout.  sweeps, jk_blocks, measure_interval as in
     DetQMCParams."""
 
-    def __init__(self, state: ExchangeState, scalar_names, vector_specs, sweeps, jk_blocks=1, measure_interval=1, timeseries=False):
+    def __init__(self, state: ExchangeState, scalar_names, vector_specs, sweeps, jk_blocks=1, measure_interval=1, timeseries=False,
+                 sweeps_has_changed=False):
         self.state = state
         self.scalar_names = list(scalar_names)
         self.vector_specs = [(n, int(l)) for n, l in vector_specs]
@@ -251,6 +254,7 @@ class ObservableRouterPT:
         self.sweeps, self.jk_blocks, self.measure_interval = int(sweeps), max(1, int(jk_blocks)), int(measure_interval)
         self.jk_block_size_sweeps = max(1, self.sweeps // self.jk_blocks)              # mpiobservablehandlerpt.h:141-142
         self.timeseries = timeseries
+        self.sweeps_has_changed = bool(sweeps_has_changed)      # DetQMCParams::sweepsHasChanged: a resumed run with a new sweep count
         self.count_values = 0
         self.last_sweep_logged = 0
         self.nproc = len(state.controlParameterValues)
@@ -306,16 +310,19 @@ class ObservableRouterPT:
         mean = self.par_total[cpi] / self.count_values
         err = np.zeros(self.width)
         if self.sweeps - self.last_sweep_logged <= self.measure_interval:
-            if self.jk_blocks > 1:
+            # an error estimate needs several jackknife blocks, and blocks of a fixed size (mpiobservablehandlerpt.h:196)
+            if self.jk_blocks > 1 and not self.sweeps_has_changed:
                 block_samples = self.count_values // self.jk_blocks
                 total_samples = self.count_values - block_samples
                 blocks = self.par_jk[cpi] / total_samples
                 bc = self.jk_blocks
                 err = np.sqrt((bc - 1.0) / bc * np.sum((mean[None, :] - blocks) ** 2, axis=0))      # jackknife(), statistics.h:132-144
-            elif self.timeseries and len(self.par_series[cpi]) == self.count_values:
-                ns = len(self.scalar_names)
-                ts = np.array(self.par_series[cpi])
-                err[:ns] = np.sqrt(np.mean((ts - mean[None, :ns]) ** 2, axis=0))
+        # scalar observables with a single block: standard deviation of the buffered time series, variance() of
+        # statistics.h:36-46 divides by N - 1 (mpiobservablehandlerpt.cpp:98-100; outside the end-of-run condition there too)
+        if self.jk_blocks <= 1 and self.timeseries and len(self.par_series[cpi]) == self.count_values and self.count_values > 1:
+            ns = len(self.scalar_names)
+            ts = np.array(self.par_series[cpi])
+            err[:ns] = np.sqrt(np.sum((ts - mean[None, :ns]) ** 2, axis=0) / (len(ts) - 1))
         return mean, err
 
     def write_results(self, directory, parameter_name, meta_model=None, meta_mc=None, meta_pt=None):
@@ -331,15 +338,18 @@ class ObservableRouterPT:
             mean, err = self.evaluate_jackknife(cpi)
             mm = dict(meta_model or {})
             mm[parameter_name] = num_to_string(float(value))                          # par_metaModel[cpi]: only that entry replaced
-            meta = [mm, dict(meta_mc or {}), dict(meta_pt or {})]
+            meta = [("meta", mm), ("meta", dict(meta_mc or {})), ("meta", dict(meta_pt or {}))]
             ns = len(self.scalar_names)
             order = sorted(range(ns), key=lambda i: self.scalar_names[i])               # std::map<std::string, num>: sorted by name
-            _write_data_map(os.path.join(sub, "results.values"), ["Monte Carlo results for observable expectation values", "observable\t value \t error"],
-                            meta, "observable", [(self.scalar_names[i], mean[i], err[i]) for i in order])
+            _write_data_map(os.path.join(sub, "results.values"),
+                            [("text", "Monte Carlo results for observable expectation values")] + meta +
+                            [("kv", "key", "observable"), ("text", "observable\t value \t error")],
+                            [(self.scalar_names[i], mean[i], err[i]) for i in order])
             o = ns
-            for name, l in self.vector_specs:
+            for name, l in self.vector_specs:                                           # :286-297
                 _write_data_map(os.path.join(sub, "results-%s.values" % name),
-                                ["Monte Carlo results for vector observable %s expectation values" % name, "site\t value \t error"], meta, "site",
+                                [("text", "Monte Carlo results for vector observable %s expectation values" % name)] + meta +
+                                [("kv", "key", "site"), ("kv", "observable", name), ("text", "key\t value \t error")],
                                 [(float(i), mean[o + i], err[o + i]) for i in range(l)])
                 o += l
 
@@ -351,18 +361,116 @@ def write_exchange_statistics(state: ExchangeState, directory, meta=None):
     if not state.current_process_par:
         return
     n = len(state.controlParameterValues)
-    meta = [dict(m) for m in (meta or [])] if isinstance(meta, (list, tuple)) else [dict(meta or {})]
+    metas = [("meta", dict(m)) for m in (meta or [])] if isinstance(meta, (list, tuple)) else [("meta", dict(meta or {}))]
     acc = [(state.par_swapUpAccepted[c] / state.par_swapUpProposed[c]) if state.par_swapUpProposed[c] else 0.0 for c in range(n)]
     df = []
     for c in range(n):
         up, down = state.par_countGoingUp[c], state.par_countGoingDown[c]
         df.append(up / (up + down) if (up + down) else 0.0)
+    key = [("kv", "key", "control parameter index")]
     _write_data_map(os.path.join(directory, "exchange-parameters.values"),
-                    ["Control parameter values", "control parameter index \t control parameter value"], meta, "control parameter index",
+                    metas + key + [("text", "Control parameter values"), ("text", "control parameter index \t control parameter value")],
                     [(c, float(state.controlParameterValues[c])) for c in range(n)])
     _write_data_map(os.path.join(directory, "exchange-acceptance.values"),
-                    ["Acceptance ratio of exchanging replicas at control parameters (upwards)", "control parameter index \t acceptance ratio"],
-                    meta, "control parameter index", [(c, acc[c]) for c in range(n)])
+                    metas + key + [("text", "Acceptance ratio of exchanging replicas at control parameters (upwards)"),
+                                   ("text", "control parameter index \t acceptance ratio")], [(c, acc[c]) for c in range(n)])
     _write_data_map(os.path.join(directory, "exchange-diffusion.values"),
-                    ["Diffusion fraction of replicas at control parameters: df = nUp / (nUp + nDown)", "control parameter index \t diffusion fraction"],
-                    meta, "control parameter index", [(c, df[c]) for c in range(n)])
+                    metas + key + [("text", "Diffusion fraction of replicas at control parameters: df = nUp / (nUp + nDown)"),
+                                   ("text", "control parameter index \t diffusion fraction")], [(c, df[c]) for c in range(n)])
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's configuration file and metadata headers, so that a run of scripts/run_pt.py on the reference's own
+# simulation.conf writes the reference's own output tree (checked file by file against the tree the reference's
+# detqmcptsdwo2 wrote: tests/golden/detqmcpt_run_o2_L4/expected, tests/test_gpu_parity.py).
+# ---------------------------------------------------------------------------------------------------------------------
+def parse_simulation_conf(path):
+    """boost::program_options config-file syntax as the reference uses it (src/mpimaindetqmcptsdwopdim.cpp:60-262):
+    `key = value` lines, `#` comments, a repeated key builds a list (rValues)."""
+    conf = {}
+    for raw in open(path):
+        line = raw.split("#", 1)[0].strip()
+        if not line:
+            continue
+        k, v = [t.strip() for t in line.split("=", 1)]
+        if k in conf:
+            if not isinstance(conf[k], list):
+                conf[k] = [conf[k]]
+            conf[k].append(v)
+        else:
+            conf[k] = v
+    return conf
+
+
+def _b(v):
+    return str(v).strip().lower() in ("1", "true", "yes", "on")
+
+
+def reference_metadata(conf, rvalues):
+    """(model, mc, pt) metadata maps of a replica-exchange run as the reference prints them: prepareModelMetadataMap
+    (src/detsdwopdim.cpp:363-438: numbers through numToString, the global-move switches as 0 / 1, the others as true / false),
+    DetQMCParams::prepareMetadataMap (src/detqmcparams.cpp:60-98), DetQMCPTParams::prepareMetadataMap (src/detqmcptparams.cpp:40-68).
+    Values are strings; `r` is filled in per control parameter by the caller."""
+    g = lambda k, d: conf.get(k, d)
+    f = lambda k, d: num_to_string(float(g(k, d)))
+    tf = lambda k, d: "true" if _b(g(k, d)) else "false"
+    i01 = lambda k, d: "1" if _b(g(k, d)) else "0"
+    L = int(g("L", 4))
+    m = int(g("m", 0)) or int(round(float(g("beta", 0)) / float(g("dtau", 0.1))))
+    dtau = float(g("dtau", 0.1))
+    model = {
+        "model": "sdw", "opdim": str(int(g("opdim", 3))), "L": str(L), "N": str(L * L), "d": "2", "m": str(m), "s": str(int(g("s", 1))),
+        "beta": num_to_string(m * dtau), "dtau": f("dtau", 0.1), "accRatio": f("accRatio", 0.5), "bc": g("bc", "pbc"), "c": f("c", 1.0),
+        "cdwU": f("cdwU", 0.0), "checkerboard": tf("checkerboard", "false"), "delaySteps": str(int(g("delaySteps", 16))),
+        "dumpGreensFunction": tf("dumpGreensFunction", "false"), "globalShift": i01("globalShift", "false"),
+        "globalUpdateInterval": str(int(g("globalUpdateInterval", 100))), "lambda": f("lambda", 1.0), "mu": f("mu", 0.5),
+        "overRelaxation": tf("overRelaxation", "false"), "phi2bosons": tf("phi2bosons", "false"), "phiFixed": tf("phiFixed", "false"),
+        "repeatUpdateInSlice": str(int(g("repeatUpdateInSlice", 1))), "spinProposalMethod": g("spinProposalMethod", "box"),
+        "turnoffFermionMeasurements": tf("turnoffFermionMeasurements", "false"), "turnoffFermions": tf("turnoffFermions", "false"),
+        "txhor": f("txhor", -1.0), "txver": f("txver", -0.5), "tyhor": f("tyhor", 0.5), "tyver": f("tyver", 1.0), "u": f("u", 1.0),
+        "updateMethod": g("updateMethod", "iterative"), "weakZflux": tf("weakZflux", "false"),
+        "wolffClusterShiftUpdate": i01("wolffClusterShiftUpdate", "false"), "wolffClusterUpdate": i01("wolffClusterUpdate", "false"),
+    }
+    mi = int(g("measureInterval", 1))
+    mc = {
+        "greenUpdateType_string": g("greenUpdateType", "stabilized"), "jkBlocks": str(int(g("jkBlocks", 1))), "measureInterval": str(mi),
+        "rngSeed": str(int(g("rngSeed", 0))), "saveConfigurationStreamBinary": tf("saveConfigurationStreamBinary", "false"),
+        "saveConfigurationStreamInterval": str(int(g("saveConfigurationStreamInterval", mi))),
+        "saveConfigurationStreamText": tf("saveConfigurationStreamText", "false"), "saveInterval": str(int(g("saveInterval", 0))),
+        "simindex": str(int(g("simindex", 0))), "sweeps": str(int(g("sweeps", 0))), "thermalization": str(int(g("thermalization", 0))),
+        "timeseries": tf("timeseries", "false"),
+    }
+    pt = {"controlParameterName": "r", "controlParameterValues": " ".join(num_to_string(float(v)) for v in rvalues),
+          "exchangeInterval": str(int(g("exchangeInterval", 1)))}
+    return model, mc, pt
+
+
+def write_timeseries(router, directory, parameter_name, meta_model, meta_mc, meta_pt):
+    """<obs>.series per control parameter (ScalarObservableHandlerPT::outputTimeseries, src/mpiobservablehandlerpt.cpp:105-160):
+    one value per line at the stream's default precision; rank 0 only"""
+    import os
+    if not router.is_root or not router.timeseries:
+        return
+    for cpi in range(router.nproc):
+        sub = os.path.join(directory, control_parameter_subdir(cpi, parameter_name, router.state.controlParameterValues[cpi]))
+        os.makedirs(sub, exist_ok=True)
+        mm = dict(meta_model or {})
+        mm[parameter_name] = num_to_string(float(router.state.controlParameterValues[cpi]))
+        for i, name in enumerate(router.scalar_names):
+            with open(os.path.join(sub, name + ".series"), "w") as f:
+                f.write("## Timeseries for observable %s\n" % name)
+                for meta in (mm, meta_mc or {}, meta_pt or {}):
+                    for k in sorted(meta):
+                        f.write("# %s = %s\n" % (k, meta[k]))
+                f.write("# observable = %s\n" % name)
+                for row in router.par_series[cpi]:
+                    f.write("%s\n" % num_to_string(float(row[i])))
+
+
+def write_config_infoheader(directory, meta_model, meta_mc, meta_pt):
+    """configs-phi.infoheader next to a configuration stream (src/detsdwsystemconfig.cpp:60-96)"""
+    import os
+    with open(os.path.join(directory, "configs-phi.infoheader"), "w") as f:
+        for meta in (meta_model, meta_mc, meta_pt):
+            for k in sorted(meta):
+                f.write("#%s = %s\n" % (k, meta[k]))
+        f.write("## binary phi configuration stream (64 bit double precision floats) in file configs-phi.binarystream\n")

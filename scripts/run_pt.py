@@ -42,7 +42,12 @@ def main():
     ap.add_argument("--out", default=None, help="directory for the per-parameter results tree (rank 0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--one-device", action="store_true", help="all ranks drive GPU 0 (rehearsal on a one-GPU box, needs --backend gloo)")
+    ap.add_argument("--conf", default=None, help="the reference's simulation.conf (mpimaindetqmcptsdwopdim): run THAT simulation -- thermalization, "
+                    "measurement sweeps, replica exchange, per-parameter results / time series / configuration streams -- and write the "
+                    "reference's output tree into --out (default: the directory of the file)")
     a = ap.parse_args()
+    if a.conf:
+        return run_conf(a)
 
     import torch
     from detqmc_amd import DetSDWBatch, SDWParams
@@ -111,6 +116,119 @@ def main():
     if rank == 0:
         acc = [("%d/%d" % (x, y)) for x, y in zip(st.par_swapUpAccepted[:-1], st.par_swapUpProposed[:-1])]
         print("swap up accepted/proposed per parameter pair: " + " ".join(acc), flush=True)
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_conf(a):
+    """DetQMCPT<DetSDW>::run (src/detqmcpt.h:761-958) for the reference's own configuration file: every rank holds
+    len(rValues) / world replicas in one DetSDWBatch; global replica p has the RNG stream of the reference's process p
+    (RngWrapper(rngSeed, (simindex + 1) (p + 1)), src/detqmcpt.h:301)."""
+    import torch
+    from detqmc_amd import DetSDWBatch, SDWParams
+    from detqmc_amd import pt as PT
+
+    conf = PT.parse_simulation_conf(a.conf)
+    out = a.out or os.path.dirname(os.path.abspath(a.conf))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    dist, device = None, "cpu"
+    if world > 1:
+        import torch.distributed as dist
+        if a.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            device = "cuda"
+        else:
+            dist.init_process_group("gloo")
+    rvals = [float(v) for v in (conf["rValues"] if isinstance(conf["rValues"], list) else [conf["rValues"]])]
+    nproc = len(rvals)
+    if nproc % world:
+        raise SystemExit("Number of processes %d does not divide the number of control parameter values %d" % (world, nproc))
+    per = nproc // world
+    g = lambda k, d: conf.get(k, d)
+    if g("model", "sdw") != "sdw" or g("spinProposalMethod", "box") != "box" or PT._b(g("turnoffFermions", "false")):
+        raise SystemExit("run_pt.py --conf: only model = sdw with box proposals and fermions switched on")
+    simindex = int(g("simindex", 0))
+    kw = dict(opdim=int(g("opdim", 3)), L=int(g("L", 4)), dtau=float(g("dtau", 0.1)), s=int(g("s", 1)), c=float(g("c", 1.0)),
+              u=float(g("u", 1.0)), lambda_=float(g("lambda", 1.0)), txhor=float(g("txhor", -1.0)), txver=float(g("txver", -0.5)),
+              tyhor=float(g("tyhor", 0.5)), tyver=float(g("tyver", 1.0)), mu=float(g("mu", 0.5)), accRatio=float(g("accRatio", 0.5)),
+              delaySteps=int(g("delaySteps", 16)), updateMethod=g("updateMethod", "iterative"), bc=g("bc", "pbc"),
+              weakZflux=PT._b(g("weakZflux", "false")), globalShift=PT._b(g("globalShift", "false")),
+              wolffClusterUpdate=PT._b(g("wolffClusterUpdate", "false")), wolffClusterShiftUpdate=PT._b(g("wolffClusterShiftUpdate", "false")),
+              globalUpdateInterval=int(g("globalUpdateInterval", 100)), checkerboard=PT._b(g("checkerboard", "false")),
+              fermionMeasurements=not PT._b(g("turnoffFermionMeasurements", "false")), rngSeed=int(g("rngSeed", 0)),
+              cdwU=float(g("cdwU", 0.0)), stabilisation=a.stabilisation, device=local)
+    if "m" in conf:
+        kw["m"] = int(conf["m"])
+    else:
+        kw["beta"] = float(conf["beta"])
+    p0 = SDWParams(**kw)
+    mine = [rank * per + b for b in range(per)]
+    batch = DetSDWBatch([dataclasses.replace(p0, r=rvals[p], simindex=(simindex + 1) * (p + 1) - 1) for p in mine])
+    reps = [PT.ReplicaAdapter(batch.chain(b)) for b in range(per)]
+    st = PT.ExchangeState.create(rvals, rank, world, per)
+    therm, sweeps = int(g("thermalization", 0)), int(g("sweeps", 0))
+    mi, xi = int(g("measureInterval", 1)), int(g("exchangeInterval", 1))
+    csi = int(g("saveConfigurationStreamInterval", mi))
+    save_bin = PT._b(g("saveConfigurationStreamBinary", "false"))
+    timeseries = PT._b(g("timeseries", "false"))
+    opdim, N = kw["opdim"], kw["L"] ** 2
+    scalars = ["normMeanPhi", "associatedEnergy"] + (["phiRhoS_Gs", "phiRhoS_Gc"] if opdim == 2 else [])
+    vectors = []
+    if kw["fermionMeasurements"]:
+        scalars += ["pairPlusMax", "pairMinusMax", "greenK0", "greenLocal", "occDiffSq"]
+        vectors = [("kOccX", N), ("kOccY", N), ("pairPlus", N), ("pairMinus", N)]
+    router = PT.ObservableRouterPT(st, scalars, vectors, sweeps=sweeps, jk_blocks=int(g("jkBlocks", 1)), measure_interval=mi, timeseries=timeseries)
+    meta_model, meta_mc, meta_pt = PT.reference_metadata(conf, rvals)
+    subdir = lambda cpi: os.path.join(out, PT.control_parameter_subdir(cpi, "r", rvals[cpi]))
+
+    def exchange(done):
+        if xi != 0 and done % xi == 0:
+            PT.replica_exchange_step(reps, st, dist, device=device)
+        if a.check:
+            PT.replica_exchange_consistency_check(reps, st, dist, device=device)
+
+    for sw in range(1, therm + 1):                                       # stage T
+        batch.sweepThermalization()
+        exchange(sw)
+    if save_bin:                                                          # setup_SaveConfigurations (:662-699)
+        for cpi in st.local_parameter_indices if world > 1 else range(nproc):
+            os.makedirs(subdir(cpi), exist_ok=True)
+    sw_counter = 0
+    for done in range(sweeps):                                            # stage M; `done` = sweepsDone before the sweep
+        sw_counter += 1
+        measure = sw_counter % mi == 0
+        batch.sweep(measure)
+        if measure:
+            vals = []
+            for b in range(per):
+                c = batch.chain(b)
+                o = c.observables
+                vals.append(({n: getattr(o, n) for n in scalars}, {n: c.observable_vector(n) for n, _ in vectors}))
+            router.insert(done, vals, dist, device)
+            if save_bin and sw_counter % csi == 0:
+                # buffer_local_system_configuration / gather_and_output_buffered_system_configurations (:703-757): the
+                # configuration is filed under the control parameter its replica holds NOW
+                for b in range(per):
+                    d = subdir(st.local_parameter_indices[b])
+                    os.makedirs(d, exist_ok=True)
+                    batch.chain(b).saveConfigurationStreamBinary(d)
+        if done + 1 < sweeps:                                             # the last sweep ends the loop: stage F, no exchange (:946-956)
+            exchange(therm + done + 1)
+    if rank == 0:
+        os.makedirs(out, exist_ok=True)
+        router.write_results(out, "r", meta_model, meta_mc, meta_pt)
+        PT.write_timeseries(router, out, "r", meta_model, meta_mc, meta_pt)
+        PT.write_exchange_statistics(st, out, [{k: v for k, v in meta_model.items() if k != "r"}, meta_mc, meta_pt])
+        if save_bin:
+            for cpi in range(nproc):
+                mm = dict(meta_model)
+                mm["r"] = PT.num_to_string(rvals[cpi])
+                PT.write_config_infoheader(subdir(cpi), mm, meta_mc, meta_pt)
+        print("Measurements finished", flush=True)
     batch.close()
     if dist is not None:
         dist.barrier()

@@ -114,27 +114,15 @@ def _mpilib():
             os.symlink(os.path.join("/opt/conda/lib", lib), dst)
 
 
-def test_detqmcpt_driver_with_gpu_model_over_mpi_writes_the_reference_output_tree(tmp_path):
-    """mpiexec -n 4 detqmcptsdwgpu: DetQMCPT<DetSDWGpu, ModelParamsDetSDW> -- the reference's own replicaExchangeStep,
-    per-control-parameter observable handlers, exchange statistics and per-parameter configuration streams, every replica on
-    the GPU (4 processes, one card) -- against the output tree the reference's CPU program (mpiexec -n 4 detqmcptsdwo2_ref)
-    wrote for the same configuration file: p<cpi>_r<value>/{results*.values, *.series, configs-phi.binarystream},
-    exchange-{parameters,acceptance,diffusion}.values."""
-    assert os.path.exists(PT_EXE), "oracle/_ref/detqmcptsdwgpu missing: run `make -C oracle/ref_build detqmcptsdwgpu` in the build container"
-    assert os.path.exists(MPIEXEC), "MPICH launcher of the image not found"
-    _mpilib()
-    shutil.copy(os.path.join(PT_CASE, "simulation.conf"), tmp_path)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([MPIEXEC, "-n", "4", PT_EXE, "-c", "simulation.conf"], cwd=str(tmp_path), capture_output=True, text=True,
-                         timeout=900, env=env)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    assert "Measurements finished" in out.stdout
+def _compare_pt_tree(workdir):
+    """every file of tests/golden/detqmcpt_run_o2_L4/expected (written by the reference's CPU program `mpiexec -n 4 detqmcptsdwo2_ref`):
+    metadata headers equal line by line, values to 1e-9, jackknife errors to 1e-5, configuration streams byte for byte"""
     exp = os.path.join(PT_CASE, "expected")
     nfiles = 0
     for dirpath, _, files in os.walk(exp):
         rel = os.path.relpath(dirpath, exp)
         for fn in sorted(files):
-            want, got = os.path.join(dirpath, fn), os.path.join(str(tmp_path), rel, fn)
+            want, got = os.path.join(dirpath, fn), os.path.join(workdir, rel, fn)
             assert os.path.exists(got), "the GPU-backed replica-exchange run did not write " + os.path.join(rel, fn)
             nfiles += 1
             if fn.endswith(".binarystream"):
@@ -154,10 +142,57 @@ def test_detqmcpt_driver_with_gpu_model_over_mpi_writes_the_reference_output_tre
                         assert x == y, fn
                         continue
                     tol = 1e-5 if (fn.startswith("results") and j == len(ra) - 1) else 1e-9
+                    if fn.endswith(".series"):
+                        tol = 2e-6                      # six significant digits in the file
                     assert abs(fx - fy) <= tol * max(abs(fy), 1e-3), (rel, fn, ra, rb)
     assert nfiles == 4 * 16 + 3
+
+
+def test_detqmcpt_driver_with_gpu_model_over_mpi_writes_the_reference_output_tree(tmp_path):
+    """mpiexec -n 4 detqmcptsdwgpu: DetQMCPT<DetSDWGpu, ModelParamsDetSDW> -- the reference's own replicaExchangeStep,
+    per-control-parameter observable handlers, exchange statistics and per-parameter configuration streams, every replica on
+    the GPU (4 processes, one card) -- against the output tree the reference's CPU program (mpiexec -n 4 detqmcptsdwo2_ref)
+    wrote for the same configuration file: p<cpi>_r<value>/{results*.values, *.series, configs-phi.binarystream},
+    exchange-{parameters,acceptance,diffusion}.values."""
+    assert os.path.exists(PT_EXE), "oracle/_ref/detqmcptsdwgpu missing: run `make -C oracle/ref_build detqmcptsdwgpu` in the build container"
+    assert os.path.exists(MPIEXEC), "MPICH launcher of the image not found"
+    _mpilib()
+    shutil.copy(os.path.join(PT_CASE, "simulation.conf"), tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([MPIEXEC, "-n", "4", PT_EXE, "-c", "simulation.conf"], cwd=str(tmp_path), capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "Measurements finished" in out.stdout
+    _compare_pt_tree(str(tmp_path))
     for p in range(4):
         assert os.path.exists(tmp_path / ("simulation.%d.state" % p))
+
+
+@pytest.mark.parametrize("launch", ["one process, 4 replicas in one batch", "2 processes x 2 replicas (gloo)"])
+def test_python_replica_exchange_driver_writes_the_reference_output_tree(tmp_path, launch):
+    """The repo's OWN replica-exchange driver -- scripts/run_pt.py over detqmc_amd/pt.py (replica_exchange_step, ObservableRouterPT,
+    write_exchange_statistics, time series, per-parameter configuration streams) -- run on the reference's configuration file must
+    write the tree the reference's `mpiexec -n 4 detqmcptsdwo2` wrote: same exchange decisions (DetQMCPT::replicaExchangeStep,
+    /root/reference/src/detqmcpt.h:963-1118), same per-control-parameter accumulation and jackknife errors
+    (src/mpiobservablehandlerpt.cpp:65-110, 176-215), same exchange-*.values (src/detqmcpt.h:596-660).  Once with all four replicas
+    in one batch on one rank, once spread over two ranks (torch.distributed, gloo, both on the one GPU of the box)."""
+    import sys
+    shutil.copy(os.path.join(PT_CASE, "simulation.conf"), tmp_path)
+    script = os.path.join(ROOT, "scripts", "run_pt.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if launch.startswith("one"):
+        cmd = [sys.executable, script, "--conf", "simulation.conf", "--stabilisation", "svd"]
+    else:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script, "--conf", "simulation.conf", "--backend", "gloo", "--one-device", "--check"]
+    out = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "Measurements finished" in out.stdout
+    _compare_pt_tree(str(tmp_path))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -205,3 +205,53 @@ def test_observables_are_routed_to_the_control_parameter_two_ranks_gloo(tmp_path
     drow = [l.split("\t") for l in open(tmp_path / "exchange-diffusion.values").read().splitlines() if not l.startswith("#")]
     for c in range(4):
         assert abs(float(drow[c][1]) - (up[c] / (up[c] + down[c]) if up[c] + down[c] else 0.0)) < 1e-14
+
+
+def test_reference_metadata_headers_match_the_reference_output_tree(tmp_path):
+    """parse_simulation_conf + reference_metadata + the data-map writers reproduce, line by line, the headers of the files the
+    reference's detqmcptsdwo2 wrote for tests/golden/detqmcpt_run_o2_L4/simulation.conf (DataMapWriter,
+    /root/reference/src/datamapwriter.h:116-160; metadata maps src/detsdwopdim.cpp:363-438, src/detqmcparams.cpp:60-98,
+    src/detqmcptparams.cpp:40-68); the numbers are checked on the GPU (tests/test_gpu_detqmc_shim.py)."""
+    import os
+    import numpy as np
+    from detqmc_amd import pt as PT
+    case = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detqmcpt_run_o2_L4")
+    conf = PT.parse_simulation_conf(os.path.join(case, "simulation.conf"))
+    rvals = [float(v) for v in conf["rValues"]]
+    assert rvals == [-1.3, -1.2, -1.1, -1.0]
+    mm, mc, mp = PT.reference_metadata(conf, rvals)
+    st = PT.ExchangeState.create(rvals, 0, 1, 4)
+    scal = ["normMeanPhi", "associatedEnergy", "phiRhoS_Gs", "phiRhoS_Gc", "pairPlusMax", "pairMinusMax", "greenK0", "greenLocal", "occDiffSq"]
+    router = PT.ObservableRouterPT(st, scal, [("kOccX", 16), ("kOccY", 16), ("pairPlus", 16), ("pairMinus", 16)], sweeps=20, jk_blocks=5,
+                                   measure_interval=2, timeseries=True)
+    rng = np.random.default_rng(1)
+    for sw in range(1, 20, 2):
+        router.insert(sw, [({n: rng.random() for n in scal}, {n: rng.random(16) for n in ("kOccX", "kOccY", "pairPlus", "pairMinus")})
+                           for _ in range(4)], None)
+    router.write_results(tmp_path, "r", mm, mc, mp)
+    PT.write_timeseries(router, tmp_path, "r", mm, mc, mp)
+    PT.write_exchange_statistics(st, tmp_path, [{k: v for k, v in mm.items() if k != "r"}, mc, mp])
+    for cpi in range(4):
+        m2 = dict(mm)
+        m2["r"] = PT.num_to_string(rvals[cpi])
+        PT.write_config_infoheader(os.path.join(tmp_path, PT.control_parameter_subdir(cpi, "r", rvals[cpi])), m2, mc, mp)
+    hdr = lambda p: [l for l in open(p) if l.startswith("#")]
+    nfiles = 0
+    for dirpath, _, files in os.walk(os.path.join(case, "expected")):
+        rel = os.path.relpath(dirpath, os.path.join(case, "expected"))
+        for fn in files:
+            if fn.endswith(".binarystream"):
+                continue
+            got = os.path.join(tmp_path, rel, fn)
+            assert os.path.exists(got), os.path.join(rel, fn)
+            assert hdr(got) == hdr(os.path.join(dirpath, fn)), os.path.join(rel, fn)
+            nfiles += 1
+    assert nfiles == 4 * 15 + 3
+    # single-block error estimate: standard deviation with N - 1 (variance(), src/statistics.h:36-46)
+    r1 = PT.ObservableRouterPT(st, ["x"], [], sweeps=4, jk_blocks=1, measure_interval=1, timeseries=True)
+    xs = [[0.1, 0.4, 0.2, 0.9], [1.0, 2.0, 4.0, 8.0], [0, 0, 0, 1.0], [3.0, 3.0, 3.0, 3.0]]
+    for sw in range(4):
+        r1.insert(sw, [({"x": xs[p][sw]}, {}) for p in range(4)], None)
+    for p in range(4):
+        mean, err = r1.evaluate_jackknife(p)
+        assert abs(mean[0] - np.mean(xs[p])) < 1e-15 and abs(err[0] - np.std(xs[p], ddof=1)) < 1e-15
