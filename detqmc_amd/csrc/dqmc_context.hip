@@ -510,6 +510,12 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     memset(&hm, 0, sizeof(hm));
     hm.opdim = p->opdim; hm.MSF = MSF; hm.L = p->L; hm.N = N; hm.ng = ng; hm.m = p->m; hm.s = p->s; hm.n = c->n;
     hm.D = p->delaySteps; hm.P = N / 4; hm.phi2bosons = p->phi2bosons;
+    // proposals per delayed-update block: twice the block depth (the step-size adaptation steers the acceptance to
+    // accRatio = 0.5), never below it (dqmc_update_slice launches ceil(N / D) rounds); DQMC_PROPOSAL_BUDGET overrides, 0 = no limit.
+    // Shallow blocks (woodbury / iterative: D = 1) gain nothing from it.
+    hm.pbudget = p->delaySteps >= 8 ? 2 * p->delaySteps : 0;
+    if (getenv("DQMC_PROPOSAL_BUDGET")) hm.pbudget = atoi(getenv("DQMC_PROPOSAL_BUDGET"));
+    if (hm.pbudget > 0 && hm.pbudget < p->delaySteps) hm.pbudget = p->delaySteps;
 #ifdef DQMC_DECIDE_TIMING
     hm.dbg = (getenv("DQMC_DECIDE_TIMING") && atoi(getenv("DQMC_DECIDE_TIMING"))) ? 8 : 0;   // phase timers of k_update_decide; never changes a result
 #endif
@@ -613,7 +619,8 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     }
     A_(alloc_slot(c, c->eye));
     const int WD = MSF * c->D;
-    A_(dalloc(c, &c->X, (size_t)ng * WD)); A_(dalloc(c, &c->Gr, (size_t)WD * ng)); A_(dalloc(c, &c->W, (size_t)WD * WD));
+    const int WD8 = (WD + 7) & ~7;          // X and GrT are zero padded to a multiple of 8 columns for the flush kernel
+    A_(dalloc(c, &c->X, (size_t)ng * WD8)); A_(dalloc(c, &c->Gr, (size_t)WD8 * ng)); A_(dalloc(c, &c->W, (size_t)WD * WD));
     c->uni_cap = (size_t)(p->opdim + 1) * N * p->m + 64;     // one sweep's worst case
     A_(dalloc(c, &c->uniforms, c->uni_cap));
     A_(dalloc(c, &c->us, 1));
@@ -1114,7 +1121,7 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
             launch_update_gather(c->lc, c->hm, c->us, c->G, c->W, c->X, c->Gr);
         }
         ProfScope ps(c, FAM_FLUSH, 1);
-        launch_flush(c->lc, c->X, c->n_g, c->Gr, WD, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
+        launch_flush(c->lc, c->X, c->Gr, c->n_g, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
     }
     return finish(c, "dqmc_update_slice");
 }

@@ -52,6 +52,7 @@ __device__ __forceinline__ void xcd_chain_tile(int tiles, int nb, int& chain, in
 struct DevModel {
     int opdim, MSF, L, N, ng, m, s, n, D, P;   // P = plaquettes per subgroup = N/4
     int phi2bosons;
+    int pbudget;       // proposals per delayed-update block (0: no limit); a launch-balancing knob, the chain does not depend on it
     int dbg;           // bit 3: phase timers of k_update_decide; only ever set in builds with -DDQMC_DECIDE_TIMING (always 0 otherwise)
     int dense;         // CB_NONE: the hopping part is a dense GEMM done by the host loop, the chain kernel
                        // only applies e^{+-dtau V}; ov/ovinv are 1 (mu sits inside propK)
@@ -126,8 +127,9 @@ struct GemmArgs {
                                 // name (template argument), so that profiles keep it apart from the model's n_g^3 products
 };
 void launch_gemm(const Launch& lc, const GemmArgs& a);
-// G += X Gr, K = min(Kmax, *Kdev * Kmul): the delayed-update flush as a register-only read-modify-write stream
-void launch_flush(const Launch& lc, const cplx* X, int ldx, const cplx* Gr, int ldg, cplx* G, int ldc, int n, int Kmax,
+// G += X GrT^T, K = min(Kmax, *Kdev * Kmul): the delayed-update flush as a register-only read-modify-write stream.  X and GrT are
+// n x K8 (K8 = K rounded up to a multiple of 8, columns K .. K8 - 1 zero), both with leading dimension ld
+void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx* G, int ldc, int n, int Kmax,
                   const int* Kdev, int Kmul);
 
 // one-sided Jacobi SVD, M = U diag(d) V^H, d descending.  work: A (n*n), V (n*n), norms(n), rank(n),
@@ -152,7 +154,7 @@ int svd_block_cols(int n);      // columns per block used by the Jacobi kernel f
 void launch_update_decide(const Launch& lc, const DevModel* dm, const DevModel& hm, DevUpdateState* us,
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal);
 void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,
-                          const cplx* W, cplx* X, cplx* Gr);
+                          const cplx* W, cplx* X, cplx* GrT);
 
 // Hubbard replica (kernels_hubbard.hip)
 void launch_hubbard_vscale(const Launch& lc, const DevModel& hm, int side, int inverse, int k, cplx* A, int lda);

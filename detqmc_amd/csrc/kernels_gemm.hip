@@ -24,7 +24,10 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template<int TM, int TN, bool M3, int TAG>
+// OPA / OPB (op = conjugate transpose) are template parameters: as run-time flags the two addressing variants of each operand were
+// two branches in the tile loop, and the compiler -- reusing the registers of one variant as addresses of the other -- waited for
+// ALL outstanding loads (s_waitcnt vmcnt(0)) between them, in front of the MFMA block of every tile.
+template<int TM, int TN, bool M3, int TAG, bool OPA, bool OPB>
 __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb) {   // 2 workgroups per CU: <= 256 registers
     constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16;
     constexpr int NA = BM * BK / 256, NB_ = BN * BK / 256;      // elements of the A / B tile staged per thread
@@ -56,30 +59,44 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
         for (int b = 0; b < TN; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); if (M3) acc_p2[a][b] = (v4d)(0.0); }
 
     cplx ra[NA], rb[NB_];
+    double rsc[NA];
+    bool oka[NA], okb[NB_];
     // global -> registers: op(A) tile element (i, k), op(B) tile element (k, j).  Every load has a clamped, always valid
-    // address and the bounds are applied afterwards by a select: guarded loads compile to one exec-masked branch +
-    // s_waitcnt vmcnt(0) per element, which serialises the eight loads of a tile instead of keeping them in flight
-    // behind the MFMAs of the previous tile.
+    // address; NOTHING is done with the loaded values here -- bounds (select), conjugation and the k-scale are applied in
+    // sstore(), i.e. AFTER the MFMAs of the tile before.  (Round 2 applied the select right after the load: the compiler put
+    // s_waitcnt vmcnt(..) + v_cndmask in front of the MFMA block, so every tile waited for its successor's loads before it
+    // started computing -- the double buffering overlapped nothing.)
     const int Mm1 = g.M - 1, Nm1 = g.N - 1;
+    // column gather of A (a_kgather): the indices of a tile are requested ONE TILE AHEAD, so the dependent index -> element
+    // chain never sits in front of an MFMA block
+    // Optional operands (gather list, k-scale) are loaded UNCONDITIONALLY, from a stand-in address inside A when absent: a
+    // conditional load leaves a phi (loaded value | old value) behind, and the compiler guards the "old value" arm with
+    // s_waitcnt vmcnt(0) -- in the common case without k-scale that wait sat right behind the tile's A loads.
+    const bool has_gather = !OPA && g.a_kgather != nullptr, has_kscale = g.kscale != nullptr;
+    const int* kgather = has_gather ? g.a_kgather : (const int*)g.A;          // K ints resp. K doubles are inside A (>= K columns of 16 lda bytes)
+    const double* kscale = has_kscale ? g.kscale : (const double*)g.A;
+    int cnext[NA];
+    auto gidx = [&](int k0) {
+        if (!OPA) {
+#pragma unroll
+            for (int e = 0; e < NA; ++e) cnext[e] = kgather[min(k0 + (tid + e * 256) / BM, K - 1)];
+        }
+    };
     auto gload = [&](int k0) {
         const int Km1 = K - 1;
         int ka[NA];
-        bool oka[NA];
-        if (g.opA == 0) {
+        if (!OPA) {
             int ia[NA], ca[NA];
 #pragma unroll
             for (int e = 0; e < NA; ++e) {
                 const int idx = tid + e * 256;
                 const int gi = i0 + idx % BM, gk = k0 + idx / BM;
                 oka[e] = gi < g.M && gk < K;
-                ia[e] = min(gi, Mm1); ka[e] = min(gk, Km1); ca[e] = ka[e];
-            }
-            if (g.a_kgather) {
-#pragma unroll
-                for (int e = 0; e < NA; ++e) ca[e] = g.a_kgather[ka[e]];
+                ia[e] = min(gi, Mm1); ka[e] = min(gk, Km1); ca[e] = has_gather ? cnext[e] : ka[e];
             }
 #pragma unroll
             for (int e = 0; e < NA; ++e) ra[e] = g.A[(size_t)ca[e] * g.lda + ia[e]];
+            gidx(k0 + BK);
         } else {
 #pragma unroll
             for (int e = 0; e < NA; ++e) {
@@ -87,63 +104,57 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
                 const int gk = k0 + idx % BK, gi = i0 + idx / BK;
                 oka[e] = gi < g.M && gk < K;
                 ka[e] = min(gk, Km1);
-                const cplx t = g.A[(size_t)min(gi, Mm1) * g.lda + ka[e]];
-                ra[e] = make_double2(t.x, -t.y);
-            }
-        }
-        if (g.kscale) {
-            double sc[NA];
-#pragma unroll
-            for (int e = 0; e < NA; ++e) sc[e] = g.kscale[ka[e]];
-#pragma unroll
-            for (int e = 0; e < NA; ++e) {
-                const double f = g.kscale_invert ? 1.0 / sc[e] : sc[e];
-                ra[e].x *= f; ra[e].y *= f;
+                ra[e] = g.A[(size_t)min(gi, Mm1) * g.lda + ka[e]];
             }
         }
 #pragma unroll
-        for (int e = 0; e < NA; ++e) if (!oka[e]) ra[e] = make_double2(0.0, 0.0);
-        if (g.opB == 0) {
+        for (int e = 0; e < NA; ++e) rsc[e] = kscale[ka[e]];
+        if (!OPB) {
 #pragma unroll
             for (int e = 0; e < NB_; ++e) {
                 const int idx = tid + e * 256;
                 const int gk = k0 + idx % BK, gj = j0 + idx / BK;
-                const cplx t = g.B[(size_t)min(gj, Nm1) * g.ldb + min(gk, Km1)];
-                rb[e] = (gj < g.N && gk < K) ? t : make_double2(0.0, 0.0);
+                rb[e] = g.B[(size_t)min(gj, Nm1) * g.ldb + min(gk, Km1)];
+                okb[e] = gj < g.N && gk < K;
             }
         } else {
 #pragma unroll
             for (int e = 0; e < NB_; ++e) {
                 const int idx = tid + e * 256;
                 const int gj = j0 + idx % BN, gk = k0 + idx / BN;
-                const cplx t = g.B[(size_t)min(gk, Km1) * g.ldb + min(gj, Nm1)];
-                rb[e] = (gj < g.N && gk < K) ? make_double2(t.x, -t.y) : make_double2(0.0, 0.0);
+                rb[e] = g.B[(size_t)min(gk, Km1) * g.ldb + min(gj, Nm1)];
+                okb[e] = gj < g.N && gk < K;
             }
         }
     };
     auto sstore = [&](int buf) {
+        constexpr double csgnA = OPA ? -1.0 : 1.0, csgnB = OPB ? -1.0 : 1.0;       // op = conjugate transpose
 #pragma unroll
         for (int e = 0; e < NA; ++e) {
             const int idx = tid + e * 256;
             int i, k;
-            if (g.opA == 0) { i = idx % BM; k = idx / BM; } else { k = idx % BK; i = idx / BK; }
-            sA[buf][k][i] = ra[e];
+            if (!OPA) { i = idx % BM; k = idx / BM; } else { k = idx % BK; i = idx / BK; }
+            cplx v = make_double2(ra[e].x, csgnA * ra[e].y);
+            if (has_kscale) { const double f = g.kscale_invert ? 1.0 / rsc[e] : rsc[e]; v.x *= f; v.y *= f; }
+            if (!oka[e]) v = make_double2(0.0, 0.0);
+            sA[buf][k][i] = v;
         }
 #pragma unroll
         for (int e = 0; e < NB_; ++e) {
             const int idx = tid + e * 256;
             int j, k;
-            if (g.opB == 0) { k = idx % BK; j = idx / BK; } else { j = idx % BN; k = idx / BN; }
-            sB[buf][k][j] = rb[e];
+            if (!OPB) { k = idx % BK; j = idx / BK; } else { j = idx % BN; k = idx / BN; }
+            sB[buf][k][j] = okb[e] ? make_double2(rb[e].x, csgnB * rb[e].y) : make_double2(0.0, 0.0);
         }
     };
 
     const int kbeg = g.b_lower ? (j0 / BK) * BK : 0;      // triangular op(B): rows above the tile's first column are zero
-    if (K > kbeg) { gload(kbeg); sstore(0); }
+    if (K > kbeg) { gidx(kbeg); gload(kbeg); sstore(0); }
     __syncthreads();
     for (int k0 = kbeg, buf = 0; k0 < K; k0 += BK, buf ^= 1) {
         const bool more = k0 + BK < K;
         if (more) gload(k0 + BK);
+        __builtin_amdgcn_sched_barrier(0);      // the loads stay in front of the MFMA block, their first use behind it
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             cplx af[TM], bf[TN];
@@ -175,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
                     }
                 }
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) sstore(buf ^ 1);
         __syncthreads();       // one barrier per tile: nobody refills a buffer that a slower wave still reads
     }
@@ -209,25 +221,31 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Delayed-update flush  G += X Gr  (reference: g += X * Y, src/detsdwopdim.cpp:3156) with K = MSF * (accepted
-// updates of the block) <= 64 read on the device.  This is a read-modify-write stream over G (2 x 16 n^2 bytes)
-// with a thin product riding on it, so it is built for the memory system, not for the matrix cores: no LDS, no
-// barrier -- every wave pulls its MFMA operand fragments and then its 32 x 32 tile of G straight from global
-// memory into registers; two workgroups per CU so that one's loads overlap the other's MFMAs.
-// Fragment convention as in k_zgemm (operand roles swapped so that the stores coalesce).
+// Delayed-update flush  G += X GrT^T  (reference: g += X * Y, src/detsdwopdim.cpp:3156) with K = MSF * (accepted
+// updates of the block) <= 64 read on the device.  A read-modify-write stream over G (2 x 16 n^2 bytes) with a thin
+// product riding on it: no LDS, no barrier -- every wave pulls its MFMA operand fragments and then its 32 x 32 tile of G
+// straight from global memory into registers.  Fragment convention as in k_zgemm (operand roles swapped so that the
+// stores coalesce).  Both operands are n x K8 column-major (k_update_gather writes Gr transposed), K8 = K rounded up to a
+// multiple of 8 with ZERO padding, so the k loop has no bounds check at all and every fragment load is a 256-byte run.
+//
+// Round 3: the k loop is branch free.  Round 2's version guarded its fragment loads with `k < K ? load : 0`; the compiler
+// turned each guard into an exec-masked branch around the load and, unable to count outstanding loads across the branches,
+// put `s_waitcnt vmcnt(0)` in front of the MFMAs of EVERY trip (ISA: fl.s:374) -- the fragments requested "two steps ahead"
+// were waited for at once, and the only overlap of memory and matrix cores came from the other resident waves.
 // ---------------------------------------------------------------------------------------------
 // FULL: n is a multiple of 32 -- every wave's 32 x 32 tile lies inside G or outside of it, no clamps or guards
-template<bool M3, bool FULL>
-__global__ __launch_bounds__(256, FULL ? 3 : 2) void k_flush(const cplx* __restrict__ X, int ldx, const cplx* __restrict__ Gr, int ldg,
+template<bool M3, bool FULL, int STAGE>
+__global__ __launch_bounds__(256, (FULL && STAGE == 1) ? 3 : 2) void k_flush(const cplx* __restrict__ X, const cplx* __restrict__ GrT, int ld,
                                                   cplx* __restrict__ G, int ldc, int n, int Kmax, const int* __restrict__ Kdev,
                                                   int Kmul, size_t cs, int nb) {
     const int tn = (n + 63) / 64;
     int chain, tile;
     xcd_chain_tile(tn * tn, nb, chain, tile);
-    X = chain_ptr_i(X, cs, chain); Gr = chain_ptr_i(Gr, cs, chain); G = chain_ptr_i(G, cs, chain); Kdev = chain_ptr_i(Kdev, cs, chain);
+    X = chain_ptr_i(X, cs, chain); GrT = chain_ptr_i(GrT, cs, chain); G = chain_ptr_i(G, cs, chain); Kdev = chain_ptr_i(Kdev, cs, chain);
     int K = Kmax;
     if (Kdev) { int kd = (*Kdev) * Kmul; K = kd < K ? kd : K; }
     if (K <= 0) return;
+    const int K8 = (K + 7) & ~7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int i0 = (tile % tn) * 64 + (wave >> 1) * 32, j0 = (tile / tn) * 64 + (wave & 1) * 32;
@@ -237,58 +255,78 @@ __global__ __launch_bounds__(256, FULL ? 3 : 2) void k_flush(const cplx* __restr
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); if (M3) acc_p2[a][b] = (v4d)(0.0); }
-    // operand fragments of k-step k0 (clamped addresses + select: no branch, no wait per load); the fragments of step
-    // k0 + 4 are requested before the MFMAs of step k0 are issued
-    auto loadab = [&](int k0, cplx (&a_)[2], cplx (&b_)[2]) {
-        const int gk = k0 + l4, gkc = min(gk, K - 1);
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int gi = i0 + a * 16 + l15;
-            const cplx t = X[(size_t)gkc * ldx + (FULL ? gi : min(gi, n - 1))];
-            a_[a] = (gk < K && (FULL || gi < n)) ? t : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int gj = j0 + b * 16 + l15;
-            const cplx t = Gr[(size_t)(FULL ? gj : min(gj, n - 1)) * ldg + gkc];
-            b_[b] = (gk < K && (FULL || gj < n)) ? t : make_double2(0.0, 0.0);
-        }
+    // fragments of one k-step: f[0], f[1] = X[i0 + {0, 16} + l15, k0 + l4];  f[2], f[3] = GrT[j0 + {0, 16} + l15, k0 + l4].
+    // Rows past n (ragged tiles only) are clamped: they feed accumulator entries that are never stored.
+    const int ia = FULL ? i0 + l15 : min(i0 + l15, n - 1), ia2 = FULL ? ia + 16 : min(i0 + 16 + l15, n - 1);
+    const int jb = FULL ? j0 + l15 : min(j0 + l15, n - 1), jb2 = FULL ? jb + 16 : min(j0 + 16 + l15, n - 1);
+    const cplx* xa = X + (size_t)l4 * ld;
+    const cplx* gb = GrT + (size_t)l4 * ld;
+    auto loadf = [&](int k0, cplx (&f)[4]) {
+        const size_t o = (size_t)k0 * ld;
+        f[0] = xa[o + ia]; f[1] = xa[o + ia2]; f[2] = gb[o + jb]; f[3] = gb[o + jb2];
     };
-    auto mac = [&](const cplx (&af)[2], const cplx (&bf)[2]) {
+    auto mac = [&](const cplx (&f)[4]) {
         double asum[2], bsum[2];
         if (M3) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) { asum[a] = af[a].x + af[a].y; bsum[a] = bf[a].x + bf[a].y; }
+            for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 if (M3) {
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
-                    acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].y, acc_p2[a][b], 0, 0, 0);
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                    acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
                     acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
                 } else {
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc_re[a][b], 0, 0, 0);
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bf[b].y, af[a].y, acc_re[a][b], 0, 0, 0);
-                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].x, acc_im[a][b], 0, 0, 0);
-                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].y, acc_im[a][b], 0, 0, 0);
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f[2 + b].y, f[a].y, acc_re[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].x, acc_im[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].y, acc_im[a][b], 0, 0, 0);
                 }
             }
     };
-    // two k-steps per trip, the fragments of the trip after next requested before the MFMAs of this one (a second k-step past K
-    // multiplies zeros: K = MSF j is even, at most one idle step per tile)
-    cplx a0[2], b0[2], a1[2], b1[2];
-    loadab(0, a0, b0);
-    loadab(4, a1, b1);
-    for (int k0 = 0; k0 < K; k0 += 8) {
-        cplx a2[2], b2[2], a3[2], b3[2];
-        loadab(k0 + 8, a2, b2);
-        mac(a0, b0);
-        loadab(k0 + 12, a3, b3);
-        if (k0 + 4 < K) mac(a1, b1);
-#pragma unroll
-        for (int a = 0; a < 2; ++a) { a0[a] = a2[a]; b0[a] = b2[a]; a1[a] = a3[a]; b1[a] = b3[a]; }
+    // Software pipeline: two fragment sets that swap roles, written out twice per loop iteration so that no register copy closes
+    // the cycle -- with `cur = next` at the end of a trip the register coalescer merges the two sets and the loads land right in
+    // front of the MFMAs that use them.  The scheduling barriers keep each batch of loads in front of the OTHER set's MFMAs.  A
+    // step past the end requests the last fragments again (uniform clamp of the index instead of a branch around the loads).
+    //   STAGE 1: a set = one k-step (4 k, 12 MFMAs between request and use); 150 VGPRs, three workgroups per CU
+    //   STAGE 2: a set = two k-steps (24 MFMAs between request and use); 188 VGPRs, two workgroups per CU
+    if constexpr (STAGE == 1) {
+        cplx s[4], t[4];
+        loadf(0, s);
+        for (int k0 = 0; k0 < K8; k0 += 8) {
+            loadf(k0 + 4, t);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(s);
+            __builtin_amdgcn_sched_barrier(0);
+            loadf(min(k0 + 8, K8 - 4), s);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        cplx s0[4], s1[4], t0[4], t1[4];
+        loadf(0, s0);
+        loadf(4, s1);
+        for (int k0 = 0; k0 < K8; k0 += 16) {
+            const int kn = min(k0 + 8, K8 - 8);
+            loadf(kn, t0);
+            loadf(kn + 4, t1);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(s0);
+            mac(s1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + 8 >= K8) break;
+            const int kn2 = min(k0 + 16, K8 - 8);
+            loadf(kn2, s0);
+            loadf(kn2 + 4, s1);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(t0);
+            mac(t1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // 3M: the three accumulators are combined first (96 -> 64 registers), which makes room for the tile of G
     if (M3) {
@@ -301,10 +339,9 @@ __global__ __launch_bounds__(256, FULL ? 3 : 2) void k_flush(const cplx* __restr
             }
     }
     // The tile of G is requested only now -- holding it across the MFMA loop costs 64 VGPRs, i.e. the third resident workgroup
-    // per CU whose loads overlap this one's MFMAs (scripts/micro/flush_tiles.hip: 75 -> 55 us; round 2: 197 -> 212 ms per
-    // 128-chain sweep when it was tried again) -- but then ALL 16 loads of the 32 x 32 tile go out together (one memory round trip
-    // per wave instead of four), as nontemporal accesses: G is streamed once per launch and must not evict the X / Gr panels of its
-    // chain from the L2 (scripts/micro/flush_r2.hip, 128 chains: 258 -> 218 us at K ~ 30, 357 -> 308 us at K = 64).
+    // per CU whose loads overlap this one's MFMAs -- but then ALL 16 loads of the 32 x 32 tile go out together (one memory round
+    // trip per wave instead of four), as nontemporal accesses: G is streamed once per launch and must not evict the X / GrT
+    // panels of its chain from the L2.
     if constexpr (FULL) {
         cplx c[2][2][4];
         cplx* base = G + (size_t)(j0 + l4) * ldc + i0 + l15;
@@ -355,18 +392,30 @@ static bool use_4m() {
     return v;
 }
 
-void launch_flush(const Launch& lc, const cplx* X, int ldx, const cplx* Gr, int ldg, cplx* G, int ldc, int n, int Kmax,
+void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx* G, int ldc, int n, int Kmax,
                   const int* Kdev, int Kmul) {
     const int tn = (n + 63) / 64;
     const dim3 grid = (lc.nb % 8 == 0) ? dim3(tn * tn * lc.nb, 1, 1) : dim3(tn * tn, 1, lc.nb);
     static const bool force_ragged = getenv("DQMC_FLUSH_RAGGED") && atoi(getenv("DQMC_FLUSH_RAGGED")) != 0;   // developer knob (A/B)
     const bool full = n % 32 == 0 && !force_ragged;
-#define FLUSH_LAUNCH(M3_, FULL_) hipLaunchKernelGGL((k_flush<M3_, FULL_>), grid, dim3(256), 0, lc.st, X, ldx, Gr, ldg, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb)
-    if (use_4m()) { if (full) FLUSH_LAUNCH(false, true); else FLUSH_LAUNCH(false, false); }
-    else          { if (full) FLUSH_LAUNCH(true, true);  else FLUSH_LAUNCH(true, false); }
+    static const int stage = getenv("DQMC_FLUSH_STAGE") ? atoi(getenv("DQMC_FLUSH_STAGE")) : 1;                 // developer knob (A/B)
+#define FLUSH_LAUNCH(M3_, FULL_, ST_) hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb)
+    if (use_4m()) { if (full) FLUSH_LAUNCH(false, true, 1); else FLUSH_LAUNCH(false, false, 1); }
+    else if (stage == 2) { if (full) FLUSH_LAUNCH(true, true, 2);  else FLUSH_LAUNCH(true, false, 2); }
+    else          { if (full) FLUSH_LAUNCH(true, true, 1);  else FLUSH_LAUNCH(true, false, 1); }
 #undef FLUSH_LAUNCH
 }
 
+template<int TM, int TN, bool M3, int TAG>
+static void launch_gemm_ops(const Launch& lc, const GemmArgs& a, dim3 grid) {
+    if (!a.opA) {
+        if (!a.opB) hipLaunchKernelGGL((k_zgemm<TM, TN, M3, TAG, false, false>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        else        hipLaunchKernelGGL((k_zgemm<TM, TN, M3, TAG, false, true>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+    } else {
+        if (!a.opB) hipLaunchKernelGGL((k_zgemm<TM, TN, M3, TAG, true, false>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        else        hipLaunchKernelGGL((k_zgemm<TM, TN, M3, TAG, true, true>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+    }
+}
 template<int TAG>
 static void launch_gemm_tagged(const Launch& lc, const GemmArgs& a) {
     // fill the chip: 64x64 tiles only when they still give >= 256 workgroups
@@ -374,13 +423,13 @@ static void launch_gemm_tagged(const Launch& lc, const GemmArgs& a) {
     if (tiles64 >= 256 && a.N > 32 && a.M > 32) {
         const int t = ((a.M + 63) / 64) * ((a.N + 63) / 64);
         const dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
-        if (use_4m()) hipLaunchKernelGGL((k_zgemm<2, 2, false, TAG>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
-        else          hipLaunchKernelGGL((k_zgemm<2, 2, true, TAG>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        if (use_4m() && TAG == 0) launch_gemm_ops<2, 2, false, 0>(lc, a, grid);
+        else                      launch_gemm_ops<2, 2, true, TAG>(lc, a, grid);
     } else {
         const int t = ((a.M + 31) / 32) * ((a.N + 31) / 32);
         const dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
-        if (use_4m()) hipLaunchKernelGGL((k_zgemm<1, 1, false, TAG>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
-        else          hipLaunchKernelGGL((k_zgemm<1, 1, true, TAG>), grid, dim3(256), 0, lc.st, a, lc.cs, lc.nb);
+        if (use_4m() && TAG == 0) launch_gemm_ops<1, 1, false, 0>(lc, a, grid);
+        else                      launch_gemm_ops<1, 1, true, TAG>(lc, a, grid);
     }
 }
 void launch_gemm(const Launch& lc, const GemmArgs& a) {

@@ -296,6 +296,11 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
 #endif
     int j = 0;
     const int dnow = min(D, N - site);            // delayStepsNow (:3052)
+    // A block also ends after `pbudget` PROPOSALS (0: no limit).  Where a block ends does not change the chain (the flush is exact,
+    // test_update_slice_delay_steps_invariance), but in a batched launch every chain waits for the slowest one: the number of
+    // proposals until D are accepted scatters (68 +- 9 at acceptance 0.5, D = 32: the slowest of 128 chains needs ~ 91), a
+    // proposal budget makes the chains of a launch finish together.
+    const int budget = dm.pbudget > 0 ? dm.pbudget : N;
     double pre[NIT];                               // wave 0: the prefetched scalar items, one per lane
     cplx pu[SLOTS], pv[SLOTS];                     // wave 0: u = G[c, I], v = G[I, c] for the I known at issue time
 #pragma unroll
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     bool prev_acc = false, prev_used_uniform = true;
 
     int it = 0;                                    // proposal counter of this launch: selects the u/v buffer
-    while (j < dnow && site < N) {
+    while (j < dnow && site < N && it < budget) {
         if (cur + OPDIM + 1 > avail) { err = DQMC_ERNG; break; }
         const int nI = MSF * j;
         cplx* su = su2 + (it & 1) * MSF * WD;
@@ -697,54 +702,81 @@ void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevMod
         hipLaunchKernelGGL((k_update_decide<3>), dim3(1, 1, lc.nb), dim3(256), lds, lc.st, hm, us, uniforms, G, W, k, first, thermal, lc.cs);
 }
 
-// X[:, i'] = sum_i G[:, I_i] W[i, i']   (n_g x nI, ld n_g);   Gr[i, :] = G[I_i, :] - E   (nI x n_g, ld WD)
-// One workgroup per 32 rows of X / 32 columns of Gr, no LDS staging: the columns G[:, I_i] are contiguous, so the
-// MFMA operand fragments of X = G[:, I] W come straight from global memory (16 lanes = 16 consecutive rows);
-// wave w forms the 16 columns 16 w .. 16 w + 15 of the tile (operand roles swapped as in k_zgemm so that the stores
-// coalesce).  The rows G[I_i, :] are a strided gather by nature (16 useful bytes per 64-byte sector).
+// X[:, i'] = sum_i G[:, I_i] W[i, i']   (n_g x nI8, ld n_g);   GrT[:, i] = (G[I_i, :] - E)^T   (n_g x nI8, ld n_g)
+// nI8 = nI rounded up to a multiple of 8, the padding columns are ZERO: the flush kernel runs its k loop in steps of 8 without
+// a single bounds check.  One workgroup per 32 rows of X / of GrT.
+//   * GrT: the rows G[I_i, :] of a column-major G are a strided gather by nature -- but the accepted sites of a block are nearly
+//     consecutive (every proposal of a window of <= pbudget sites, about half of them accepted), so for one column r the needed
+//     entries lie in MSF contiguous runs of `span` rows.  A wave reads such a run with ONE coalesced load (lane = row), keeps the
+//     accepted rows (LDS map row -> index) in an LDS tile [i][32 columns], and the tile goes out as 512-byte runs of GrT.  Round 2
+//     read the same sectors with one 16-byte request per lane and sector (1.41 x the algorithmic traffic at 0.30 of the HBM roof).
+//   * X: the columns G[:, I_i] are contiguous, the MFMA operand fragments of X = G[:, I] W come straight from global memory
+//     (16 lanes = 16 consecutive rows); wave w forms the 16 columns 16 w .. 16 w + 15 of the tile (operand roles swapped as in
+//     k_zgemm so that the stores coalesce).
+// __launch_bounds__(256, 2): with 512 registers on offer the compiler keeps MFMA accumulators in AGPRs and copies them to VGPRs
+// and back on every trip of a loop with a run-time trip count (round 2: 48 v_accvgpr_read + 48 writes per 6 MFMAs in this kernel).
 typedef double u_v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpdateState* __restrict__ us,
-                                                        const cplx* __restrict__ G, const cplx* __restrict__ Wg,
-                                                        cplx* __restrict__ X, cplx* __restrict__ Gr, size_t cs) {
-    CHAIN(us); CHAIN(G); CHAIN(Wg); CHAIN(X); CHAIN(Gr);
+#define GATHER_MAXSPAN 2048
+__global__ __launch_bounds__(256, 2) void k_update_gather(DevModel dm, const DevUpdateState* __restrict__ us,
+                                                           const cplx* __restrict__ G, const cplx* __restrict__ Wg,
+                                                           cplx* __restrict__ X, cplx* __restrict__ GrT, size_t cs) {
+    CHAIN(us); CHAIN(G); CHAIN(Wg); CHAIN(X); CHAIN(GrT);
     const int j = us->block_j;
     if (j <= 0) return;
     const int MSF = dm.MSF, N = dm.N, ng = dm.ng, WD = MSF * dm.D;
-    const int nI = MSF * j;
+    const int nI = MSF * j, nI8 = (nI + 7) & ~7;
     __shared__ int sI[DQMC_MAX_WDIM];
-    for (int t = threadIdx.x; t < nI; t += 256) sI[t] = us->block_sites[t / MSF] + (t % MSF) * N;
-    __syncthreads();
+    __shared__ short smap[GATHER_MAXSPAN];                 // site - first site of the block  ->  index among the accepted, or -1
+    __shared__ cplx tile[DQMC_MAX_WDIM][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s_first = us->block_sites[0], span = us->block_sites[j - 1] - s_first + 1;
+    for (int t = tid; t < nI; t += 256) sI[t] = us->block_sites[t / MSF] + (t % MSF) * N;
+    for (int t = tid; t < span; t += 256) smap[t] = -1;
+    __syncthreads();
+    for (int t = tid; t < j; t += 256) smap[us->block_sites[t] - s_first] = (short)t;
+    __syncthreads();
     const int r0 = blockIdx.x * 32;
-    // ---- Gr[i, r] = G[I_i, r] - delta ----
+    // ---- GrT, phase 1: coalesced runs of rows -> LDS tile ----
     {
-        // all (<= 8) row-gather loads of a thread in flight together: clamped indices, bounds applied at the store
-        const int r = r0 + (tid & 31);
-        const int rc = min(r, ng - 1);
-        constexpr int NIT = DQMC_MAX_WDIM / 8;
-        cplx h[NIT];
-        int si[NIT];
+        const int nchunk = (span + 63) >> 6;
+        const int nitems = 32 * MSF * nchunk;              // (column c, band b, chunk q)
+        constexpr int U = 8;                               // loads in flight per lane
+        for (int base = wave * U; base < nitems; base += 4 * U) {
+            cplx h[U];
+            int li[U], cc[U];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            si[it] = sI[min((tid >> 5) + 8 * it, nI - 1)];
-            h[it] = G[(size_t)rc * ng + si[it]];
-        }
+            for (int u = 0; u < U; ++u) {
+                const int item = min(base + u, nitems - 1);
+                const int c = item & 31, bq = item >> 5, b = bq % MSF, q = bq / MSF;
+                const int t = q * 64 + lane;
+                const int tcl = min(t, span - 1);
+                const int row = b * N + s_first + tcl, col = min(r0 + c, ng - 1);
+                h[u] = G[(size_t)col * ng + row];
+                const int l = smap[tcl];
+                const bool ok = base + u < nitems && t < span && l >= 0;
+                li[u] = ok ? l * MSF + b : -1;
+                cc[u] = c;
+                if (row == r0 + c) h[u].x -= 1.0;          // - E_I: the unit entry sits where row I_i meets column I_i
+            }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = (tid >> 5) + 8 * it;
-            if (r == si[it]) h[it].x -= 1.0;
-            if (r < ng && i < nI) Gr[(size_t)r * WD + i] = h[it];
+            for (int u = 0; u < U; ++u) if (li[u] >= 0) tile[li[u]][cc[u]] = h[u];
         }
+    }
+    __syncthreads();
+    // ---- GrT, phase 2: 512-byte runs, zero padding up to nI8 ----
+    {
+        const int c = tid & 31, r = r0 + c;
+        for (int i = tid >> 5; i < nI8; i += 8)
+            if (r < ng) GrT[(size_t)i * ng + r] = (i < nI) ? tile[i][c] : make_double2(0.0, 0.0);
     }
     // ---- X tile: rows r0 .. r0 + 31, columns 16 wave .. 16 wave + 15 ----
     const int c0 = wave * 16;
-    if (c0 >= nI) return;
+    if (c0 >= nI8) return;
     const int l15 = lane & 15, l4 = lane >> 4;
     // 3M complex product as in k_zgemm (kernels_gemm.hip): acc_re = P1 = w_r g_r, acc_p2 = P2 = w_i g_i, acc_im = P3 = (w_r + w_i)(g_r + g_i)
     u_v4d acc_re[2], acc_im[2], acc_p2[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) { acc_re[a] = (u_v4d)(0.0); acc_im[a] = (u_v4d)(0.0); acc_p2[a] = (u_v4d)(0.0); }
-#pragma unroll 2
     for (int k0 = 0; k0 < nI; k0 += 4) {
         const int gk = k0 + l4;
         const bool kok = gk < nI;
@@ -771,11 +803,12 @@ __global__ __launch_bounds__(256) void k_update_gather(DevModel dm, const DevUpd
         for (int rr = 0; rr < 4; ++rr) {
             const int c = c0 + l4 + 4 * rr, r = r0 + a * 16 + l15;      // D[m = l4 + 4 rr][n = l15]
             const double p1 = acc_re[a][rr], p2 = acc_p2[a][rr];
-            if (c < nI && r < ng) X[(size_t)c * ng + r] = make_double2(p1 - p2, (acc_im[a][rr] - p1) - p2);
+            // columns nI .. nI8 - 1: W was masked to zero there, so the product IS the zero padding
+            if (c < nI8 && r < ng) X[(size_t)c * ng + r] = make_double2(p1 - p2, (acc_im[a][rr] - p1) - p2);
         }
 }
 
 void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,
-                          const cplx* W, cplx* X, cplx* Gr) {
-    hipLaunchKernelGGL(k_update_gather, dim3((hm.ng + 31) / 32, 1, lc.nb), dim3(256), 0, lc.st, hm, us, G, W, X, Gr, lc.cs);
+                          const cplx* W, cplx* X, cplx* GrT) {
+    hipLaunchKernelGGL(k_update_gather, dim3((hm.ng + 31) / 32, 1, lc.nb), dim3(256), 0, lc.st, hm, us, G, W, X, GrT, lc.cs);
 }
