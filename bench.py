@@ -38,14 +38,41 @@ sys.path.insert(0, ROOT)
 # delaySteps: depth of the delayed-update blocks -- a performance knob, the Markov chain does not depend on it (tests:
 # test_update_slice_delay_steps_invariance, test_qr_mode_headline_size_vs_reference_checksums[32]); 32 halves the
 # read-modify-write traffic of G per accepted update.  The reference CPU baseline runs with its own setting (16).
-WORKLOAD = dict(opdim=2, L=16, beta=10.0, dtau=0.1, s=10, delaySteps=int(os.environ.get("DQMC_DELAY_STEPS", "32")), r=-1.0, c=3.0, u=1.0, lambda_=1.0,
-                mu=-0.5, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, bc="pbc", accRatio=0.5,
-                rngSeed=1020304050,
-                # same Green's functions and Markov chain as the reference-exact "svd" mode (tests), ~10x cheaper
-                stabilisation=os.environ.get("DQMC_STABILISATION", "qr"))
-# production variant (reference example/simulation.job:27-44): a global shift move every 10 sweeps
-if os.environ.get("DQMC_BENCH_GLOBAL_SHIFT"):
-    WORKLOAD.update(globalShift=True, globalUpdateInterval=int(os.environ["DQMC_BENCH_GLOBAL_SHIFT"]))
+_COMMON = dict(dtau=0.1, s=10, r=-1.0, c=3.0, u=1.0, lambda_=1.0, mu=-0.5, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, bc="pbc", accRatio=0.5,
+               rngSeed=1020304050,
+               # same Green's functions and Markov chain as the reference-exact "svd" mode (tests), ~10x cheaper
+               stabilisation=os.environ.get("DQMC_STABILISATION", "qr"))
+# BASELINE.json configs 2-5 (config 1, the Hubbard replica, is CPU plumbing: tests/test_gpu_hubbard.py).  `--config` selects one; the
+# default is the configuration the metric is quoted on (config 3).  batch / sub: chains per GPU and kernel contexts they are spread over.
+CONFIGS = {
+    "o2_L16_b10": dict(workload=dict(opdim=2, L=16, beta=10.0, delaySteps=32), batch=512, sub=4,
+                       label="SDW-O2 L=16 beta=10", text="DetSDW O(2) L=16 beta=10 dtau=0.1 s=10"),
+    "o2_L8_b5": dict(workload=dict(opdim=2, L=8, beta=5.0, delaySteps=32), batch=512, sub=4,
+                     label="SDW-O2 L=8 beta=5", text="DetSDW O(2) L=8 beta=5 dtau=0.1 s=10"),
+    "o2_L16_b20": dict(workload=dict(opdim=2, L=16, beta=20.0, delaySteps=32), batch=256, sub=4,
+                       label="SDW-O2 L=16 beta=20", text="DetSDW O(2) L=16 beta=20 dtau=0.1 s=10"),
+    # no magnetic flux: the reference refuses weakZflux for opdim = 3 (src/detsdwparams.cpp:57-60), and so does detsdw_create
+    "o3_L24_b20": dict(workload=dict(opdim=3, L=24, beta=20.0, delaySteps=16), batch=8, sub=1,
+                       label="SDW-O3 L=24 beta=20", text="DetSDW O(3) L=24 beta=20 dtau=0.1 s=10 (no flux: the reference rejects O(3) + flux)",
+                       ref_parts=True),
+}
+DEFAULT_CONFIG = "o2_L16_b10"
+CONFIG = DEFAULT_CONFIG
+WORKLOAD = {}
+
+
+def select_config(name):
+    global CONFIG, WORKLOAD
+    CONFIG = name
+    WORKLOAD = dict(_COMMON, **CONFIGS[name]["workload"])
+    if os.environ.get("DQMC_DELAY_STEPS"):
+        WORKLOAD["delaySteps"] = int(os.environ["DQMC_DELAY_STEPS"])
+    # production variant (reference example/simulation.job:27-44): a global shift move every 10 sweeps
+    if os.environ.get("DQMC_BENCH_GLOBAL_SHIFT"):
+        WORKLOAD.update(globalShift=True, globalUpdateInterval=int(os.environ["DQMC_BENCH_GLOBAL_SHIFT"]))
+
+
+select_config(DEFAULT_CONFIG)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F64_PEAK_TF = 78.6        # CDNA4 v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s (= fp64 vector rate)
 # What the instruction sustains on the box with nothing else going on: scripts/micro/valu_mfma_mix.hip (8 independent accumulators per
@@ -67,9 +94,6 @@ def _mfma_sustained():
 
 
 MFMA_F64_SUSTAINED_TF = _mfma_sustained()
-DEFAULT_BATCH = 512            # chains per worker process (detsdw_create_batch), spread over DEFAULT_SUB kernel contexts
-DEFAULT_SUB = 4                # kernel contexts (sub-batches, one host thread + HIP stream each) per process: the latency-bound
-                               # kernels of one context overlap the streaming / MFMA kernels of the others
 DEFAULT_WORKERS = 1            # worker processes per GPU
 FAKE = bool(os.environ.get("DQMC_BENCH_FAKE_WORKER"))     # CPU rehearsal of the control flow (tests/test_bench_cpu.py)
 
@@ -77,18 +101,50 @@ FAKE = bool(os.environ.get("DQMC_BENCH_FAKE_WORKER"))     # CPU rehearsal of the
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the real reference binary, 1 core and all cores
 # ---------------------------------------------------------------------------------------------------------------------
-REF_EXE = os.path.join(ROOT, "oracle", "_ref", "ref_harness_fast_o2")
-REF_ARGS = ["L=16", "beta=10", "dtau=0.1", "s=10", "delaySteps=16", "opdim=2", "mode=time"]
-REF_DESC = ("crstnbr/detqmc DetSDW<CB_ASSAAD_BERG,2> built from the reference sources "
-            "(-O3 -ffast-math -mavx2 -mfma, MKL 1 thread per process)")
+def ref_exe():
+    return os.path.join(ROOT, "oracle", "_ref", "ref_harness_fast_o%d" % WORKLOAD["opdim"])
+
+
+def ref_args():
+    return ["L=%d" % WORKLOAD["L"], "beta=%g" % WORKLOAD["beta"], "dtau=0.1", "s=10", "delaySteps=16", "opdim=%d" % WORKLOAD["opdim"]]
+
+
+def ref_desc():
+    return ("crstnbr/detqmc DetSDW<CB_ASSAAD_BERG,%d> built from the reference sources "
+            "(-O3 -ffast-math -mavx2 -mfma, MKL 1 thread per process)" % WORKLOAD["opdim"])
 
 
 def _ref_start(warmup, sweeps, tag):
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
     d = "/tmp/dqmc_ref_%d_%s" % (os.getpid(), tag)
     os.makedirs(d, exist_ok=True)
-    return subprocess.Popen([REF_EXE, d] + REF_ARGS + ["warmup=%d" % warmup, "sweeps=%d" % sweeps], stdout=subprocess.PIPE,
+    return subprocess.Popen([ref_exe(), d] + ref_args() + ["mode=time", "warmup=%d" % warmup, "sweeps=%d" % sweeps], stdout=subprocess.PIPE,
                             stderr=subprocess.DEVNULL, text=True, env=env)
+
+
+def cpu_baseline_parts(m, nst):
+    """Sizes where ONE reference sweep takes hours (config 5: 40 SVDs of 2304 x 2304 per sweep): the reference binary on the SAME
+    lattice at beta = 0.3 (3 time slices), its per-slice cost (local updates + wrap) and the cost of one stabilisation step
+    (advanceDownGreen -> greenFromUdV) timed separately (mode=timeparts of oracle/ref_build/ref_harness.cpp) and extrapolated to
+    sweep = m * slice + n * advance.  MKL gets all host cores here: a single core would need ten minutes for this sample."""
+    ncpu = host_cores()
+    env = dict(os.environ, MKL_NUM_THREADS=str(ncpu), OMP_NUM_THREADS=str(ncpu))
+    d = "/tmp/dqmc_ref_%d_parts" % os.getpid()
+    os.makedirs(d, exist_ok=True)
+    args = [a for a in ref_args() if not a.startswith("beta=")] + ["beta=0.3", "mode=timeparts"]
+    t0 = time.time()
+    out = subprocess.run([ref_exe(), d] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, timeout=1500).stdout
+    for line in out.splitlines():
+        if line.startswith("REF_PARTS"):
+            kv = dict(tok.split("=") for tok in line.split()[1:])
+            ts, ta = float(kv["slice_seconds"]), float(kv["advance_seconds"])
+            sweep_s = m * ts + nst * ta
+            return {"value": 1.0 / sweep_s, "unit": "sweeps/s", "cores": ncpu, "kind": "reference",
+                    "sample": ref_desc().replace("MKL 1 thread per process", "MKL %d threads" % ncpu) +
+                              ": same lattice at beta = 0.3 (n_g = %s), %.2f s per time slice (local updates + wrap) and %.1f s per "
+                              "stabilisation step (advanceDownGreen) measured in %.0f s of wall time incl. construction, extrapolated to "
+                              "m = %d slices + n = %d steps = %.0f s per sweep" % (kv["ng"], ts, ta, time.time() - t0, m, nst, sweep_s)}
+    raise RuntimeError("reference harness printed no REF_PARTS line")
 
 
 def _ref_finish(p, timeout):
@@ -150,14 +206,24 @@ class CpuBaseline:
     def __init__(self, sweeps=2):
         self.sweeps = sweeps
         self.p1 = None
-        if os.path.exists(REF_EXE) and not FAKE:
+        self.parts = bool(CONFIGS[CONFIG].get("ref_parts"))
+        if self.parts:
+            return
+        if os.path.exists(ref_exe()) and not FAKE:
             try:
                 self.p1 = _ref_start(1, sweeps, "one")
             except Exception as e:
                 sys.stderr.write("reference binary unusable (%r)\n" % (e,))
 
-    def finish(self):
+    def finish(self, m=None, nst=None):
         out = {}
+        if self.parts:
+            try:
+                out["cpu_baseline"] = cpu_baseline_parts(m, nst)
+            except Exception as e:
+                sys.stderr.write("reference timeparts run failed (%r)\n" % (e,))
+                out["cpu_baseline"] = None
+            return out
         if self.p1 is None:
             out["cpu_baseline"] = cpu_baseline_port()
             return out
@@ -168,14 +234,14 @@ class CpuBaseline:
             out["cpu_baseline"] = cpu_baseline_port()
             return out
         out["cpu_baseline"] = {"value": n / sec, "unit": "sweeps/s", "cores": 1, "kind": "reference",
-                               "sample": REF_DESC + ": %d sweepThermalization() after init + 1 warm-up sweep, %.1f s" % (n, sec)}
+                               "sample": ref_desc() + ": %d sweepThermalization() after init + 1 warm-up sweep, %.1f s" % (n, sec)}
         ncpu = host_cores()
         try:
             ps = [_ref_start(1, self.sweeps, "all%d" % i) for i in range(ncpu)]
             res = [_ref_finish(p, 900) for p in ps]
             out["cpu_baseline_all_cores"] = {
                 "value": sum(n_ / s_ for n_, s_ in res), "unit": "sweeps/s", "cores": ncpu, "kind": "reference",
-                "sample": REF_DESC + ": %d independent replicas at the same time (one process per core, as under mpirun), each %d "
+                "sample": ref_desc() + ": %d independent replicas at the same time (one process per core, as under mpirun), each %d "
                                      "sweepThermalization() after init + 1 warm-up sweep; slowest %.1f s, fastest %.1f s"
                                      % (ncpu, self.sweeps, max(s_ for _, s_ in res), min(s_ for _, s_ in res))}
         except Exception as e:
@@ -189,11 +255,15 @@ class CpuBaseline:
 class _FakeBatch:
     """stands in for DetSDWBatch in the CPU rehearsal of the control flow (no GPU, no library)"""
 
-    def __init__(self, B):
-        self.B = B
+    def __init__(self, B, device=0):
+        self.B, self.device, self.timed = B, device, False
 
     def sweepThermalization(self):
         time.sleep(0.01)
+        # rehearsal of a worker that dies mid-run (tests/test_bench_cpu.py): DQMC_BENCH_FAKE_DIE = "<device>:<exit code>"
+        die = os.environ.get("DQMC_BENCH_FAKE_DIE")
+        if die and self.timed and int(die.split(":")[0]) == self.device:
+            os._exit(int(die.split(":")[1]))
 
 
 def worker(a, readline=None, emit=None):
@@ -203,7 +273,7 @@ def worker(a, readline=None, emit=None):
     emit = emit or (lambda line: print(line, flush=True))
     B = max(1, a.batch)
     if FAKE:
-        batch, ctx = _FakeBatch(B), None
+        batch, ctx = _FakeBatch(B, a.device), None
     else:
         from detqmc_amd import DetSDWBatch, SDWParams
         p0 = SDWParams(device=a.device, **WORKLOAD)
@@ -216,6 +286,8 @@ def worker(a, readline=None, emit=None):
     emit("READY")
     if readline().strip() != "GO":
         return
+    if FAKE:
+        batch.timed = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
         batch.sweepThermalization()          # one C call per lockstep sweep of all B chains
@@ -326,7 +398,9 @@ def rooflines(rawprof, n, m, B, traffic):
     """one entry per kernel family: achieved algorithmic GB/s and TFLOP/s over the family's device time, the fraction of
     each peak, and `bound` = the roof it is closer to.  `traffic` = HBM bytes per launch from the PMC passes, if taken."""
     prof = {k: (tuple(v) if isinstance(v, list) else v) for k, v in rawprof.items()}
-    N, MSF, D, OPD, s = n // 2, 2, WORKLOAD["delaySteps"], WORKLOAD["opdim"], WORKLOAD["s"]
+    OPD = WORKLOAD["opdim"]
+    MSF = 4 if OPD == 3 else 2
+    N, D, s = n // MSF, WORKLOAD["delaySteps"], WORKLOAD["s"]
 
     def entry(name, kernel, ms, launches, total_bytes, total_flops, note, latency_bound=False):
         gbs = total_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -360,7 +434,7 @@ def rooflines(rawprof, n, m, B, traffic):
     # G[c,c], G[c,prev], G[prev,c] with |I| = MSF*D/2 on average
     cand_bytes = (OPD + 1) * 8 + 2 * OPD * 8 + 16 + (2 * MSF * (MSF * D // 2) + 3 * MSF * MSF) * 16
     nslices = prof["decide"][1] // ((N + D - 1) // D)
-    roofs.append(entry("decide", "k_update_decide<2>", *prof["decide"], float(N) * cand_bytes * nslices * B, 0.0,
+    roofs.append(entry("decide", "k_update_decide<%d>" % OPD, *prof["decide"], float(N) * cand_bytes * nslices * B, 0.0,
                        "sequential Metropolis chain of one slice: ONE workgroup per chain by construction -- latency bound, "
                        "neither roof is its limit; launches of finished slices exit at once", latency_bound=True))
     if WORKLOAD["stabilisation"] == "svd":
@@ -375,7 +449,7 @@ def rooflines(rawprof, n, m, B, traffic):
                            "block reflectors of up to 4 panels applied to the trailing matrix / to Q with the columns in registers: "
                            "one read + one write per launch, 2 x 8 rows 16 ncols flop per reflector"))
         rest_ms = max(prof["decomp"][0] - prof["decomp_round_ms"], 0.0)
-        roofs.append(entry("qr_rest", "k_qr_panel, LU of the Green's function (k_lu_panel, k_lu_rowswap_trsm, K = 32 updates), triangular solves, glue", rest_ms, max(prof["decomp"][1] - prof["decomp_rounds"], 1),
+        roofs.append(entry("qr_rest", "k_qr_panel, " + ("LU of the Green's function (k_lu_panel, k_lu_rowswap_trsm, K = 32 updates), " if n <= 512 else "") + "triangular solves, glue", rest_ms, max(prof["decomp"][1] - prof["decomp_rounds"], 1),
                            0.0, 0.0, "panel factorisations (a chain of dependent reductions: latency bound) and the small kernels "
                            "around the QR; no roofline claimed", latency_bound=True))
     bl = prof["bmult"][1]
@@ -427,11 +501,14 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS),
+                    help="BASELINE.json workload: o2_L16_b10 (config 3, the one the metric is quoted on; default), o2_L8_b5 (2), "
+                         "o2_L16_b20 (4), o3_L24_b20 (5, without the flux the reference rejects)")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("DQMC_WORKERS_PER_GPU", str(DEFAULT_WORKERS))),
                     help="worker processes (kernel contexts) per GPU")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DQMC_CHAINS_PER_WORKER", str(DEFAULT_BATCH))),
-                    help="independent Markov chains per worker process")
-    ap.add_argument("--sub-batches", type=int, default=int(os.environ.get("DQMC_SUB_BATCHES", str(DEFAULT_SUB))),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DQMC_CHAINS_PER_WORKER", "0")),
+                    help="independent Markov chains per worker process (default: the configuration's)")
+    ap.add_argument("--sub-batches", type=int, default=int(os.environ.get("DQMC_SUB_BATCHES", "0")),
                     help="kernel contexts per worker process the chains are spread over (swept concurrently, one host thread each)")
     ap.add_argument("--inprocess", action="store_true",
                     help="ONE context in this process instead of worker processes (for rocprofv3)")
@@ -439,6 +516,11 @@ def main():
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--simindex", type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    select_config(a.config)
+    if a.batch <= 0:
+        a.batch = CONFIGS[a.config]["batch"]
+    if a.sub_batches <= 0:
+        a.sub_batches = CONFIGS[a.config]["sub"]
     if a.worker:
         return worker(a)
 
@@ -482,7 +564,7 @@ def main():
         S -= 1
 
     def spawn(device, simindex, batch, steps, warmup, sub=None):
-        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--device", str(0 if one_device else device), "--simindex",
+        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--config", a.config, "--device", str(0 if one_device else device), "--simindex",
                str(simindex), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch), "--sub-batches", str(sub or S)]
         return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
 
@@ -500,7 +582,13 @@ def main():
         while True:
             line = p.stdout.readline()
             if not line:
-                raise SystemExit("bench worker died (exit code %s)" % p.poll())
+                # a dead worker ends the whole job with a non-zero status that names it: no JSON line is printed
+                rc = p.wait() if hasattr(p, "wait") else p.poll()
+                for _, q in procs:
+                    if q is not p and q.poll() is None and hasattr(q, "kill"):
+                        q.kill()
+                sys.stderr.write("bench worker died while the parent waited for %s (exit code %s)\n" % (tag, rc))
+                raise SystemExit(3)
             if line.startswith(tag):
                 return line[len(tag):].strip()
 
@@ -568,7 +656,7 @@ def main():
         r0 = results[0]
         n = r0["n_g"]
         res = {
-            "metric": "DQMC sweeps/sec (SDW-O2 L=16 beta=10 fp64)",
+            "metric": "DQMC sweeps/sec (%s fp64)" % CONFIGS[a.config]["label"],
             "value": n_gpus * R * B * a.steps / dt,
             "unit": "sweeps/s",
             "n_gpus": n_gpus,
@@ -581,7 +669,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (random initial field, fixed seed)",
-            "config": {"workload": "DetSDW O(2) L=16 beta=10 dtau=0.1 s=10 checkerboard delayed(%d) " % WORKLOAD["delaySteps"] +
+            "config": {"workload": CONFIGS[a.config]["text"] + " checkerboard delayed(%d) " % WORKLOAD["delaySteps"] +
                                    "sweepThermalization, %d independent chains per GPU (%d process x %d kernel contexts x %d lockstep chains), stabilisation=%s%s"
                                    % (R * B, R, S, B // S, WORKLOAD["stabilisation"],
                                       ", global shift move every %d sweeps" % WORKLOAD["globalUpdateInterval"] if WORKLOAD.get("globalShift") else ""),
@@ -617,7 +705,7 @@ def main():
             res["decompositions"] = {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
                                      "max_sweeps": prof["svd_sweeps_max"], "qr_calls": prof["qr_calls"], "lu_calls": prof.get("lu_calls", 0)}
         if cpu is not None:
-            res.update(cpu.finish())
+            res.update(cpu.finish(r0["m"], (r0["m"] + WORKLOAD["s"] - 1) // WORKLOAD["s"]))
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

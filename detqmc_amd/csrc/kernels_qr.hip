@@ -285,7 +285,8 @@ __global__ __launch_bounds__(NT) void k_qr_panel(cplx* __restrict__ A, int lda, 
 //           the read-modify-write of C go straight to global memory, 256 contiguous bytes per group.
 typedef double q_v4d __attribute__((ext_vector_type(4)));
 template<bool TRANS_T>
-__global__ __launch_bounds__(256) void k_qr_apply(const cplx* __restrict__ Vp, int ldv, const cplx* __restrict__ Tn,
+// (256, 2): with 512 registers on offer the compiler parks the accumulators in AGPRs and copies them back and forth in the loops
+__global__ __launch_bounds__(256, 2) void k_qr_apply(const cplx* __restrict__ Vp, int ldv, const cplx* __restrict__ Tn,
                                                    cplx* __restrict__ C, int ldc, int rows, int ncols, int nb, size_t cs) {
     __shared__ cplx sV[64][QR_NB + 1];
     __shared__ cplx sC[64][QR_NB + 1];

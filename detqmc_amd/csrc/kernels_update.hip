@@ -366,30 +366,45 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         cur += OPDIM;
         TICK(2);
         if (tid >= 64) {
-            // ---- E: p = W v and, speculatively (needed only on acceptance), q = u W.  Work item = one dot product
-            //      split over a quad of lanes; items [0, nI MSF) are p(i, b), items [nI MSF, 2 nI MSF) are q(a, i). ----
-            const int nitems = 2 * nI * MSF;
+            // ---- E: p = W v and, speculatively (needed only on acceptance), q = u W.  Work item = one ROW of p (all MSF entries
+            //      from one pass over row i of W) or one COLUMN of q, split over a quad of lanes; items [0, nI) are p(i, :), items
+            //      [nI, 2 nI) are q(:, i).  Two independent accumulator sets per lane (even / odd trips) keep two rounds of LDS reads
+            //      in flight: the dependent fma chain of a single accumulator left the LDS latency of every trip exposed. ----
+            const int nitems = 2 * nI;
             for (int t = tid - 64; t < 4 * nitems; t += 192) {
-                int item = t >> 2, part = t & 3;
-                cplx acc = make_double2(0.0, 0.0);
-                cplx* dst;
-                if (item < nI * MSF) {
-                    int i = item / MSF, b = item - i * MSF;
-                    const cplx* wrow = W + i * WS;
-                    for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(wrow[i2], sv[i2 * MSF + b], acc);
-                    dst = sp + i * MSF + b;
-                } else {
-                    int it2 = item - nI * MSF;
-                    int a = 0;
+                const int item = t >> 2, part = t & 3;
+                cplx acc0[MSF], acc1[MSF];
 #pragma unroll
-                    for (int q = 1; q < MSF; ++q) a += (it2 >= q * nI) ? 1 : 0;
-                    const int i = it2 - a * nI;
-                    for (int i2 = part; i2 < nI; i2 += 4) acc = u_cfma(su[a * WD + i2], W[i2 * WS + i], acc);
-                    dst = sq + a * WD + i;
+                for (int b = 0; b < MSF; ++b) { acc0[b] = make_double2(0.0, 0.0); acc1[b] = make_double2(0.0, 0.0); }
+                const bool isp = item < nI;
+                const int i = isp ? item : item - nI;
+                // p: W[i][i2] v[i2][b];  q: u[a][i2] W[i2][i]
+                const cplx* wp = isp ? W + i * WS : W + i;
+                const int wstep = isp ? 1 : WS;
+                const cplx* xp = isp ? sv : su;
+                const int xstep = isp ? MSF : 1, xsel = isp ? 1 : WD;        // operand (i2, b): xp[i2 * xstep + b * xsel]
+                int i2 = part;
+                for (; i2 + 4 < nI; i2 += 8) {
+                    const cplx w0 = wp[i2 * wstep], w1 = wp[(i2 + 4) * wstep];
+#pragma unroll
+                    for (int b = 0; b < MSF; ++b) {
+                        const cplx x0 = xp[i2 * xstep + b * xsel], x1 = xp[(i2 + 4) * xstep + b * xsel];
+                        acc0[b] = u_cfma(w0, x0, acc0[b]);
+                        acc1[b] = u_cfma(w1, x1, acc1[b]);
+                    }
                 }
-                acc.x = u_dpp_add<0xB1, 0xf>(acc.x); acc.y = u_dpp_add<0xB1, 0xf>(acc.y);     // quad sum
-                acc.x = u_dpp_add<0x4E, 0xf>(acc.x); acc.y = u_dpp_add<0x4E, 0xf>(acc.y);
-                if (part == 0) *dst = acc;
+                if (i2 < nI) {
+                    const cplx w0 = wp[i2 * wstep];
+#pragma unroll
+                    for (int b = 0; b < MSF; ++b) acc0[b] = u_cfma(w0, xp[i2 * xstep + b * xsel], acc0[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < MSF; ++b) {
+                    cplx acc = make_double2(acc0[b].x + acc1[b].x, acc0[b].y + acc1[b].y);
+                    acc.x = u_dpp_add<0xB1, 0xf>(acc.x); acc.y = u_dpp_add<0xB1, 0xf>(acc.y);     // quad sum
+                    acc.x = u_dpp_add<0x4E, 0xf>(acc.x); acc.y = u_dpp_add<0x4E, 0xf>(acc.y);
+                    if (part == 0) { if (isp) sp[i * MSF + b] = acc; else sq[b * WD + i] = acc; }
+                }
             }
         } else {
             // ---- D (wave 0): the candidate's scalars (broadcast LDS reads), bosonic action (deltaSPhi, :4186-4239)
@@ -559,20 +574,38 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 }
             // block bordering of W straight from p and q in LDS (pF is formed on the fly: no staging, no barrier):
             //   W11 += (p F) q ;  W12 = p F ;  W21 = F q ;  W22 = F
-            for (int t = tid; t < nI * nI; t += 256) {
-                int i = t / nI, i2 = t - i * nI;
-                cplx pi[MSF];
+            // A lane owns column i2 of W11 (its q entries stay in registers), a wave walks the rows i = wave, wave + 4, ...: no
+            // integer division by nI, the row's p entries are broadcast reads, four rows in flight per trip.
+            if (lane < nI) {
+                cplx qc[MSF];
 #pragma unroll
-                for (int q = 0; q < MSF; ++q) pi[q] = sp[i * MSF + q];
-                cplx acc = W[i * WS + i2];
+                for (int b = 0; b < MSF; ++b) qc[b] = sq[b * WD + lane];
+                const int wv = tid >> 6;
+                for (int i = wv; i < nI; i += 16) {
+                    cplx wold[4], pf[4][MSF];
 #pragma unroll
-                for (int b = 0; b < MSF; ++b) {
-                    cplx pf = make_double2(0.0, 0.0);
+                    for (int r = 0; r < 4; ++r) {
+                        const int ir = min(i + 4 * r, nI - 1);
+                        wold[r] = W[ir * WS + lane];
+                        cplx pi[MSF];
 #pragma unroll
-                    for (int q = 0; q < MSF; ++q) pf = u_cfma(pi[q], F[q][b], pf);
-                    acc = u_cfma(pf, sq[b * WD + i2], acc);
+                        for (int q = 0; q < MSF; ++q) pi[q] = sp[ir * MSF + q];
+#pragma unroll
+                        for (int b = 0; b < MSF; ++b) {
+                            cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+                            for (int q = 0; q < MSF; ++q) acc = u_cfma(pi[q], F[q][b], acc);
+                            pf[r][b] = acc;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        cplx acc = wold[r];
+#pragma unroll
+                        for (int b = 0; b < MSF; ++b) acc = u_cfma(pf[r][b], qc[b], acc);
+                        if (i + 4 * r < nI) W[(i + 4 * r) * WS + lane] = acc;
+                    }
                 }
-                W[i * WS + i2] = acc;
             }
             for (int i = tid; i < nI; i += 256) {
                 cplx pi[MSF];

@@ -79,7 +79,8 @@ CASES = {
                        drop=("init_coshTermPhi", "init_sinhTermPhi", "init_udv"), subsample=32, hash_fields=True),
     # BASELINE config 5's size (O(3) L = 24, beta = 20, n_g = 2304; no flux -- the reference rejects weakZflux for opdim 3,
     # src/detsdwparams.cpp:57-60): the state after construction only (200 B-multiplies + 20 SVDs of 2304 x 2304 on the CPU)
-    "o3_L24_b20_init": dict(args=dict(opdim=3, L=24, beta=20, s=10, delaySteps=16, sweeps=0, sliceTrace=0, setupOnly=1),
+    # round 3: plus ONE updateInSlice (k = m) and the wrap behind it -- 576 accept / reject decisions at n_g = 2304 from the reference
+    "o3_L24_b20_init": dict(args=dict(opdim=3, L=24, beta=20, s=10, delaySteps=16, sweeps=0, sliceTrace=2, setupOnly=1),
                             drop=("init_coshTermPhi", "init_sinhTermPhi", "init_udv_U", "init_udv_Vt", "sweep"), subsample=64,
                             hash_fields=True, threads=4),
     # one FULL Green's function at the headline size (closes the gap the sub-sampled checksums leave)

@@ -9,6 +9,7 @@
 // Usage: ref_harness <outdir> key=value ...
 //   mode=dump   : write fixtures for one parameter set
 //   mode=time   : run sweeps and print sweeps/s (CPU baseline, kind "reference")
+//   mode=timeparts : time the slices of the top block and one stabilisation step (CPU baseline at sizes where a sweep takes hours)
 //
 // Reference entry points exercised (file:line in /root/reference/src):
 //   createReplica                      detsdwopdim.cpp:49-84
@@ -212,6 +213,27 @@ static int run(const std::map<std::string, std::string>& kv) {
         return 0;
     }
 
+    if (mode == "timeparts") {
+        // CPU baseline for sizes where a whole reference sweep takes hours (n_g = 2304): the slices of the top partial block and
+        // ONE stabilisation step (advanceDownGreen through greenFromUdV: the general case) of a down sweep, timed separately; the
+        // caller extrapolates  sweep = m * slice + n * advance.  Run it at a small beta (m >= 3) -- the per-slice and per-step
+        // costs depend on the lattice, not on beta.
+        typename SDW::sdwLeftMultiplyBmatInv lInv(rep.get());
+        typename SDW::sdwRightMultiplyBmat rB(rep.get());
+        auto t0 = std::chrono::steady_clock::now();
+        uint32_t nsl = 0;
+        for (uint32_t k = m; k >= (n - 1) * s + 1; --k) {
+            rep->updateInSliceThermalization(k);
+            rep->wrapDownGreen(lInv, rB, k, 0);
+            ++nsl;
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        rep->advanceDownGreen(rB, n, 0);
+        auto t2 = std::chrono::steady_clock::now();
+        printf("REF_PARTS slices=%u slice_seconds=%.6f advance_seconds=%.6f m=%u n=%u s=%u ng=%u\n", nsl,
+               std::chrono::duration<double>(t1 - t0).count() / nsl, std::chrono::duration<double>(t2 - t1).count(), m, n, s, ng);
+        return 0;
+    }
     {
         arma::Col<double> meta(8);
         meta[0] = pars.opdim; meta[1] = pars.L; meta[2] = m; meta[3] = s; meta[4] = n; meta[5] = ng;
@@ -272,6 +294,8 @@ static int run(const std::map<std::string, std::string>& kv) {
         typename SDW::sdwRightMultiplyBmat rB(rep.get());
         rep->wrapDownGreen(lInv, rB, m, 0);
         dump("slice_g_wrapped", rep->g);
+        // sliceTrace=2: this one slice only (the largest sizes: a full CPU sweep at n_g = 2304 takes hours)
+        if (get<int>(kv, "sliceTrace", 1) == 2) { dump_scalar("slice_phiDelta", rep->ad.phiDelta); return 0; }
         for (uint32_t k = m - 1; k >= (n - 1) * s + 1; --k) {
             rep->updateInSliceThermalization(k);
             rep->wrapDownGreen(lInv, rB, k, 0);
@@ -363,7 +387,7 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
-    if (mode != "time") g_manifest.open(g_outdir + "/manifest.txt");
+    if (mode != "time" && mode != "timeparts") g_manifest.open(g_outdir + "/manifest.txt");
 
     uint32_t opdim = get<uint32_t>(kv, "opdim", 2);
     try {

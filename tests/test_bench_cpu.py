@@ -76,3 +76,16 @@ def test_roofline_block_reports_the_binding_roof():
     assert 0 < whole["hbm_frac"] < 1 and 0 < whole["mfma_frac"] < 1
     for r in roofs:
         assert r["frac"] == max(r["hbm_frac"], r["mfma_frac"]) and r["peak"] in (bench.HBM_PEAK_GBS, bench.MFMA_F64_PEAK_TF)
+
+
+def test_bench_exits_nonzero_when_a_worker_dies():
+    """A worker process that dies in the timed region (here: the stand-in worker of GPU 1 exits with status 7) must end
+    `python bench.py --gpus 2` with a non-zero status and the worker's exit code in the message -- and without a JSON line
+    (a scaling run must not report the surviving GPUs' rate as the job's)."""
+    env = _env(DQMC_BENCH_FAKE_DIE="1:7")
+    env.pop("DQMC_BENCH_ONE_DEVICE")           # the stand-in workers must see their real device ordinals
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0
+    assert "exit code 7" in out.stderr, out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

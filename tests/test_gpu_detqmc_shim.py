@@ -168,6 +168,27 @@ def test_detqmcpt_driver_with_gpu_model_over_mpi_writes_the_reference_output_tre
         assert os.path.exists(tmp_path / ("simulation.%d.state" % p))
 
 
+def test_one_device_per_rank_without_enough_devices_fails_cleanly(tmp_path):
+    """Multi-GPU readiness on a one-GPU box: `mpiexec -n 2 detqmcptsdwgpu` with DQMC_DEVICE_PER_RANK=1 asks for device 1, which this
+    box does not have.  dqmc_create must answer DQMC_ENODEV, rank 1 must report it and abort the job (MPI_Abort through the
+    reference driver's own error path) -- no hang, no partial output tree.  Reference behaviour for a rank / parameter mismatch:
+    /root/reference/src/detqmcpt.h:285-289 (throws at start-up), :805-851 (all ranks stop together)."""
+    import time
+    assert os.path.exists(PT_EXE) and os.path.exists(MPIEXEC)
+    _mpilib()
+    conf = [l for l in open(os.path.join(PT_CASE, "simulation.conf")) if not l.startswith("rValues = -1.1") and not l.startswith("rValues = -1.0")]
+    (tmp_path / "simulation.conf").write_text("".join(conf))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DQMC_DEVICE_PER_RANK="1")
+    env.pop("DQMC_DEVICE", None)
+    t0 = time.time()
+    out = subprocess.run([MPIEXEC, "-n", "2", PT_EXE, "-c", "simulation.conf"], cwd=str(tmp_path), capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0, out.stdout[-2000:]
+    assert "rank 1" in out.stderr and "device ordinal out of range" in out.stderr, out.stderr[-3000:]
+    assert time.time() - t0 < 120
+    assert not [d for d in os.listdir(tmp_path) if d.startswith("p0_") or d.startswith("p1_") or d.startswith("exchange-")]
+
+
 @pytest.mark.parametrize("launch", ["one process, 4 replicas in one batch", "2 processes x 2 replicas (gloo)"])
 def test_python_replica_exchange_driver_writes_the_reference_output_tree(tmp_path, launch):
     """The repo's OWN replica-exchange driver -- scripts/run_pt.py over detqmc_amd/pt.py (replica_exchange_step, ObservableRouterPT,
