@@ -831,7 +831,8 @@ static int udt_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
     cplx* Tt = transpose ? out.U : out.Vt;
     SvdProfHooks hk;
     c->qw.apply_hooks = qr_hooks(c, hk);
-    int launches = run_qr(c->lc, n, c->sw.A, Q, c->qw);
+    // n > 1024: block Gram-Schmidt + Cholesky-QR2 on the GEMM kernel instead of 144 tall Householder panels (kernels_qr.hip)
+    int launches = qr_use_bgs(n) ? run_qr_bgs(c->lc, n, c->sw.A, Q, c->qw) : run_qr(c->lc, n, c->sw.A, Q, c->qw);
     launch_udt_diag(c->lc, c->sw.A, n, out.d);
     if (lazy) launch_udt_lazy(c->lc, out.d, c->qr_perm, n, c->qr_dinv, c->qr_perm_inv);
     else launch_udt_tmat(c->lc, c->sw.A, out.d, c->qr_perm, n, Tt);
@@ -880,14 +881,24 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
         launch_udt_init(c->lc, c->T2, n, nullptr, nullptr, c->qr_perm, 0, c->sw.A, n);
         SvdProfHooks hk;
         c->qw.apply_hooks = qr_hooks(c, hk);
-        int launches = run_qr(c->lc, n, c->sw.A, nullptr, c->qw);        // sw.A = R factor, Q stays in reflector form
+        static const bool green_bgs = getenv("DQMC_GREEN_BGS") ? atoi(getenv("DQMC_GREEN_BGS")) != 0 : false;
+        const bool bgs = green_bgs && qr_use_bgs(n);                      // Z is not a graded B-chain: Householder unless asked otherwise
+        int launches = bgs ? run_qr_bgs(c->lc, n, c->sw.A, c->T4, c->qw)   // explicit Q in T4
+                           : run_qr(c->lc, n, c->sw.A, nullptr, c->qw);    // sw.A = R factor, Q stays in reflector form
         launch_permute_scale_cols(c->lc, L.Vt, c->lmax_inv, c->qr_perm, n, c->T3);
         launches += run_trsm_right_upper(c->lc, n, c->sw.A, c->T3, c->qw);   // T3 = (V_l Dlmax^-1 P) R^-1
         launch_logdet_vector(c->lc, c->sw.A, c->rmax_inv, c->lmax_inv, n, c->sv);
-        launch_udt_init(c->lc, R.U, n, c->rmax_inv, nullptr, nullptr, 1, c->T1, n);   // T1 = Drmax^-1 U_r^H
-        launches += run_qr_apply_q(c->lc, n, c->T1, c->qw, 1);            // T1 = Q^H Drmax^-1 U_r^H: Q is never formed
-        c->fam_launches[FAM_JACOBI] += launches + 6;
-        c->qr_calls += 1;
+        if (bgs) {
+            launch_udt_init(c->lc, R.U, n, c->rmax_inv, nullptr, nullptr, 1, c->sw.V, n);   // sw.V = Drmax^-1 U_r^H
+            c->fam_launches[FAM_JACOBI] += launches + 6;
+            c->qr_calls += 1;
+            gemm_dev(c, 1, 0, c->T4, c->sw.V, c->T1);                     // T1 = Q^H Drmax^-1 U_r^H
+        } else {
+            launch_udt_init(c->lc, R.U, n, c->rmax_inv, nullptr, nullptr, 1, c->T1, n);   // T1 = Drmax^-1 U_r^H
+            launches += run_qr_apply_q(c->lc, n, c->T1, c->qw, 1);            // T1 = Q^H Drmax^-1 U_r^H: Q is never formed
+            c->fam_launches[FAM_JACOBI] += launches + 6;
+            c->qr_calls += 1;
+        }
     }
     gemm_dev(c, 0, 0, c->T3, c->T1, c->G);                                 // G = T3 T1
     return DQMC_OK;

@@ -182,7 +182,10 @@ size_t measure_accum_doubles(int N, int L);
 struct SvdProfHooks;
 struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; const SvdProfHooks* apply_hooks; };   // hooks: optional timing of the k_qr_apply launches
 int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit (Q == nullptr: reflectors only)
-int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans);       // C <- Q C or Q^H C with the reflectors of the last run_qr
+int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans);
+// large n: QR by block Gram-Schmidt with reorthogonalisation + Cholesky-QR2 panels, all on the GEMM kernel (kernels_qr.hip); Q is always explicit
+bool qr_use_bgs(int n);
+int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);
 int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w, int trans = 0, int unit = 0);   // C <- C R^-1 (trans: R = (stored lower triangle)^H; unit: unit diagonal)
 #define LU_SWAP_INTS 128
 int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps);                                 // P A = L U in place (n <= 512, else -1), kernels_lu.hip

@@ -828,6 +828,130 @@ int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// QR of LARGE matrices (n > 1024: O(3) lattices, n_g = 2304 at L = 24) WITHOUT tall panels.
+//
+// A 2304 x 16 complex panel is more than the register file of one CU holds: the register-resident panel kernel spills there
+// (400 - 770 us per panel), a left-looking streaming panel is no faster (scripts/micro/attic/qr_panel_stream.hip.txt), and with 144
+// panels + 288 block-reflector launches per factorisation a Householder QR of one 2304 x 2304 matrix takes ~ 90 ms of dependent
+// small launches -- 60 % of a config-5 sweep.  The matrix cores want GEMMs instead:
+//
+//   block classical Gram-Schmidt with reorthogonalisation (BCGS2), block width 64, panels by Cholesky-QR, twice (CholQR2):
+//       W1 = Q_prev^H A_j;  A_j -= Q_prev W1;  W2 = Q_prev^H A_j;  A_j -= Q_prev W2;        R[prev, j] = W1 + W2
+//       G = A_j^H A_j = R1^H R1;  A_j <- A_j R1^-1;   G' = A_j^H A_j = R2^H R2;  Q_j = A_j R2^-1;    R[j, j] = R2 R1
+//   -- 2 n^3 complex multiply-adds (Householder incl. forming Q: 8/3 n^3), all of them in k_zgemm launches that carry every chain.
+//
+// Why it is accurate HERE: the matrices factored are B-chains times scales, columns pre-pivoted by norm.  Gram-Schmidt and
+// Cholesky are invariant under column scaling (rounding errors are relative per column), so what matters is the conditioning of
+// the column-EQUILIBRATED matrix -- a product of s = 10 slice matrices and a unitary factor, kappa ~ 10^2 - 10^3, far from the
+// 10^8 where Cholesky-QR's kappa^2 breaks down; the second pass of each stage restores orthogonality to rounding (BCGS2: Barlow &
+// Smoktunowicz 2013; CholQR2: Yamamoto et al. 2015).  Checked like the Householder path: tests/test_gpu_parity.py (Q unitary to
+// 1e-11, G against the reference's CPU construction at n_g = 2304 to 1e-10, DQMC_QR_BGS=1 forces it on the small fixtures).
+// ---------------------------------------------------------------------------------------------
+#define BGS_NB 64
+// Cholesky factor of the nb x nb Hermitian block at (j0, j0) of Gm (upper triangle read), R upper with R^H R = G written back in
+// place (strict lower part zeroed).  If R1m != nullptr its block at (j0, j0) is replaced by R R1 (second CholQR pass: R_jj = R2 R1).
+// ONE wavefront per chain, the block in LDS, lane = column: LDS operations of one wave complete in order, so no barrier is needed.
+__global__ __launch_bounds__(64) void k_chol64(cplx* __restrict__ Gm, int ld, int j0, int nb, cplx* __restrict__ R1m, size_t cs) {
+    __shared__ cplx s[BGS_NB][BGS_NB + 1];
+    __shared__ cplx s1[BGS_NB][BGS_NB + 1];
+    CHAIN(Gm); CHAIN(R1m);
+    const int j = threadIdx.x;
+    for (int i = 0; i < nb; ++i) {
+        s[i][j] = (j < nb && i <= j) ? Gm[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
+        if (R1m) s1[i][j] = (j < nb && i <= j) ? R1m[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
+    }
+    for (int k = 0; k < nb; ++k) {
+        const double d = sqrt(fmax(s[k][k].x, 1e-300));
+        if (j >= k && j < nb) {
+            const cplx g = s[k][j];
+            const cplx r = (j == k) ? make_double2(d, 0.0) : make_double2(g.x / d, g.y / d);
+            s[k][j] = r;
+        }
+        if (j > k && j < nb) {
+            const cplx rkj = s[k][j];
+            for (int i = k + 1; i <= j; ++i) {
+                const cplx rki = s[k][i];                     // conj(r_ki) r_kj
+                cplx g = s[i][j];
+                g.x -= rki.x * rkj.x + rki.y * rkj.y;
+                g.y -= rki.x * rkj.y - rki.y * rkj.x;
+                s[i][j] = g;
+            }
+        }
+    }
+    if (j < nb) {
+        for (int i = 0; i < nb; ++i) Gm[(size_t)(j0 + j) * ld + (j0 + i)] = (i <= j) ? s[i][j] : make_double2(0.0, 0.0);
+        if (R1m) {
+            for (int i = 0; i <= j; ++i) {                   // (R2 R1)[i][j] = sum_{q = i .. j} R2[i][q] R1[q][j]
+                cplx acc = make_double2(0.0, 0.0);
+                for (int q = i; q <= j; ++q) {
+                    const cplx a = s[i][q], b = s1[q][j];
+                    acc.x += a.x * b.x - a.y * b.y;
+                    acc.y += a.x * b.y + a.y * b.x;
+                }
+                R1m[(size_t)(j0 + j) * ld + (j0 + i)] = acc;
+            }
+        }
+    }
+}
+// C[0:rows, 0:cols] += D[0:rows, 0:cols] (both with leading dimension ld)
+__global__ void k_add_block(cplx* __restrict__ C, const cplx* __restrict__ D, int ld, int rows, int cols, size_t cs) {
+    CHAIN(C); CHAIN(D);
+    const size_t total = (size_t)rows * cols;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % rows), jj = (int)(idx / rows);
+        const size_t o = (size_t)jj * ld + i;
+        const cplx d = D[o];
+        cplx c = C[o];
+        c.x += d.x; c.y += d.y;
+        C[o] = c;
+    }
+}
+__global__ void k_zero(cplx* __restrict__ A, size_t count, size_t cs) {
+    CHAIN(A);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < count; idx += (size_t)gridDim.x * blockDim.x) A[idx] = make_double2(0.0, 0.0);
+}
+bool qr_use_bgs(int n) {
+    static const int env = getenv("DQMC_QR_BGS") ? atoi(getenv("DQMC_QR_BGS")) : -1;      // 1 / 0: force on / off (tests, A/B)
+    return env >= 0 ? env != 0 : n > 1024;
+}
+// A (n x n, ld n) -> R in place (upper triangular, positive diagonal), Q explicit (n x n); w.V is scratch.  Returns the launch count.
+int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
+    int launches = 0;
+    const size_t n2 = (size_t)n * n;
+    launch_copy(lc, A, Q, n2);                                     // the columns of the working copy become Q
+    hipLaunchKernelGGL(k_zero, dim3(1024, 1, lc.nb), dim3(256), 0, lc.st, A, n2, lc.cs);
+    launches += 2;
+    cplx* S = w.V;
+    auto gemm = [&](int opA, const cplx* Am, int opB, const cplx* Bm, cplx* Cm, int M, int N, int K, int sub) {
+        GemmArgs g = GemmArgs();
+        g.A = Am; g.lda = n; g.opA = opA; g.B = Bm; g.ldb = n; g.opB = opB; g.C = Cm; g.ldc = n;
+        g.M = M; g.N = N; g.K = K; g.Kmul = 1; g.accumulate = sub; g.negate = sub; g.tag = 1;
+        launch_gemm(lc, g);
+        ++launches;
+    };
+    for (int j0 = 0; j0 < n; j0 += BGS_NB) {
+        const int b = (n - j0 < BGS_NB) ? (n - j0) : BGS_NB;
+        cplx* Qj = Q + (size_t)j0 * n;
+        cplx* Rj = A + (size_t)j0 * n;                               // rows 0 .. j0 - 1 of R's block column
+        if (j0 > 0) {
+            gemm(1, Q, 0, Qj, Rj, j0, b, n, 0);                      // W1 = Q_prev^H A_j
+            gemm(0, Q, 0, Rj, Qj, n, b, j0, 1);                      // A_j -= Q_prev W1
+            gemm(1, Q, 0, Qj, S, j0, b, n, 0);                       // W2 = Q_prev^H A_j   (what the first pass left behind)
+            gemm(0, Q, 0, S, Qj, n, b, j0, 1);                       // A_j -= Q_prev W2
+            hipLaunchKernelGGL(k_add_block, dim3(64, 1, lc.nb), dim3(256), 0, lc.st, Rj, S, n, j0, b, lc.cs);
+            ++launches;
+        }
+        gemm(1, Qj, 0, Qj, Rj + j0, b, b, n, 0);                     // G = A_j^H A_j into R's diagonal block
+        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(64), 0, lc.st, A, n, j0, b, (cplx*)nullptr, lc.cs);
+        launches += 1 + trsm_rec(lc, n, A, Q, j0, b, 0, 0);          // A_j <- A_j R1^-1
+        gemm(1, Qj, 0, Qj, S + (size_t)j0 * n + j0, b, b, n, 0);     // second pass: G' = A_j^H A_j (close to the identity)
+        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(64), 0, lc.st, S, n, j0, b, A, lc.cs);   // R2; R_jj = R2 R1
+        launches += 1 + trsm_rec(lc, n, S, Q, j0, b, 0, 0);          // Q_j = A_j R2^-1
+    }
+    return launches;
+}
+
+// ---------------------------------------------------------------------------------------------
 // glue for the UDT decomposition  Ms P = Q R  ->  (Q, d, T^H) resp. (T^H, d, Q)
 // ---------------------------------------------------------------------------------------------
 // W[:, perm[j]] = Ms[:, j] (or Ms^H when T != 0), Ms = diag(rowscale) M diag(colscale); perm == nullptr: identity

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     static_assert(O_GCC % 2 == 0, "complex items must be 16-byte aligned in LDS");
     __shared__ __attribute__((aligned(16))) double scand[NIT * 64];
     __shared__ __attribute__((aligned(16))) double sdec[4 * MSF * MSF + 2];   // wave 0 -> all: delta, G[c,c], exp(-dS), uniform
+    __shared__ cplx salg[MSF == 4 ? 4 * 80 : 1];                              // O(3): wave-private scratch of the 4 x 4 algebra (S, M', cofactors, M'^-1, F)
 
     auto neighbours = [&](int s, int (&nbr)[4]) {
         // neighbortable.h:34-36 (XPLUS, XMINUS, YPLUS, YMINUS), computed: a table look-up would put a dependent
@@ -491,18 +492,20 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         __syncthreads();                              // barrier 2 of 2: p, q visible
         TICK(5);
         // ---- every thread picks up what wave 0 published ----
-        cplx delta[MSF][MSF], Gcc[MSF][MSF];
-#pragma unroll
-        for (int a = 0; a < MSF; ++a)
-#pragma unroll
-            for (int b = 0; b < MSF; ++b) {
-                delta[a][b] = *(const cplx*)&sdec[2 * (a * MSF + b)];
-                Gcc[a][b] = *(const cplx*)&sdec[2 * MSF * MSF + 2 * (a * MSF + b)];
-            }
         const double probSPhi = sdec[4 * MSF * MSF], uacc = sdec[4 * MSF * MSF + 1];
-        // ---- G: S = Gcc + u p ----
-        cplx S[MSF][MSF];
-        if (MSF == 2) {
+        cplx delta[MSF == 2 ? 2 : 1][MSF == 2 ? 2 : 1], Minv[MSF == 2 ? 2 : 1][MSF == 2 ? 2 : 1];
+        cplx det;
+        if constexpr (MSF == 2) {
+            cplx Gcc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    delta[a][b] = *(const cplx*)&sdec[2 * (a * 2 + b)];
+                    Gcc[a][b] = *(const cplx*)&sdec[2 * 4 + 2 * (a * 2 + b)];
+                }
+            // ---- G: S = Gcc + u p ----
+            cplx S[2][2];
             // 16 lanes per entry (a, b) = (lane >> 5, (lane >> 4) & 1); sum within the DPP row, then 8 readlanes
             const int e_a = lane >> 5, e_b = (lane >> 4) & 1, l16 = lane & 15;
             cplx part = make_double2(0.0, 0.0);
@@ -522,30 +525,71 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                                                  __builtin_amdgcn_readlane(__double2loint(part.y), src));
                     S[a][b] = make_double2(Gcc[a][b].x + re, Gcc[a][b].y + im);
                 }
-        } else {
+            TICK(6);
+            // ---- M' = 1 + (1 - S) delta ; det ; acceptance ----
+            cplx Mj[2][2];
 #pragma unroll
-            for (int a = 0; a < MSF; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < MSF; ++b) {
-                    cplx part = make_double2(0.0, 0.0);
-                    for (int i = lane; i < nI; i += 64) part = u_cfma(su[a * WD + i], sp[i * MSF + b], part);
-                    S[a][b] = make_double2(Gcc[a][b].x + u_wave_total(part.x), Gcc[a][b].y + u_wave_total(part.y));
+                for (int b = 0; b < 2; ++b) {
+                    cplx acc = make_double2((a == b ? 1.0 : 0.0) + delta[a][b].x, delta[a][b].y);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc = u_cfma(make_double2(-S[a][q].x, -S[a][q].y), delta[q][b], acc);
+                    Mj[a][b] = acc;
                 }
-        }
-        TICK(6);
-        // ---- M' = 1 + (1 - S) delta ; det ; acceptance ----
-        cplx Mj[MSF][MSF], Minv[MSF][MSF];
-#pragma unroll
-        for (int a = 0; a < MSF; ++a)
-#pragma unroll
-            for (int b = 0; b < MSF; ++b) {
-                cplx acc = make_double2((a == b ? 1.0 : 0.0) + delta[a][b].x, delta[a][b].y);
-#pragma unroll
-                for (int q = 0; q < MSF; ++q)
-                    acc = u_cfma(make_double2(-S[a][q].x, -S[a][q].y), delta[q][b], acc);
-                Mj[a][b] = acc;
+            det = small_det_inv<2>(Mj, Minv);
+        } else {
+            // ---- O(3): the 4 x 4 complex algebra of a decision is spread over the lanes of the wave instead of being done in full by
+            //      every thread (round 2: 16 wave-wide reductions for S, a Gauss-Jordan inverse with run-time pivot selects in each
+            //      thread -- about a thousand fp64 instructions and 326 registers; 5.4 us per proposal at n_g = 2304).  Lane (e, sub):
+            //      entry e = (a, b) of a 4 x 4 matrix, sub = one of the four terms of its sum; the matrices hop through a wave-private
+            //      LDS scratch (LDS operations of one wave complete in order: no barrier).  Inverse by cofactors (M' = 1 + (1 - S)
+            //      delta is a well-conditioned 4 x 4 matrix; the reference's LAPACK inverse agrees to rounding). ----
+            cplx* aS = salg + (tid >> 6) * 80;
+            cplx* aM = aS + 16; cplx* aC = aS + 32; cplx* aI = aS + 48;
+            const int e = lane >> 2, sub = lane & 3, ea = e >> 2, eb = e & 3;
+            auto quadsum = [&](cplx v) {
+                v.x = u_dpp_add<0xB1, 0xf>(v.x); v.y = u_dpp_add<0xB1, 0xf>(v.y);
+                v.x = u_dpp_add<0x4E, 0xf>(v.x); v.y = u_dpp_add<0x4E, 0xf>(v.y);
+                return v;
+            };
+            {   // S = Gcc + u p
+                cplx part = make_double2(0.0, 0.0);
+                for (int i = sub; i < nI; i += 4) part = u_cfma(su[ea * WD + i], sp[i * MSF + eb], part);
+                part = quadsum(part);
+                const cplx g = *(const cplx*)&sdec[2 * MSF * MSF + 2 * e];
+                if (sub == 0) aS[e] = make_double2(g.x + part.x, g.y + part.y);
             }
-        cplx det = small_det_inv<MSF>(Mj, Minv);
+            TICK(6);
+            {   // M' = 1 + delta - S delta: lane sub carries the term q = sub
+                const cplx t = quadsum(u_cmul(aS[ea * 4 + sub], *(const cplx*)&sdec[2 * (sub * 4 + eb)]));
+                const cplx d = *(const cplx*)&sdec[2 * e];
+                if (sub == 0) aM[e] = make_double2((ea == eb ? 1.0 : 0.0) + d.x - t.x, d.y - t.y);
+            }
+            {   // cofactor of entry (ea, eb): signed 3 x 3 minor
+                const int r0 = (ea == 0) ? 1 : 0, r1 = (ea <= 1) ? 2 : 1, r2 = (ea == 3) ? 2 : 3;
+                const int c0 = (eb == 0) ? 1 : 0, c1 = (eb <= 1) ? 2 : 1, c2 = (eb == 3) ? 2 : 3;
+                const cplx m00 = aM[r0 * 4 + c0], m01 = aM[r0 * 4 + c1], m02 = aM[r0 * 4 + c2];
+                const cplx m10 = aM[r1 * 4 + c0], m11 = aM[r1 * 4 + c1], m12 = aM[r1 * 4 + c2];
+                const cplx m20 = aM[r2 * 4 + c0], m21 = aM[r2 * 4 + c1], m22 = aM[r2 * 4 + c2];
+                const cplx k0 = u_csub(u_cmul(m11, m22), u_cmul(m12, m21));
+                const cplx k1 = u_csub(u_cmul(m10, m22), u_cmul(m12, m20));
+                const cplx k2 = u_csub(u_cmul(m10, m21), u_cmul(m11, m20));
+                cplx d3 = u_csub(u_cmul(m00, k0), u_cmul(m01, k1));
+                d3 = u_cfma(m02, k2, d3);
+                const double sg = ((ea + eb) & 1) ? -1.0 : 1.0;
+                if (sub == 0) aC[e] = make_double2(sg * d3.x, sg * d3.y);
+            }
+            det = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) det = u_cfma(aM[q], aC[q], det);          // expansion along row 0
+            {
+                const double dn = det.x * det.x + det.y * det.y;
+                const cplx idet = make_double2(det.x / dn, -det.y / dn);
+                if (sub == 0) aI[e] = u_cmul(aC[eb * 4 + ea], idet);              // M'^-1 = adj(M') / det
+            }
+        }
         double probSFermion = (OPDIM == 3) ? det.x : (det.x * det.x + det.y * det.y);
         double prob = probSPhi * probSFermion;
         bool accept = prob > 1.0;
@@ -563,15 +607,29 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             }
             // F = delta M'^-1
             cplx F[MSF][MSF];
+            if constexpr (MSF == 2) {
 #pragma unroll
-            for (int a = 0; a < MSF; ++a)
+                for (int a = 0; a < MSF; ++a)
 #pragma unroll
-                for (int b = 0; b < MSF; ++b) {
-                    cplx acc = make_double2(0.0, 0.0);
+                    for (int b = 0; b < MSF; ++b) {
+                        cplx acc = make_double2(0.0, 0.0);
 #pragma unroll
-                    for (int q = 0; q < MSF; ++q) acc = u_cfma(delta[a][q], Minv[q][b], acc);
-                    F[a][b] = acc;
-                }
+                        for (int q = 0; q < MSF; ++q) acc = u_cfma(delta[a][q], Minv[q][b], acc);
+                        F[a][b] = acc;
+                    }
+            } else {
+                cplx* aI = salg + (tid >> 6) * 80 + 48;
+                cplx* aF = salg + (tid >> 6) * 80 + 64;
+                const int e = lane >> 2, sub = lane & 3, ea = e >> 2, eb = e & 3;
+                cplx t = u_cmul(*(const cplx*)&sdec[2 * (ea * 4 + sub)], aI[sub * 4 + eb]);
+                t.x = u_dpp_add<0xB1, 0xf>(t.x); t.y = u_dpp_add<0xB1, 0xf>(t.y);
+                t.x = u_dpp_add<0x4E, 0xf>(t.x); t.y = u_dpp_add<0x4E, 0xf>(t.y);
+                if (sub == 0) aF[e] = t;
+#pragma unroll
+                for (int a = 0; a < MSF; ++a)
+#pragma unroll
+                    for (int b = 0; b < MSF; ++b) F[a][b] = aF[a * MSF + b];
+            }
             // block bordering of W straight from p and q in LDS (pF is formed on the fly: no staging, no barrier):
             //   W11 += (p F) q ;  W12 = p F ;  W21 = F q ;  W22 = F
             // A lane owns column i2 of W11 (its q entries stay in registers), a wave walks the rows i = wave, wave + 4, ...: no

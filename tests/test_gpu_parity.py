@@ -959,8 +959,9 @@ def test_config4_L16_beta20_eight_replicas_with_exchange_vs_reference():
 def test_config5_O3_L24_beta20_full_size():
     """BASELINE config 5's size (O(3) L = 24, beta = 20: n_g = 2304, m = 200, n = 20; without the flux, which the
     reference rejects for opdim = 3, src/detsdwparams.cpp:57-60).  G(beta) and log det against the reference's
-    construction (20 SVDs of 2304 x 2304 on the CPU), then a thermalisation sweep with size-independent
-    properties: B^-1 B = 1, wrapped vs re-stabilised G, cosh/sinh caches, unitarity of the chain factor."""
+    construction (20 SVDs of 2304 x 2304 on the CPU), ONE slice of local updates and the wrap behind it against the reference,
+    then a thermalisation sweep with size-independent properties: B^-1 B = 1, wrapped vs re-stabilised G, cosh/sinh caches,
+    unitarity of the chain factor."""
     from detqmc_amd import DetSDW
     g = load_golden("o3_L24_b20_init")
     rep = DetSDW(_sdw_params(g["params"], stabilisation="qr"))
@@ -983,9 +984,34 @@ def test_config5_O3_L24_beta20_full_size():
     ctx.advanceDownGreen(n)
     Ga = ctx.g
     assert relerr(Gw, Ga) < 1e-7, "wrapped and re-stabilised G differ"
-    # back to a consistent state, then one full thermalisation sweep
+    # back to a consistent state
     ctx.setupUdVStorage_and_calculateGreen()
     assert relerr(ctx.g, G) < 1e-12
+    # ONE updateInSlice at full size against the reference (round 3: ref_harness sliceTrace=2 -- updateInSliceThermalization(m)
+    # and wrapDownGreen(m) after the 20 CPU SVDs of the construction; /root/reference/src/detsdwopdim.cpp:3023-3175, 3294-3375):
+    # all 576 accept / reject decisions at n_g = 2304, the updated G and the wrapped G
+    from dsfmt_oracle import RngWrapper
+    op = oracle_params(g["params"]).finalize()
+    r = RngWrapper(op.rngSeed, op.simindex + 1)
+    for _ in range((op.opdim + 1) * op.N * op.m):           # the draws that went into the random field
+        r.rand01()
+    ctx.push_uniforms(np.array([r.rand01() for _ in range((op.opdim + 1) * op.N)]))
+    ctx.updateInSlice(m, thermalization=True)
+    st = ctx.update_state()
+    phi_after = ctx.get_fields()[0]
+    assert np.array_equal(phi_after[m], g["slice_phi_m"]), "accept / reject decisions at n_g = 2304 differ from the reference"
+    assert abs(st.lastAccRatio - g["slice_accRatio"][0]) < 1e-15
+    Gs = ctx.g
+    assert relerr(Gs[::64, ::64], g["slice_g_sub64"]) < TOL and relerr(np.diag(Gs), g["slice_g_diag"]) < TOL
+    assert abs(np.linalg.norm(Gs) - g["slice_g_fro"][0]) < TOL * g["slice_g_fro"][0]
+    ctx.wrapDownGreen(m)
+    Gw = ctx.g
+    assert relerr(Gw[::64, ::64], g["slice_g_wrapped_sub64"]) < TOL and relerr(np.diag(Gw), g["slice_g_wrapped_diag"]) < TOL
+    assert abs(np.linalg.norm(Gw) - g["slice_g_wrapped_fro"][0]) < TOL * g["slice_g_wrapped_fro"][0]
+    # a fresh replica for the full thermalisation sweep (the slice above consumed uniforms outside the replica's RNG bookkeeping)
+    rep.close()
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr"))
+    ctx = rep.kernel_context
     rep.sweepThermalization()
     phi, ch, sh = ctx.get_fields()
     nrm = np.sqrt(np.sum(phi[1:] ** 2, axis=2))
