@@ -613,6 +613,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
         const int np = (ng + 15) / 16;
         A_(dalloc(c, &c->qw.V, n2)); A_(dalloc(c, &c->qw.T, (size_t)np * 2 * 256));
         A_(dalloc(c, &c->qw.W, (size_t)16 * ng)); A_(dalloc(c, &c->qw.W2, (size_t)16 * ng)); A_(dalloc(c, &c->qw.Rneg, (size_t)32 * ng));
+        if (ng > 1024) { c->qw.part_count = (size_t)ng * 64 * 8; A_(dalloc(c, &c->qw.part, c->qw.part_count)); }   // split-K scratch of the block Gram-Schmidt QR
         A_(dalloc(c, &c->qr_perm, (size_t)ng)); A_(dalloc(c, &c->lu_swaps, (size_t)LU_SWAP_INTS)); A_(dalloc(c, &c->qr_perm_inv, (size_t)ng)); A_(dalloc(c, &c->qr_dinv, (size_t)ng));
         A_(dalloc(c, &c->rmax_inv, (size_t)ng)); A_(dalloc(c, &c->rmin, (size_t)ng));
         A_(dalloc(c, &c->lmax_inv, (size_t)ng)); A_(dalloc(c, &c->lmin, (size_t)ng));
@@ -630,6 +631,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     A_(dalloc(c, &c->macc, c->macc_n));
     A_(arena_commit(c));                    // from here on the per-chain pointers are real (chain 0) addresses, zero filled
 #undef A_
+    c->qw.err = &c->us->pub.error;
     hm.phi = c->phi; hm.coshT = c->coshT; hm.sinhT = c->sinhT;
     DevUpdateState hus;
     memset(&hus, 0, sizeof(hus));
@@ -881,8 +883,11 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
         launch_udt_init(c->lc, c->T2, n, nullptr, nullptr, c->qr_perm, 0, c->sw.A, n);
         SvdProfHooks hk;
         c->qw.apply_hooks = qr_hooks(c, hk);
-        static const bool green_bgs = getenv("DQMC_GREEN_BGS") ? atoi(getenv("DQMC_GREEN_BGS")) != 0 : false;
-        const bool bgs = green_bgs && qr_use_bgs(n);                      // Z is not a graded B-chain: Householder unless asked otherwise
+        // the matrix inverted here is not a graded B-chain but the scale-split sum Z (entries O(1)); the block Gram-Schmidt QR holds
+        // on it as well (tests: every QR-mode fixture with DQMC_QR_BGS=1 DQMC_GREEN_QR=1, the reference's G at n_g = 2304); a panel
+        // that loses definiteness raises DQMC_ENOCONV.  DQMC_GREEN_BGS=0 keeps Householder panels for this one.
+        static const bool green_bgs = getenv("DQMC_GREEN_BGS") ? atoi(getenv("DQMC_GREEN_BGS")) != 0 : true;
+        const bool bgs = green_bgs && qr_use_bgs(n);
         int launches = bgs ? run_qr_bgs(c->lc, n, c->sw.A, c->T4, c->qw)   // explicit Q in T4
                            : run_qr(c->lc, n, c->sw.A, nullptr, c->qw);    // sw.A = R factor, Q stays in reflector form
         launch_permute_scale_cols(c->lc, L.Vt, c->lmax_inv, c->qr_perm, n, c->T3);
@@ -1106,7 +1111,8 @@ extern "C" int dqmc_get_update_states_all_host(dqmc_ctx* c, dqmc_update_state* o
     HIPCHK(hipMemcpy2DAsync(out, sizeof(dqmc_update_state), &c->us->pub, c->lc.cs, sizeof(dqmc_update_state), (size_t)c->nb, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     for (int b = 0; b < c->nb; ++b)
-        if (out[b].error) return fail(out[b].error, "device ran out of pre-drawn uniforms");
+        if (out[b].error) return fail(out[b].error, out[b].error == DQMC_ENOCONV ? "decomposition failed: Cholesky-QR panel lost definiteness (block Gram-Schmidt QR, n_g > 1024; DQMC_QR_BGS=0 selects Householder panels)"
+                                                                                   : "device ran out of pre-drawn uniforms");
     return DQMC_OK;
 }
 
@@ -1151,7 +1157,7 @@ extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
     }
 #endif
     HIPCHK(copy_sync(c, out, &selp(c, c->us)->pub, sizeof(*out), hipMemcpyDeviceToHost));
-    if (out->error) return fail(out->error, "device ran out of pre-drawn uniforms");
+    if (out->error) return fail(out->error, out->error == DQMC_ENOCONV ? "decomposition failed: Cholesky-QR panel lost definiteness (block Gram-Schmidt QR)" : "device ran out of pre-drawn uniforms");
     return DQMC_OK;
 }
 extern "C" int dqmc_set_update_state_host(dqmc_ctx* c, const dqmc_update_state* in) {

@@ -123,6 +123,9 @@ struct GemmArgs {
     int sharedA, sharedB;       // operand is one matrix for all chains (not shifted by the chain stride)
     const int* a_kgather;       // opA == 0 only: column k of op(A) is column a_kgather[k] of A
     int b_lower;                // op(B) is lower triangular (entries with k < j are zero): the k loop of a column tile starts at its first column
+    // split-K (skinny products with a long contraction index, e.g. Q_prev^H A_j of the block Gram-Schmidt QR: few output tiles, K = n):
+    // ksplit > 1 slices of K are computed by separate workgroups into part[slice][N][M] and summed in a fixed order by a second kernel
+    int ksplit; cplx* part;
     int tag;                    // 1: a product inside a factorisation (LU trailing update, triangular solve) -- same code, its own kernel
                                 // name (template argument), so that profiles keep it apart from the model's n_g^3 products
 };
@@ -180,7 +183,7 @@ size_t measure_accum_doubles(int N, int L);
 
 // ---- QR / UDT building blocks (kernels_qr.hip) ------------------------------------------------
 struct SvdProfHooks;
-struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; const SvdProfHooks* apply_hooks; };   // hooks: optional timing of the k_qr_apply launches
+struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; const SvdProfHooks* apply_hooks; cplx* part; size_t part_count; int* err; };   // part: split-K scratch (n > 1024); err: per-chain error word (DevUpdateState::pub.error)   // hooks: optional timing of the k_qr_apply launches
 int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit (Q == nullptr: reflectors only)
 int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans);
 // large n: QR by block Gram-Schmidt with reorthogonalisation + Cholesky-QR2 panels, all on the GEMM kernel (kernels_qr.hip); Q is always explicit

@@ -20,6 +20,7 @@
 // Workgroup = 4 waves in a 2x2 arrangement, each wave TMxTN MFMA tiles: 32x32 block tiles when
 // n_g = 512 (256 workgroups = one per CU), 64x64 for the large O(3) lattices.
 #include "dqmc_internal.h"
+#include <algorithm>
 #include <cstdlib>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -45,6 +46,14 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
     int K = g.K;
     if (g.Kdev) { int kd = (*g.Kdev) * g.Kmul; K = kd < K ? kd : K; }
     if (K <= 0 && g.accumulate) return;
+    // split-K: this workgroup contracts k in [kslice0, K) only (K shortened to the end of its slice); raw sums go to g.part
+    int kslice0 = 0;
+    if (g.ksplit > 1) {
+        const int kc = ((K + g.ksplit - 1) / g.ksplit + 15) & ~15;
+        kslice0 = blockIdx.y * kc;
+        K = min(K, kslice0 + kc);
+        g.part = chain_ptr_i(g.part, cs, chain);
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
         }
     };
 
-    const int kbeg = g.b_lower ? (j0 / BK) * BK : 0;      // triangular op(B): rows above the tile's first column are zero
+    const int kbeg = g.ksplit > 1 ? kslice0 : (g.b_lower ? (j0 / BK) * BK : 0);      // triangular op(B): rows above the tile's first column are zero
     if (K > kbeg) { gidx(kbeg); gload(kbeg); sstore(0); }
     __syncthreads();
     for (int k0 = kbeg, buf = 0; k0 < K; k0 += BK, buf ^= 1) {
@@ -211,6 +220,10 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
                 const int gj = j0 + wn * 16 * TN + b * 16 + l4 + 4 * r;
                 double re = acc_re[a][b][r], im = acc_im[a][b][r];
                 if (M3) { const double p1 = re, p2 = acc_p2[a][b][r]; re = p1 - p2; im = (im - p1) - p2; }
+                if (g.ksplit > 1) {
+                    if (gi < g.M && gj < g.N) g.part[((size_t)blockIdx.y * g.N + gj) * g.M + gi] = make_double2(re, im);
+                    continue;
+                }
                 if (g.rowscale) { double sc = g.rowscale[gic] * g.colscale[min(gj, Nm1)]; re *= sc; im *= sc; }
                 else if (g.colscale) { double sc = g.colscale[min(gj, Nm1)]; re *= sc; im *= sc; }
                 if (g.negate) { re = -re; im = -im; }
@@ -406,6 +419,21 @@ void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx
 #undef FLUSH_LAUNCH
 }
 
+// C (+)= (-) sum over the slices of part[slice][N][M], slices added in their fixed order (deterministic)
+__global__ void k_gemm_reduce(const cplx* __restrict__ part, int ksplit, int M, int N, cplx* __restrict__ C, int ldc, int accumulate, int negate, size_t cs) {
+    CHAIN(part); CHAIN(C);
+    const size_t total = (size_t)M * N;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % M), j = (int)(idx / M);
+        double re = 0.0, im = 0.0;
+        for (int sl = 0; sl < ksplit; ++sl) { const cplx v = part[(size_t)sl * total + idx]; re += v.x; im += v.y; }
+        if (negate) { re = -re; im = -im; }
+        cplx* c = C + (size_t)j * ldc + i;
+        if (accumulate) { re += c->x; im += c->y; }
+        *c = make_double2(re, im);
+    }
+}
+
 template<int TM, int TN, bool M3, int TAG>
 static void launch_gemm_ops(const Launch& lc, const GemmArgs& a, dim3 grid) {
     if (!a.opA) {
@@ -427,7 +455,23 @@ static void launch_gemm_tagged(const Launch& lc, const GemmArgs& a) {
         else                      launch_gemm_ops<2, 2, true, TAG>(lc, a, grid);
     } else {
         const int t = ((a.M + 31) / 32) * ((a.N + 31) / 32);
-        const dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
+        dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
+        // split-K: few tiles, long contraction, a scratch buffer offered and no epilogue scaling -> slices of >= 256 k until ~ 256
+        // workgroups are in flight
+        int ks = 1;
+        if (a.part && a.K >= 1024 && !a.Kdev && !a.kscale && !a.rowscale && !a.colscale && !a.b_lower && (long)t * lc.nb < 128) {
+            ks = (int)std::min<long>(std::min<long>(8, a.K / 256), (256 + (long)t * lc.nb - 1) / ((long)t * lc.nb));
+            if (ks < 2) ks = 1;
+        }
+        if (ks > 1) {
+            GemmArgs g2 = a;
+            g2.ksplit = ks; g2.accumulate = 0; g2.negate = 0;
+            grid.y = ks;
+            launch_gemm_ops<1, 1, true, TAG>(lc, g2, grid);
+            hipLaunchKernelGGL(k_gemm_reduce, dim3(std::min(256, (a.M * a.N + 255) / 256), 1, lc.nb), dim3(256), 0, lc.st, a.part, ks, a.M, a.N,
+                               a.C, a.ldc, a.accumulate, a.negate, lc.cs);
+            return;
+        }
         if (use_4m() && TAG == 0) launch_gemm_ops<1, 1, false, 0>(lc, a, grid);
         else                      launch_gemm_ops<1, 1, true, TAG>(lc, a, grid);
     }

@@ -850,41 +850,48 @@ int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const 
 #define BGS_NB 64
 // Cholesky factor of the nb x nb Hermitian block at (j0, j0) of Gm (upper triangle read), R upper with R^H R = G written back in
 // place (strict lower part zeroed).  If R1m != nullptr its block at (j0, j0) is replaced by R R1 (second CholQR pass: R_jj = R2 R1).
-// ONE wavefront per chain, the block in LDS, lane = column: LDS operations of one wave complete in order, so no barrier is needed.
-__global__ __launch_bounds__(64) void k_chol64(cplx* __restrict__ Gm, int ld, int j0, int nb, cplx* __restrict__ R1m, size_t cs) {
+// One workgroup of four waves per chain, the block in LDS: thread (j, q) owns the rows i = q (mod 4) of column j; a step reads the
+// UNSCALED pivot row (broadcast reads, scaled on the fly), updates the trailing columns and scales row K in place afterwards --
+// nobody reads row K again -- so a step costs ONE barrier.  (Versions with one wave per block: 195 us with the block in LDS and
+// dependent read-modify-write chains, 174 us with the columns in 512 registers; this one: see profiles/.)
+__global__ __launch_bounds__(256) void k_chol64(cplx* __restrict__ Gm, int ld, int j0, int nb, cplx* __restrict__ R1m, int* __restrict__ err, size_t cs) {
     __shared__ cplx s[BGS_NB][BGS_NB + 1];
     __shared__ cplx s1[BGS_NB][BGS_NB + 1];
-    CHAIN(Gm); CHAIN(R1m);
-    const int j = threadIdx.x;
-    for (int i = 0; i < nb; ++i) {
-        s[i][j] = (j < nb && i <= j) ? Gm[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
-        if (R1m) s1[i][j] = (j < nb && i <= j) ? R1m[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
+    CHAIN(Gm); CHAIN(R1m); CHAIN(err);
+    const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int i = q; i < BGS_NB; i += 4) {
+        const bool in = j < nb && i <= j;
+        s[i][j] = in ? Gm[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
+        if (R1m) s1[i][j] = in ? R1m[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
     }
-    for (int k = 0; k < nb; ++k) {
-        const double d = sqrt(fmax(s[k][k].x, 1e-300));
-        if (j >= k && j < nb) {
-            const cplx g = s[k][j];
-            const cplx r = (j == k) ? make_double2(d, 0.0) : make_double2(g.x / d, g.y / d);
-            s[k][j] = r;
-        }
-        if (j > k && j < nb) {
-            const cplx rkj = s[k][j];
-            for (int i = k + 1; i <= j; ++i) {
-                const cplx rki = s[k][i];                     // conj(r_ki) r_kj
+    __syncthreads();
+    for (int K = 0; K < nb; ++K) {
+        // a pivot that is not positive: the Gram matrix has lost definiteness -- the panel is too ill conditioned for Cholesky-QR.
+        // Reported like a failed decomposition (reference: "SVD failed", udv.h:77-88), never papered over.
+        if (!(s[K][K].x > 0.0) && threadIdx.x == 0 && err) *err = DQMC_ENOCONV;
+        const double d = sqrt(fmax(s[K][K].x, 1e-300)), id = 1.0 / d;
+        if (j > K && j < nb) {
+            const cplx rkj = make_double2(s[K][j].x * id, s[K][j].y * id);
+            int i = K + 1 + ((q - (K + 1)) & 3);                         // first row > K that belongs to this thread
+            for (; i <= j; i += 4) {
+                const cplx rki = make_double2(s[K][i].x * id, s[K][i].y * id);
                 cplx g = s[i][j];
-                g.x -= rki.x * rkj.x + rki.y * rkj.y;
+                g.x -= rki.x * rkj.x + rki.y * rkj.y;                   // conj(r_Ki) r_Kj
                 g.y -= rki.x * rkj.y - rki.y * rkj.x;
                 s[i][j] = g;
             }
         }
+        __syncthreads();                                                 // the pivot row has been read by everybody, row K + 1 is final
+        if (q == 0 && j >= K && j < nb) s[K][j] = (j == K) ? make_double2(d, 0.0) : make_double2(s[K][j].x * id, s[K][j].y * id);
     }
+    __syncthreads();
     if (j < nb) {
-        for (int i = 0; i < nb; ++i) Gm[(size_t)(j0 + j) * ld + (j0 + i)] = (i <= j) ? s[i][j] : make_double2(0.0, 0.0);
+        for (int i = q; i < nb; i += 4) Gm[(size_t)(j0 + j) * ld + (j0 + i)] = (i <= j) ? s[i][j] : make_double2(0.0, 0.0);
         if (R1m) {
-            for (int i = 0; i <= j; ++i) {                   // (R2 R1)[i][j] = sum_{q = i .. j} R2[i][q] R1[q][j]
+            for (int i = q; i <= j; i += 4) {                        // (R2 R1)[i][j] = sum_{t = i .. j} R2[i][t] R1[t][j]
                 cplx acc = make_double2(0.0, 0.0);
-                for (int q = i; q <= j; ++q) {
-                    const cplx a = s[i][q], b = s1[q][j];
+                for (int t = i; t <= j; ++t) {
+                    const cplx a = s[i][t], b = s1[t][j];
                     acc.x += a.x * b.x - a.y * b.y;
                     acc.y += a.x * b.y + a.y * b.x;
                 }
@@ -926,6 +933,7 @@ int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
         GemmArgs g = GemmArgs();
         g.A = Am; g.lda = n; g.opA = opA; g.B = Bm; g.ldb = n; g.opB = opB; g.C = Cm; g.ldc = n;
         g.M = M; g.N = N; g.K = K; g.Kmul = 1; g.accumulate = sub; g.negate = sub; g.tag = 1;
+        if (w.part && (size_t)M * N * 8 <= w.part_count) g.part = w.part;      // split-K scratch: the skinny Q^H A / Gram products
         launch_gemm(lc, g);
         ++launches;
     };
@@ -942,10 +950,10 @@ int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
             ++launches;
         }
         gemm(1, Qj, 0, Qj, Rj + j0, b, b, n, 0);                     // G = A_j^H A_j into R's diagonal block
-        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(64), 0, lc.st, A, n, j0, b, (cplx*)nullptr, lc.cs);
+        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, j0, b, (cplx*)nullptr, w.err, lc.cs);
         launches += 1 + trsm_rec(lc, n, A, Q, j0, b, 0, 0);          // A_j <- A_j R1^-1
         gemm(1, Qj, 0, Qj, S + (size_t)j0 * n + j0, b, b, n, 0);     // second pass: G' = A_j^H A_j (close to the identity)
-        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(64), 0, lc.st, S, n, j0, b, A, lc.cs);   // R2; R_jj = R2 R1
+        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(256), 0, lc.st, S, n, j0, b, A, w.err, lc.cs);   // R2; R_jj = R2 R1
         launches += 1 + trsm_rec(lc, n, S, Q, j0, b, 0, 0);          // Q_j = A_j R2^-1
     }
     return launches;
