@@ -484,7 +484,7 @@ def rooflines(rawprof, n, m, B, traffic):
 def load_traffic(B, D):
     """HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, WRITE_SIZE),
     taken with scripts/pmc_collect.sh + scripts/pmc_traffic_summary.py for this batch size and delay depth"""
-    for rnd in ("r02",):
+    for rnd in ("r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_b%d_d%d.json" % (rnd, B, D))
         if os.path.exists(path):
             try:

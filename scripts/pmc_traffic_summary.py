@@ -1,7 +1,7 @@
 """Per-kernel-family HBM traffic and SQ counters from the rocprofv3 --pmc passes of scripts/pmc_collect.sh ->
-profiles/r02_pmc_traffic_b<B>_d<D>.json (bench.py reads `families[*].hbm_bytes_per_launch` into roofline.traffic).
+profiles/r03_pmc_traffic_b<B>_d<D>.json (bench.py reads `families[*].hbm_bytes_per_launch` into roofline.traffic).
 
-    python scripts/pmc_traffic_summary.py gpurun_out/pmc_r02 128 32 profiles/r02_pmc_traffic_b128_d32.json
+    python scripts/pmc_traffic_summary.py gpurun_out/pmc_r03 128 32 profiles/r03_pmc_traffic_b128_d32.json
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced reads, so it is doubled
 (MI355X_MICROARCH.md, section HBM).  Averages are over ALL dispatches of a kernel, including the launches of the update
@@ -20,8 +20,10 @@ FAMILY = [("k_flush", "flush"), ("k_qr_apply_reg", "qr_apply"), ("k_qr_apply", "
 
 
 def family(name):
-    if "k_zgemm<" in name and name.split("(")[0].rstrip().endswith(", 1>"):
-        return "gemm_in_factorisation"          # TAG = 1: LU trailing updates and triangular solves (kernels_gemm.hip)
+    import re
+    m = re.search(r"k_zgemm<(\d+), (\d+), (?:true|false), (\d+)", name)        # <TM, TN, M3, TAG, OPA, OPB>
+    if m and m.group(3) == "1":
+        return "gemm_in_factorisation"          # TAG = 1: LU trailing updates, triangular solves, block Gram-Schmidt products (kernels_gemm.hip)
     for key, fam in FAMILY:
         if key in name:
             return fam

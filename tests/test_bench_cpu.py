@@ -89,3 +89,15 @@ def test_bench_exits_nonzero_when_a_worker_dies():
     assert out.returncode != 0
     assert "exit code 7" in out.stderr, out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_config_selects_the_other_baseline_workloads():
+    """`--config` runs the other BASELINE.json workloads with the same JSON shape (config 5 without the flux the reference rejects
+    for opdim = 3, /root/reference/src/detsdwparams.cpp:57-60); the default stays the configuration the metric is quoted on."""
+    for cfg, label, chains in (("o3_L24_b20", "SDW-O3 L=24 beta=20", 8), ("o2_L16_b20", "SDW-O2 L=16 beta=20", 256), (None, "SDW-O2 L=16 beta=10", 512)):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + (["--config", cfg] if cfg else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=_env())
+        assert out.returncode == 0, out.stderr
+        r = _line(out)
+        assert label in r["metric"] and r["config"]["replicas_per_gpu"] == chains and "workload" in r["config"]
+        assert r["dtype"] == "f64" and r["vs_baseline"] is None
