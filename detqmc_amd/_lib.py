@@ -30,7 +30,7 @@ class dqmc_params(C.Structure):
                 ("dtau", C.c_double), ("r", C.c_double), ("c", C.c_double), ("u", C.c_double),
                 ("lambda_", C.c_double),
                 ("txhor", C.c_double), ("txver", C.c_double), ("tyhor", C.c_double), ("tyver", C.c_double),
-                ("mux", C.c_double), ("muy", C.c_double), ("accRatio", C.c_double)]
+                ("mux", C.c_double), ("muy", C.c_double), ("accRatio", C.c_double), ("cdwU", C.c_double)]
 
 
 class dqmc_update_state(C.Structure):
@@ -128,6 +128,8 @@ SYMBOLS = [
     ("dqmc_stream", _P, [_P]),
     ("dqmc_set_fields_host", C.c_int, [_P, _DP]),
     ("dqmc_get_fields_host", C.c_int, [_P, _DP, _DP, _DP]),
+    ("dqmc_set_cdwl_host", C.c_int, [_P, _P]),
+    ("dqmc_get_cdwl_host", C.c_int, [_P, _P]),
     ("dqmc_set_fields_all_host", C.c_int, [_P, _DP]),
     ("dqmc_get_fields_all_host", C.c_int, [_P, _DP]),
     ("dqmc_bmult_host", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -178,6 +180,8 @@ SYMBOLS = [
     ("detsdw_get_observable_vector", C.c_int, [_P, C.c_int, _DP]),
     ("detsdw_get_phi", C.c_int, [_P, _DP]),
     ("detsdw_set_phi", C.c_int, [_P, _DP]),
+    ("detsdw_get_cdwl", C.c_int, [_P, _P]),
+    ("detsdw_set_cdwl", C.c_int, [_P, _P]),
     ("detsdw_get_green", C.c_int, [_P, _P]),
     ("detsdw_get_green_inv_sv", C.c_int, [_P, _DP]),
     ("detsdw_save_configuration_stream_binary", C.c_int, [_P, C.c_char_p]),

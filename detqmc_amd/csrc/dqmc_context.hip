@@ -50,6 +50,7 @@ struct dqmc_ctx {
     std::vector<void*> allocs;
     // fields + backups
     double *phi = nullptr, *coshT = nullptr, *sinhT = nullptr;
+    double *cdwl = nullptr, *cdwC = nullptr, *cdwS = nullptr;      // cdwU != 0 only
     double *phi_bak = nullptr, *cosh_bak = nullptr, *sinh_bak = nullptr;
     // Green's function, singular values of G^-1
     cplx *G = nullptr, *G_bak = nullptr;
@@ -480,6 +481,7 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
         if (p->opdim != 1 || p->weakZflux || p->bc != DQMC_BC_PBC || p->delaySteps != 1)
             return fail(DQMC_EINVAL, "Hubbard replica: opdim must be 1, delaySteps 1, bc pbc, no flux");   // dethubbardparams.cpp:41-43
         if (!(p->u >= 0)) return fail(DQMC_EINVAL, "Hubbard replica: U must be >= 0 (alpha = acosh(e^{dtau U / 2}))");
+        if (p->cdwU != 0.0) return fail(DQMC_EINVAL, "Hubbard replica: cdwU must be 0");
     }
     const int ng = MSF * N;
     if (p->stabilisation == DQMC_STAB_SVD && ng > 2304) return fail(DQMC_EINVAL, "n_g > 2304 not supported by the Jacobi kernel instantiations");
@@ -577,6 +579,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     const size_t nphi = (size_t)(p->m + 1) * p->opdim * N, ncs = (size_t)(p->m + 1) * N;
     A_(dalloc(c, &c->phi, nphi)); A_(dalloc(c, &c->coshT, ncs)); A_(dalloc(c, &c->sinhT, ncs));
     A_(dalloc(c, &c->phi_bak, nphi)); A_(dalloc(c, &c->cosh_bak, ncs)); A_(dalloc(c, &c->sinh_bak, ncs));
+    if (p->cdwU != 0.0) { A_(dalloc(c, &c->cdwl, ncs)); A_(dalloc(c, &c->cdwC, ncs)); A_(dalloc(c, &c->cdwS, ncs)); }
 
     const size_t n2 = (size_t)ng * ng;
     A_(dalloc(c, &c->G, n2)); A_(dalloc(c, &c->G_bak, n2));
@@ -622,7 +625,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     const int WD = MSF * c->D;
     const int WD8 = (WD + 7) & ~7;          // X and GrT are zero padded to a multiple of 8 columns for the flush kernel
     A_(dalloc(c, &c->X, (size_t)ng * WD8)); A_(dalloc(c, &c->Gr, (size_t)WD8 * ng)); A_(dalloc(c, &c->W, (size_t)WD * WD));
-    c->uni_cap = (size_t)(p->opdim + 1) * N * p->m + 64;     // one sweep's worst case
+    c->uni_cap = (size_t)(p->opdim + 1 + (p->cdwU != 0.0 ? 2 : 0)) * N * p->m + 64;     // one sweep's worst case (+ the cdwl pass)
     A_(dalloc(c, &c->uniforms, c->uni_cap));
     A_(dalloc(c, &c->us, 1));
     A_(dalloc(c, &c->scalar_out, 8));
@@ -633,6 +636,16 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
 #undef A_
     c->qw.err = &c->us->pub.error;
     hm.phi = c->phi; hm.coshT = c->coshT; hm.sinhT = c->sinhT;
+    if (p->cdwU != 0.0) {
+        // cdwl_eta / cdwl_gamma (detsdwopdim.h:1209-1235), getCoshSinhTermCDWl (detsdwopdim.cpp:1138-1143)
+        hm.cdw_on = 1; hm.cdwl = c->cdwl; hm.cdwC = c->cdwC; hm.cdwS = c->cdwS;
+        const double eta[2] = {std::sqrt(2. * (3. - std::sqrt(6.))), std::sqrt(2. * (3. + std::sqrt(6.)))};
+        for (int a = 0; a < 2; ++a) {
+            const double arg = std::sqrt(p->dtau) * p->cdwU * eta[a];
+            hm.cdw_cosh[a] = std::cosh(arg); hm.cdw_sinh[a] = std::sinh(arg);
+        }
+        hm.cdw_gamma[0] = 3. + std::sqrt(6.); hm.cdw_gamma[1] = 3. - std::sqrt(6.);
+    }
     DevUpdateState hus;
     memset(&hus, 0, sizeof(hus));
     hus.pub.phiDelta = 0.5;                 // AdjustmentData::InitialPhiDelta (detsdwopdim.h:489)
@@ -641,6 +654,11 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     hus.r = p->r;
     for (int b = 0; b < c->nb; ++b) HIPCHK(copy_sync(c, chainp(c, c->us, b), &hus, sizeof(hus), hipMemcpyHostToDevice));
     { int rc2 = set_slot_identity(c, c->eye); if (rc2) return rc2; }
+    if (c->hm.cdw_on) {                      // l = +1 everywhere (setupConstantField, detsdwopdim.cpp:1116-1128) until the host sets the field
+        std::vector<double> ones((size_t)(c->m + 1) * N, 1.0);
+        for (int b = 0; b < c->nb; ++b) HIPCHK(copy_sync(c, chainp(c, c->cdwl, b), ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+        launch_cdw_terms(c->lc, c->hm);
+    }
     HIPCHK(hipStreamSynchronize(c->st));
     return DQMC_OK;
 }
@@ -692,6 +710,36 @@ extern "C" int dqmc_get_fields_host(dqmc_ctx* c, double* phi, double* coshT, dou
     if (phi) HIPCHK(copy_sync(c, phi, selp(c, c->phi), nphi * sizeof(double), hipMemcpyDeviceToHost));
     if (coshT) HIPCHK(copy_sync(c, coshT, selp(c, c->coshT), ncs * sizeof(double), hipMemcpyDeviceToHost));
     if (sinhT) HIPCHK(copy_sync(c, sinhT, selp(c, c->sinhT), ncs * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+
+// the discrete field of the selected chain, l_i(tau_k) in {+-1, +-2}: cdwl[k * N + site], slice 0 unused (cdwU != 0 only)
+extern "C" int dqmc_set_cdwl_host(dqmc_ctx* c, const int32_t* cdwl) {
+    if (!c || !cdwl) return fail(DQMC_EINVAL, "null argument");
+    if (!c->hm.cdw_on) return fail(DQMC_EINVAL, "dqmc_set_cdwl_host: the context was created with cdwU == 0");
+    (void)hipSetDevice(c->p.device);
+    const size_t ncs = (size_t)(c->m + 1) * c->N;
+    std::vector<double> v(ncs);
+    for (size_t i = 0; i < ncs; ++i) {
+        const int32_t l = cdwl[i];
+        if (i >= (size_t)c->N && l != 1 && l != -1 && l != 2 && l != -2) return fail(DQMC_EINVAL, "cdwl values must be +-1 or +-2");
+        v[i] = (double)l;
+    }
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(copy_sync(c, selp(c, c->cdwl), v.data(), ncs * sizeof(double), hipMemcpyHostToDevice));
+    { ProfScope ps(c, FAM_OTHER, 1); launch_cdw_terms(c->lc, c->hm); }
+    HIPCHK(hipStreamSynchronize(c->st));
+    return DQMC_OK;
+}
+extern "C" int dqmc_get_cdwl_host(dqmc_ctx* c, int32_t* cdwl) {
+    if (!c || !cdwl) return fail(DQMC_EINVAL, "null argument");
+    if (!c->hm.cdw_on) return fail(DQMC_EINVAL, "dqmc_get_cdwl_host: the context was created with cdwU == 0");
+    (void)hipSetDevice(c->p.device);
+    const size_t ncs = (size_t)(c->m + 1) * c->N;
+    std::vector<double> v(ncs);
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(copy_sync(c, v.data(), selp(c, c->cdwl), ncs * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ncs; ++i) cdwl[i] = (int32_t)v[i];
     return DQMC_OK;
 }
 
@@ -1081,7 +1129,7 @@ extern "C" int dqmc_push_uniforms_host(dqmc_ctx* c, const double* u, size_t nval
     if (!c || (!u && nvals)) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     if (nvals > c->uni_cap)
-        return fail(DQMC_EINVAL, "more uniforms than one sweep can consume ((opdim+1)*N*m + 64)");
+        return fail(DQMC_EINVAL, "more uniforms than one sweep can consume ((opdim+1 [+2 with cdwU])*N*m + 64)");
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(copy_sync(c, selp(c, c->uniforms), u, nvals * sizeof(double), hipMemcpyHostToDevice));
     uint64_t vals[2] = {0, (uint64_t)nvals};
@@ -1095,7 +1143,7 @@ extern "C" int dqmc_push_uniforms_all_host(dqmc_ctx* c, const double* u, size_t 
     if (!c || (!u && nvals)) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     if (nvals > c->uni_cap)
-        return fail(DQMC_EINVAL, "more uniforms than one sweep can consume ((opdim+1)*N*m + 64)");
+        return fail(DQMC_EINVAL, "more uniforms than one sweep can consume ((opdim+1 [+2 with cdwU])*N*m + 64)");
     HIPCHK(hipMemcpy2DAsync(c->uniforms, c->lc.cs, u, nvals * sizeof(double), nvals * sizeof(double), (size_t)c->nb, hipMemcpyHostToDevice, c->st));
     std::vector<uint64_t> vals((size_t)2 * c->nb);
     for (int b = 0; b < c->nb; ++b) { vals[2 * b] = 0; vals[2 * b + 1] = (uint64_t)nvals; }
@@ -1132,6 +1180,20 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
         {
             ProfScope ps(c, FAM_UPDATE, 1);
             launch_update_decide(c->lc, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, thermalization);
+        }
+        {
+            ProfScope ps(c, FAM_GATHER, 1);
+            launch_update_gather(c->lc, c->hm, c->us, c->G, c->W, c->X, c->Gr);
+        }
+        ProfScope ps(c, FAM_FLUSH, 1);
+        launch_flush(c->lc, c->X, c->Gr, c->n_g, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
+    }
+    // cdwU != 0: the second pass over the slice updates the discrete field (detsdwopdim.cpp:2474-2485); its acceptance ratio is
+    // discarded there and here (no step-width adaptation)
+    for (int r = 0; c->hm.cdw_on && r < rounds; ++r) {
+        {
+            ProfScope ps(c, FAM_UPDATE, 1);
+            launch_update_decide(c->lc, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, 0, /*cdw_pass=*/1);
         }
         {
             ProfScope ps(c, FAM_GATHER, 1);

@@ -77,6 +77,14 @@ struct DevModel {
     double* phi;       // [m+1][opdim][N]
     double* coshT;     // [m+1][N]
     double* sinhT;     // [m+1][N]
+    // cdwU != 0 (cdw_on): the discrete four-valued field l_i(tau_k) in {+-1, +-2} (kept as doubles: it travels with the other per-site
+    // scalars of a proposal) and its caches cosh / sinh(sqrt(dtau) cdwU eta(l)) (coshTermCDWl / sinhTermCDWl, detsdwopdim.cpp:1138-1163)
+    int cdw_on;
+    double* cdwl;      // [m+1][N]
+    double* cdwC;      // [m+1][N]
+    double* cdwS;      // [m+1][N]
+    double cdw_cosh[2], cdw_sinh[2];   // |l| = 1, 2 (sinh for l > 0)
+    double cdw_gamma[2];               // cdwl_gamma(|l|) (detsdwopdim.h:1209-1220)
     const int* neigh;  // [4][N]  XPLUS, XMINUS, YPLUS, YMINUS (neighbortable.h:34-36)
     // Hubbard replica (dqmc_params::model == DQMC_MODEL_HUBBARD): phi holds the Ising auxiliary field (+-1.0, opdim = 1),
     // the hopping part is the dense propagator (dense = 1), the site-diagonal part is e^{+-alpha s} (kernels_hubbard.hip)
@@ -85,6 +93,7 @@ struct DevModel {
 };
 __device__ __forceinline__ DevModel chain_model(DevModel dm, size_t cs) {
     dm.phi = chain_ptr(dm.phi, cs); dm.coshT = chain_ptr(dm.coshT, cs); dm.sinhT = chain_ptr(dm.sinhT, cs);
+    if (dm.cdw_on) { dm.cdwl = chain_ptr(dm.cdwl, cs); dm.cdwC = chain_ptr(dm.cdwC, cs); dm.cdwS = chain_ptr(dm.cdwS, cs); }
     return dm;
 }
 
@@ -154,8 +163,18 @@ int run_svd(const Launch& lc, int n, const cplx* M, int ldm, const double* colsc
 int svd_block_cols(int n);      // columns per block used by the Jacobi kernel for this n
 
 // local updates
+// diagonal entries and off-diagonal scale of e^{sign dtau V} at one site: (0,0) = (2,2) = c0, (1,1) = (3,3) = c1, off-diagonal entries
+// carry xs (evMatrix, detsdwopdim.cpp:3187-3229; cd / cmd of :2003-2006).  idx = k N + site.
+__device__ __forceinline__ void cdw_site_terms(const DevModel& dm, size_t idx, double sign, double c, double& c0, double& c1, double& xs) {
+    if (dm.cdw_on) {
+        const double cC = dm.cdwC[idx], sC = dm.cdwS[idx];
+        c0 = c * cC - sign * sC; c1 = c * cC + sign * sC; xs *= cC;
+    } else { c0 = c; c1 = c; }
+}
+void launch_cdw_terms(const Launch& lc, const DevModel& hm);      // cdwC / cdwS from cdwl, all slices
+// cdw_mode 0: phi proposals (with the cdw terms in e^{dtau V} when cdw_on); 1: the cdwl pass (proposeNewCDWl, :4173-4182)
 void launch_update_decide(const Launch& lc, const DevModel* dm, const DevModel& hm, DevUpdateState* us,
-                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal);
+                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal, int cdw_pass = 0);
 void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,
                           const cplx* W, cplx* X, cplx* GrT);
 

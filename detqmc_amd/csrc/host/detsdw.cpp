@@ -94,7 +94,6 @@ void DetSDW::normalise(detsdw_params& p, int& bcv) {
         throw ParameterWrong("Either use combined wolffClusterShiftUpdate or individual global updates");   // :94-96
     if (p.repeatWolffPerSweep < 1) throw ParameterWrong("Parameter repeatWolffPerSweep has incorrect value");
     if (p.L % 2 != 0) throw ParameterWrong("Checker board decomposition only supported for even linear lattice sizes");
-    if (p.cdwU != 0.0) throw ParameterWrong("cdwU != 0 is not supported by this build");
     if (p.stabilisation != 0 && p.stabilisation != 1) throw ParameterWrong("Parameter stabilisation has incorrect value");
     // createReplica (detsdwopdim.cpp:75-79)
     if (!p.has_mux_muy) { p.mux = p.mu; p.muy = p.mu; }
@@ -134,7 +133,7 @@ DetSDW::DetSDW(const detsdw_params* in, int nchains, int sub_batches) {
     kp.bc = bcv; kp.weakZflux = p.weakZflux; kp.phi2bosons = p.phi2bosons; kp.device = p.device;
     kp.dtau = p.dtau; kp.r = p.r; kp.c = p.c; kp.u = p.u; kp.lambda = p.lambda;
     kp.txhor = p.txhor; kp.txver = p.txver; kp.tyhor = p.tyhor; kp.tyver = p.tyver;
-    kp.mux = p.mux; kp.muy = p.muy; kp.accRatio = p.accRatio;
+    kp.mux = p.mux; kp.muy = p.muy; kp.accRatio = p.accRatio; kp.cdwU = p.cdwU;
     kp.stabilisation = p.stabilisation;
     kp.cb_none = p.cb_none ? 1 : 0;          // reference option checkerboard=false (DetSDW<CB_NONE, OPDIM>)
     groups_.resize(S);
@@ -147,10 +146,12 @@ DetSDW::DetSDW(const detsdw_params* in, int nchains, int sub_batches) {
         for (int b = 0; b < nchains; ++b) {
             Chain& c = ch_[b];
             c.phi.assign((size_t)N_ * opdim_ * (m_ + 1), 0.0);
+            c.cdwl.assign((size_t)N_ * (m_ + 1), 0);
             setupRandomField(c);
             dqmc_ctx* ctx = select(b);
             check(dqmc_set_exchange_parameter(ctx, c.pars.r), "dqmc_set_exchange_parameter");
             check(dqmc_set_fields_host(ctx, c.phi.data()), "dqmc_set_fields_host");
+            if (c.pars.cdwU != 0.0) check(dqmc_set_cdwl_host(ctx, c.cdwl.data()), "dqmc_set_cdwl_host");
         }
         forEachGroup([this](Group& g) { setupUdVStorage_and_calculateGreen(g); });
     } catch (...) {
@@ -162,12 +163,13 @@ DetSDW::DetSDW(const detsdw_params* in, int nchains, int sub_batches) {
 
 DetSDW::~DetSDW() { for (auto& g : groups_) dqmc_destroy(g.ctx); }
 
-// detsdwopdim.cpp:1099-1113: k outer, site, dim; one more draw per site for the (unused) cdwl field
+// detsdwopdim.cpp:1099-1113: k outer, site, dim; one more draw per site for the discrete field (drawn whatever cdwU is)
 void DetSDW::setupRandomField(Chain& c) {
     for (int k = 1; k <= m_; ++k)
         for (int site = 0; site < N_; ++site) {
             for (int dim = 0; dim < opdim_; ++dim) c.phi[phiIdx(site, dim, k)] = c.rng.randRange(-1.0, 1.0);
-            (void)c.rng.rand01();
+            const double r = c.rng.rand01();
+            c.cdwl[(size_t)k * N_ + site] = (r <= 0.25) ? +2 : (r <= 0.5) ? -2 : (r <= 0.75) ? +1 : -1;
         }
 }
 
@@ -177,7 +179,8 @@ void DetSDW::setupUdVStorage_and_calculateGreen(Group& g) {
 
 // Ship the worst-case number of upcoming uniforms of this sweep; the device consumes a prefix.
 void DetSDW::beginLocalUpdates(Group& g) {
-    const size_t need = (size_t)(opdim_ + 1) * N_ * m_;
+    // per slice and site: opdim box draws + at most one acceptance draw; with cdwU one proposal + one acceptance draw more
+    const size_t need = (size_t)(opdim_ + 1 + (ch_[0].pars.cdwU != 0.0 ? 2 : 0)) * N_ * m_;
     g.window.resize(need * g.count);               // all chains' windows back to back: one host -> device transfer
     for (int b = 0; b < g.count; ++b) std::memcpy(&g.window[b * need], ch_[g.first + b].rng.peek(need), need * sizeof(double));
     check(dqmc_push_uniforms_all_host(g.ctx, g.window.data(), need), "dqmc_push_uniforms_all_host");
@@ -644,6 +647,19 @@ void DetSDW::getPhi(double* out, int b) {
     syncPhiFromDevice(b);
     std::memcpy(out, ch_[b].phi.data(), ch_[b].phi.size() * sizeof(double));
 }
+// cdwl(site, k) as the reference's MatInt (N x (m+1), column-major); all +-1 / +-2, slice 0 unused
+void DetSDW::getCdwl(int32_t* out, int b) {
+    if (ch_[b].pars.cdwU != 0.0) check(dqmc_get_cdwl_host(select(b), ch_[b].cdwl.data()), "dqmc_get_cdwl_host");
+    std::memcpy(out, ch_[b].cdwl.data(), ch_[b].cdwl.size() * sizeof(int32_t));
+}
+void DetSDW::setCdwl(const int32_t* in, int b) {
+    if (ch_[b].pars.cdwU == 0.0) throw ParameterWrong("setCdwl: the replica was created with cdwU == 0");
+    dqmc_ctx* ctx_ = select(b);
+    std::memcpy(ch_[b].cdwl.data(), in, ch_[b].cdwl.size() * sizeof(int32_t));
+    check(dqmc_set_cdwl_host(ctx_, ch_[b].cdwl.data()), "dqmc_set_cdwl_host");
+    setupUdVStorage_and_calculateGreen(grp(b));
+    lastSweepDir_ = Up;
+}
 // also rebuilds UdV storage and G -- of every chain of the batch (one batched setup)
 void DetSDW::setPhi(const double* in, int b) {
     dqmc_ctx* ctx_ = select(b);
@@ -668,6 +684,18 @@ void DetSDW::saveConfigurationStreamBinary(const std::string& directory, int b) 
         }
     ok &= std::fclose(f) == 0;
     if (!ok) throw GeneralError(DQMC_EINVAL, "write error on " + path);
+    if (ch_[b].pars.cdwU != 0.0) {           // configs-l.binarystream (:5015-5037): the discrete field as int32, same site order
+        check(dqmc_get_cdwl_host(select(b), ch_[b].cdwl.data()), "dqmc_get_cdwl_host");
+        const std::string lpath = directory + "/configs-l.binarystream";
+        std::FILE* fl = std::fopen(lpath.c_str(), "ab");
+        if (!fl) throw GeneralError(DQMC_EINVAL, "Could not open file " + lpath + " for writing");
+        bool okl = true;
+        for (int ix = 0; ix < L; ++ix)
+            for (int iy = 0; iy < L; ++iy)
+                for (int k = 1; k <= m_; ++k) okl &= std::fwrite(&ch_[b].cdwl[(size_t)k * N_ + iy * L + ix], sizeof(int32_t), 1, fl) == 1;
+        okl &= std::fclose(fl) == 0;
+        if (!okl) throw GeneralError(DQMC_EINVAL, "write error on " + lpath);
+    }
 }
 // ---- checkpoint / resume --------------------------------------------------------------------------------------
 namespace {
@@ -692,6 +720,10 @@ void DetSDW::saveState(const std::string& path) {
         wr(fc.f, &c.pars, sizeof(c.pars)); wr(fc.f, &cd, sizeof(cd));
         wr(fc.f, &nr, 8); wr(fc.f, rng.data(), nr * 8);
         wr(fc.f, &np, 8); wr(fc.f, c.phi.data(), np * 8);
+        if (c.pars.cdwU != 0.0) {            // the discrete field follows phi (records of a cdwU == 0 replica are unchanged)
+            check(dqmc_get_cdwl_host(select(b), c.cdwl.data()), "dqmc_get_cdwl_host");
+            wr(fc.f, c.cdwl.data(), c.cdwl.size() * sizeof(int32_t));
+        }
     }
 }
 
@@ -717,11 +749,13 @@ void DetSDW::loadState(const std::string& path) {
         rd(fc.f, &np, 8);
         if (np != c.phi.size()) throw GeneralError(DQMC_EINVAL, "checkpoint: field size mismatch");
         rd(fc.f, c.phi.data(), np * 8);
+        if (c.pars.cdwU != 0.0) rd(fc.f, c.cdwl.data(), c.cdwl.size() * sizeof(int32_t));
         c.rng.deserialize(rng);
         dqmc_ctx* ctx_ = select(b);
         c.pars.r = p.r;
         check(dqmc_set_exchange_parameter(ctx_, p.r), "dqmc_set_exchange_parameter");
         check(dqmc_set_fields_host(ctx_, c.phi.data()), "dqmc_set_fields_host");
+        if (c.pars.cdwU != 0.0) check(dqmc_set_cdwl_host(ctx_, c.cdwl.data()), "dqmc_set_cdwl_host");
         set_control_data(cd, b);
     }
     performedSweeps_ = hdr[2];
@@ -789,6 +823,8 @@ extern "C" int detsdw_get_observable_vector(detsdw_replica* r, int which, double
 }
 extern "C" int detsdw_get_phi(detsdw_replica* r, double* phi) { RGUARD(r->impl->getPhi(phi, r->sel)) }
 extern "C" int detsdw_set_phi(detsdw_replica* r, const double* phi) { RGUARD(r->impl->setPhi(phi, r->sel)) }
+extern "C" int detsdw_get_cdwl(detsdw_replica* r, int32_t* cdwl) { RGUARD(r->impl->getCdwl(cdwl, r->sel)) }
+extern "C" int detsdw_set_cdwl(detsdw_replica* r, const int32_t* cdwl) { RGUARD(r->impl->setCdwl(cdwl, r->sel)) }
 extern "C" int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g) { RGUARD(r->impl->getGreen(g, r->sel)) }
 extern "C" int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv) { RGUARD(r->impl->getGreenInvSv(sv, r->sel)) }
 extern "C" int detsdw_save_state(detsdw_replica* r, const char* path) {

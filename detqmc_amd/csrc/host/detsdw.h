@@ -57,6 +57,8 @@ public:
     void getObservableVector(int which, double* out, int b = 0) const;
     void getPhi(double* phi, int b = 0);
     void setPhi(const double* phi, int b = 0);
+    void getCdwl(int32_t* cdwl, int b = 0);
+    void setCdwl(const int32_t* cdwl, int b = 0);
     void getGreen(dqmc_cplx* g, int b = 0);
     void getGreenInvSv(double* sv, int b = 0);
     void saveConfigurationStreamBinary(const std::string& directory, int b = 0);
@@ -73,6 +75,7 @@ private:
         detsdw_params pars;
         RngStream rng;
         std::vector<double> phi;               // host mirror, valid after syncPhiFromDevice(b)
+        std::vector<int32_t> cdwl;             // discrete field l_i(tau_k), [k * N + site]; lives on the device when cdwU != 0 (getCdwl)
         int acceptedGlobalShifts = 0, attemptedGlobalShifts = 0;          // UpdateStatistics (detsdwopdim.h:285-311)
         int acceptedWolffClusterUpdates = 0, attemptedWolffClusterUpdates = 0;
         int acceptedWolffClusterShiftUpdates = 0, attemptedWolffClusterShiftUpdates = 0;

@@ -30,10 +30,10 @@ __device__ __forceinline__ cplx cfma(cplx a, cplx b, cplx c) {
 }
 __device__ __forceinline__ cplx cscale(cplx a, double s) { return make_double2(a.x * s, a.y * s); }
 
-// e^{sign dtau V} at one site, cdwU == 0: entries as in get_delta_forsite's evMatrix
-// (detsdwopdim.cpp:3188-3229) == the vectors cd/cmd/mbx/mbcx/ax/max of :2001-2030.
+// e^{sign dtau V} at one site: entries as in get_delta_forsite's evMatrix (detsdwopdim.cpp:3188-3229) == the vectors
+// cd/cmd/mbx/mbcx/ax/max of :2001-2030.  c0 / c1 / xs from cdw_site_terms (c0 = c1 = cosh term while cdwU == 0).
 template<int MSF>
-__device__ __forceinline__ void build_V(cplx (&V)[MSF][MSF], double sign, double c, double xs,
+__device__ __forceinline__ void build_V(cplx (&V)[MSF][MSF], double sign, double c0, double c1, double xs,
                                         double p0, double p1, double p2) {
 #pragma unroll
     for (int a = 0; a < MSF; ++a)
@@ -41,14 +41,14 @@ __device__ __forceinline__ void build_V(cplx (&V)[MSF][MSF], double sign, double
         for (int b = 0; b < MSF; ++b) V[a][b] = make_double2(0.0, 0.0);
     cplx bx = make_double2(sign * p0 * xs, -sign * p1 * xs);   // sign (phi0 - i phi1) x
     cplx bcx = make_double2(sign * p0 * xs, sign * p1 * xs);   // sign (phi0 + i phi1) x
-    V[0][0] = make_double2(c, 0.0);
-    V[1][1] = make_double2(c, 0.0);
+    V[0][0] = make_double2(c0, 0.0);
+    V[1][1] = make_double2(c1, 0.0);
     V[0][1] = bx;
     V[1][0] = bcx;
     if (MSF == 4) {
         double ax = sign * p2 * xs;
-        V[2][2] = make_double2(c, 0.0);
-        V[3][3] = make_double2(c, 0.0);
+        V[2][2] = make_double2(c0, 0.0);
+        V[3][3] = make_double2(c1, 0.0);
         V[0][3] = make_double2(ax, 0.0);
         V[3][0] = make_double2(ax, 0.0);
         V[1][2] = make_double2(-ax, 0.0);
@@ -171,12 +171,14 @@ __global__ __launch_bounds__(512) void k_bmult_chain(DevModel dm, cplx* __restri
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const int i = site[q];
-                                    const double c = dm.coshT[(size_t)k * N + i], xs = dm.sinhT[(size_t)k * N + i];
+                                    const double c = dm.coshT[(size_t)k * N + i];
+                                    double xs = dm.sinhT[(size_t)k * N + i], c0, c1;
+                                    cdw_site_terms(dm, (size_t)k * N + i, vsign, c, c0, c1, xs);
                                     const double p0 = ph[i];
                                     const double p1 = dm.opdim > 1 ? ph[N + i] : 0.0;
                                     const double p2 = dm.opdim > 2 ? ph[2 * N + i] : 0.0;
                                     cplx V[MSF][MSF];
-                                    build_V<MSF>(V, vsign, c, xs, p0, p1, p2);
+                                    build_V<MSF>(V, vsign, c0, c1, xs, p0, p1, p2);
                                     cplx in[MSF], out[MSF];
 #pragma unroll
                                     for (int b = 0; b < MSF; ++b) in[b] = x[b][q];
@@ -305,12 +307,13 @@ __global__ __launch_bounds__(512) void k_bmult_chain(DevModel dm, cplx* __restri
                 for (int idx = tid; idx < items; idx += nth, i = inext, v = vnext) {
                     inext = i + sid; vnext = v + svd;
                     if (inext >= N) { inext -= N; vnext += 1; }
-                    double c = dm.coshT[(size_t)k * N + i], xs = dm.sinhT[(size_t)k * N + i];
+                    double c = dm.coshT[(size_t)k * N + i], xs = dm.sinhT[(size_t)k * N + i], c0, c1;
+                    cdw_site_terms(dm, (size_t)k * N + i, vsign, c, c0, c1, xs);
                     double p0 = ph[i];
                     double p1 = dm.opdim > 1 ? ph[N + i] : 0.0;
                     double p2 = dm.opdim > 2 ? ph[2 * N + i] : 0.0;
                     cplx V[MSF][MSF];
-                    build_V<MSF>(V, vsign, c, xs, p0, p1, p2);
+                    build_V<MSF>(V, vsign, c0, c1, xs, p0, p1, p2);
                     cplx in[MSF], out[MSF];
 #pragma unroll
                     for (int q = 0; q < MSF; ++q) in[q] = sm[addr(v, q * N + i)];
@@ -440,6 +443,25 @@ __global__ void k_cosh_sinh(DevModel dm, size_t cs) {
 void launch_cosh_sinh(const Launch& lc, const DevModel& hm) {
     int total = hm.m * hm.N;
     hipLaunchKernelGGL(k_cosh_sinh, dim3((total + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, hm, lc.cs);
+}
+
+// updateCoshSinhTermsCDWl (detsdwopdim.cpp:1138-1143, 1183-1190): the caches of the discrete field, from the host-computed table of
+// cosh / sinh(sqrt(dtau) cdwU eta(l)) (cosh even, sinh odd in l)
+__global__ void k_cdw_terms(DevModel dm, size_t cs) {
+    dm = chain_model(dm, cs);
+    const int total = dm.m * dm.N;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const size_t e = (size_t)dm.N + idx;                     // slices 1..m
+        const double l = dm.cdwl[e];
+        const int a = (fabs(l) > 1.5) ? 1 : 0;
+        dm.cdwC[e] = dm.cdw_cosh[a];
+        dm.cdwS[e] = (l < 0.0) ? -dm.cdw_sinh[a] : dm.cdw_sinh[a];
+    }
+}
+void launch_cdw_terms(const Launch& lc, const DevModel& hm) {
+    if (!hm.cdw_on) return;
+    int total = hm.m * hm.N;
+    hipLaunchKernelGGL(k_cdw_terms, dim3((total + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, hm, lc.cs);
 }
 
 __global__ void k_set_identity(cplx* A, int n, size_t cs) {

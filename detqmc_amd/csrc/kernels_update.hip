@@ -52,10 +52,11 @@ __device__ __forceinline__ double propose_component(double phi_old, double low, 
     return phi_old + r;
 }
 
-// e^{sign dtau V} at one site (detsdwopdim.cpp:3188-3229, cdwU == 0)
+// e^{sign dtau V} at one site (detsdwopdim.cpp:3188-3229); c0 / c1: the diagonal entries (0,0) = (2,2) and (1,1) = (3,3), both the
+// cosh term while cdwU == 0; xs carries the factor coshTermCDWl otherwise
 template<int MSF>
 __device__ __forceinline__ void ev_matrix(cplx (&V)[MSF][MSF], double sign, const double* p, int opdim,
-                                          double c, double xs) {
+                                          double c0, double c1, double xs) {
 #pragma unroll
     for (int a = 0; a < MSF; ++a)
 #pragma unroll
@@ -63,14 +64,14 @@ __device__ __forceinline__ void ev_matrix(cplx (&V)[MSF][MSF], double sign, cons
     double p0 = p[0], p1 = opdim > 1 ? p[1] : 0.0;
     cplx bx = make_double2(sign * p0 * xs, -sign * p1 * xs);
     cplx bcx = make_double2(sign * p0 * xs, sign * p1 * xs);
-    V[0][0] = make_double2(c, 0.0);
-    V[1][1] = make_double2(c, 0.0);
+    V[0][0] = make_double2(c0, 0.0);
+    V[1][1] = make_double2(c1, 0.0);
     V[0][1] = bx;
     V[1][0] = bcx;
     if (MSF == 4) {
         double ax = sign * p[2] * xs;
-        V[2][2] = make_double2(c, 0.0);
-        V[3][3] = make_double2(c, 0.0);
+        V[2][2] = make_double2(c0, 0.0);
+        V[3][3] = make_double2(c1, 0.0);
         V[0][3] = make_double2(ax, 0.0);
         V[3][0] = make_double2(ax, 0.0);
         V[1][2] = make_double2(-ax, 0.0);
@@ -170,12 +171,16 @@ __device__ __forceinline__ double u_wave_total(double v) {
 // values, cosh/sinh, G[c,c], G[c,prev], G[prev,c]) are gathered by ONE wavefront with ONE load instruction --
 // lane l loads item l -- and handed to the other waves through LDS: the same scalars loaded by every lane of
 // every wave (wave-uniform vector loads) cost ~40 x 4 trips through the address coalescer per proposal.
-template<int OPDIM>
+// CDW 0: cdwU == 0.  CDW 1: phi proposals with the cdw terms of the site in e^{+-dtau V}.  CDW 2: the second pass over the slice
+// (detsdwopdim.cpp:2474-2485) -- proposeNewCDWl (:4173-4182): ONE uniform picks the new l, phi stays, probSPhi = 1 and the ratio
+// cdwl_gamma(new) / cdwl_gamma(old) joins the acceptance probability (:3110); its acceptance ratio is discarded.
+template<int OPDIM, int CDW>
 __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
                                                        const cplx* __restrict__ G, cplx* __restrict__ Wout,
                                                        int k, int first, int thermal, size_t cs) {
     constexpr int MSF = (OPDIM == 3) ? 4 : 2;
     constexpr int SLOTS = MSF * DQMC_MAX_WDIM / 64;
+    constexpr int NPROP = (CDW == 2) ? 1 : OPDIM;      // uniforms a proposal draws
     dm = chain_model(dm, cs); CHAIN(us); CHAIN(uni); CHAIN(G); CHAIN(Wout);
     dm.r = us->r;                         // the exchange parameter differs between the chains of a batch
     const int N = dm.N, ng = dm.ng, D = dm.D, m = dm.m;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     cplx* sq = sp + WD * MSF;             // q = u W                     [MSF][WD]
     double* sphi = (double*)(sq + MSF * WD);   // phi of slice k, [OPDIM][N]: all field reads and writes of the loop
     __shared__ int isite[DQMC_MAX_WDIM];       //   go here, the accepted values reach global memory after the loop
-    __shared__ double sacc[DQMC_MAX_WDIM][OPDIM + 2];   // accepted: new phi, cosh, sinh
+    __shared__ double sacc[DQMC_MAX_WDIM][OPDIM + 2 > 3 ? OPDIM + 2 : 3];   // accepted: new phi, cosh, sinh (CDW 2: l, its cosh, sinh)
     const int tid = threadIdx.x;          // 4 waves: scalar Metropolis arithmetic is done redundantly by every
     const int lane = tid & 63;            // wave, the vector parts (p, q, W update) are split over all 256 threads
     const int L = dm.L;
@@ -219,15 +224,18 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     constexpr int O_TE = O_TL + OPDIM;             // phi(later slice), phi(earlier slice)
     constexpr int O_CH = O_TE + OPDIM;
     constexpr int O_SH = O_CH + 1;
+    constexpr int O_CC = O_SH + 1;                 // CDW != 0: coshTermCDWl, sinhTermCDWl, l of the candidate site
+    constexpr int O_SC = O_CC + 1;
+    constexpr int O_CL = O_SC + 1;
     constexpr int GBLK = 2 * MSF * MSF;            // one MSF x MSF complex block; blocks are aligned to their size so
-    constexpr int O_GCC = (O_SH + GBLK) / GBLK * GBLK;   // none straddles a group of 64 lanes:  G[c rows, c cols]
+    constexpr int O_GCC = (O_CL + GBLK) / GBLK * GBLK;   // none straddles a group of 64 lanes:  G[c rows, c cols]
     constexpr int O_GNP = O_GCC + 2 * MSF * MSF;   // G[c_this rows, c_prev cols]
     constexpr int O_GPN = O_GNP + 2 * MSF * MSF;   // G[c_prev rows, c_this cols]
     constexpr int NITEMS = O_GPN + 2 * MSF * MSF;
     constexpr int NIT = (NITEMS + 63) / 64;
     static_assert(O_GCC % 2 == 0, "complex items must be 16-byte aligned in LDS");
     __shared__ __attribute__((aligned(16))) double scand[NIT * 64];
-    __shared__ __attribute__((aligned(16))) double sdec[4 * MSF * MSF + 2];   // wave 0 -> all: delta, G[c,c], exp(-dS), uniform
+    __shared__ __attribute__((aligned(16))) double sdec[4 * MSF * MSF + 4];   // wave 0 -> all: delta, G[c,c], exp(-dS), uniform, (CDW 2: null-proposal flag)
     __shared__ cplx salg[MSF == 4 ? 4 * 80 : 1];                              // O(3): wave-private scratch of the 4 x 4 algebra (S, M', cofactors, M'^-1, F)
 
     auto neighbours = [&](int s, int (&nbr)[4]) {
@@ -261,6 +269,8 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 addr = coshK + s;
             } else if (item == O_SH) {
                 addr = sinhK + s;
+            } else if (CDW != 0 && item >= O_CC && item <= O_CL) {
+                addr = (item == O_CC ? dm.cdwC : item == O_SC ? dm.cdwS : dm.cdwl) + (size_t)k * N + s;
             } else if (item >= O_GCC && item < NITEMS) {
                 const int t = item - O_GCC;
                 const int blk = t / (2 * MSF * MSF), e = t % (2 * MSF * MSF);
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
 
     int it = 0;                                    // proposal counter of this launch: selects the u/v buffer
     while (j < dnow && site < N && it < budget) {
-        if (cur + OPDIM + 1 > avail) { err = DQMC_ERNG; break; }
+        if (cur + NPROP + 1 > avail) { err = DQMC_ERNG; break; }
         const int nI = MSF * j;
         cplx* su = su2 + (it & 1) * MSF * WD;
         cplx* sv = sv2 + (it & 1) * WD * MSF;
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         TICK(1);
         // ---- C: start the loads of the NEXT candidate now; they complete while this decision is computed ----
         const bool have_next = (site + 1 < N);
-        if (have_next) fetch(pre, pu, pv, site + 1, site, cur + OPDIM, nI);
+        if (have_next) fetch(pre, pu, pv, site + 1, site, cur + NPROP, nI);
         // ---- the waves split the work between the two barriers: wave 0 does the scalar Metropolis arithmetic of this
         //      proposal (D) and hands delta, exp(-dS), the acceptance uniform and G[c,c] to the others through LDS; waves
         //      1-3 meanwhile form p and q (E).  Neither waits for the other before barrier 2. ----
@@ -364,7 +374,8 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         double newphi[OPDIM], coshN = 0.0, sinhN = 0.0;
 #pragma unroll
         for (int d = 0; d < OPDIM; ++d) newphi[d] = 0.0;
-        cur += OPDIM;
+        cur += NPROP;
+        double lnew = 0.0, cCn = 1.0, sCn = 0.0;          // CDW 2: the proposed l and its cosh / sinh terms
         TICK(2);
         if (tid >= 64) {
             // ---- E: p = W v and, speculatively (needed only on acceptance), q = u W.  Work item = one ROW of p (all MSF entries
@@ -417,14 +428,14 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             for (int d = 0; d < OPDIM; ++d) {
                 oldphi[d] = sphi[d * N + site];
                 double low = -phiDelta, high = phiDelta;
-                newphi[d] = propose_component(oldphi[d], low, high, scand[O_UNI + uoff + d]);
+                newphi[d] = (CDW == 2) ? oldphi[d] : propose_component(oldphi[d], low, high, scand[O_UNI + uoff + d]);
                 // XPLUS, XMINUS, YPLUS, YMINUS in the order of the reference's neighbour loop (:4208-4214)
                 snb[d] = ((0.0 + sphi[d * N + nbr[0]]) + sphi[d * N + nbr[1]]) + sphi[d * N + nbr[2]] + sphi[d * N + nbr[3]];
                 tnb[d] = scand[O_TL + d] + scand[O_TE + d];
             }
             const double coshO = scand[O_CH], sinhO = scand[O_SH];
-            double dsphi;
-            {
+            double dsphi = 0.0;
+            if constexpr (CDW != 2) {
                 double oldSq = 0.0, newSq = 0.0;
 #pragma unroll
                 for (int d = 0; d < OPDIM; ++d) { oldSq += oldphi[d] * oldphi[d]; newSq += newphi[d] * newphi[d]; }
@@ -447,7 +458,23 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 }
             }
             double probSPhi;
-            {
+            // cdw terms of the site as it is (cC, sC) and as proposed (cCn, sCn)
+            double cCo = 1.0, sCo = 0.0;
+            if constexpr (CDW != 0) { cCo = scand[O_CC]; sCo = scand[O_SC]; cCn = cCo; sCn = sCo; }
+            bool nullp = false;
+            if constexpr (CDW == 2) {
+                const double r01 = scand[O_UNI + uoff], lold = scand[O_CL];
+                lnew = (r01 <= 0.25) ? 2.0 : (r01 <= 0.5) ? -2.0 : (r01 <= 0.75) ? 1.0 : -1.0;
+                const int an = (fabs(lnew) > 1.5) ? 1 : 0, ao = (fabs(lold) > 1.5) ? 1 : 0;
+                cCn = dm.cdw_cosh[an];
+                sCn = (lnew < 0.0) ? -dm.cdw_sinh[an] : dm.cdw_sinh[an];
+                probSPhi = dm.cdw_gamma[an] / dm.cdw_gamma[ao];       // prob_cdwl; probSPhi itself is 1 for a CDWL proposal
+                // The proposal drew the value the site already has: delta = 0 and the probability is 1 in exact arithmetic -- a
+                // uniform is drawn, nothing changes (the reference's floating point lands on 1 or 1 + 2^-52 there and skips the uniform
+                // in the second case)
+                nullp = (lnew == lold);
+                coshN = coshO; sinhN = sinhO;
+            } else {
                 double nn = 0.0;
 #pragma unroll
                 for (int d = 0; d < OPDIM; ++d) nn += newphi[d] * newphi[d];
@@ -467,8 +494,13 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 sinhN = sh / nrm;
             }
             cplx evOld[MSF][MSF], emvNew[MSF][MSF];
-            ev_matrix<MSF>(evOld, +1.0, oldphi, OPDIM, coshO, sinhO);
-            ev_matrix<MSF>(emvNew, -1.0, newphi, OPDIM, coshN, sinhN);
+            if constexpr (CDW == 0) {
+                ev_matrix<MSF>(evOld, +1.0, oldphi, OPDIM, coshO, coshO, sinhO);
+                ev_matrix<MSF>(emvNew, -1.0, newphi, OPDIM, coshN, coshN, sinhN);
+            } else {
+                ev_matrix<MSF>(evOld, +1.0, oldphi, OPDIM, coshO * cCo - sCo, coshO * cCo + sCo, sinhO * cCo);
+                ev_matrix<MSF>(emvNew, -1.0, newphi, OPDIM, coshN * cCn + sCn, coshN * cCn - sCn, sinhN * cCn);
+            }
             if (tid < MSF * MSF) {             // lane (a, b) publishes delta[a][b] and G[c,c][a][b]
                 cplx dsel = make_double2(0.0, 0.0);
 #pragma unroll
@@ -485,7 +517,8 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             }
             if (tid == 0) {
                 sdec[4 * MSF * MSF] = probSPhi;
-                sdec[4 * MSF * MSF + 1] = scand[O_UNI + uoff + OPDIM];
+                sdec[4 * MSF * MSF + 1] = scand[O_UNI + uoff + NPROP];
+                if constexpr (CDW == 2) { sdec[4 * MSF * MSF + 2] = nullp ? 1.0 : 0.0; sdec[4 * MSF * MSF + 3] = lnew; }
             }
         }
         TICK(4);
@@ -594,15 +627,25 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         double prob = probSPhi * probSFermion;
         bool accept = prob > 1.0;
         bool used_uniform = false;
+        if constexpr (CDW == 2) {
+            if (sdec[4 * MSF * MSF + 2] != 0.0) { prob = 1.0; accept = false; }      // null proposal: the uniform is drawn, the state stays
+        }
         if (!accept) { accept = uacc < prob; cur += 1; used_uniform = true; }   // rand01 drawn only if prob <= 1 (:3113)
+        if constexpr (CDW == 2) {
+            if (sdec[4 * MSF * MSF + 2] != 0.0) accept = false;
+        }
         TICK(7);
         if (accept) {
             acc_count += 1;
             if (tid == 0) {
+                if constexpr (CDW == 2) {
+                    sacc[j][0] = lnew; sacc[j][1] = cCn; sacc[j][2] = sCn;
+                } else {
 #pragma unroll
-                for (int d = 0; d < OPDIM; ++d) { sphi[d * N + site] = newphi[d]; sacc[j][d] = newphi[d]; }
-                sacc[j][OPDIM] = coshN;
-                sacc[j][OPDIM + 1] = sinhN;
+                    for (int d = 0; d < OPDIM; ++d) { sphi[d * N + site] = newphi[d]; sacc[j][d] = newphi[d]; }
+                    sacc[j][OPDIM] = coshN;
+                    sacc[j][OPDIM + 1] = sinhN;
+                }
                 isite[j] = site;
             }
             // F = delta M'^-1
@@ -704,10 +747,16 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     // the accepted field values and their cosh / sinh terms (updateCoshSinhTerms, :3128-3140)
     if (tid < j) {
         const int st = isite[tid];
+        if constexpr (CDW == 2) {
+            dm.cdwl[(size_t)k * N + st] = sacc[tid][0];
+            dm.cdwC[(size_t)k * N + st] = sacc[tid][1];
+            dm.cdwS[(size_t)k * N + st] = sacc[tid][2];
+        } else {
 #pragma unroll
-        for (int d = 0; d < OPDIM; ++d) phik[d * N + st] = sacc[tid][d];
-        dm.coshT[(size_t)k * N + st] = sacc[tid][OPDIM];
-        dm.sinhT[(size_t)k * N + st] = sacc[tid][OPDIM + 1];
+            for (int d = 0; d < OPDIM; ++d) phik[d * N + st] = sacc[tid][d];
+            dm.coshT[(size_t)k * N + st] = sacc[tid][OPDIM];
+            dm.sinhT[(size_t)k * N + st] = sacc[tid][OPDIM + 1];
+        }
     }
 
     // ---- publish block result ----
@@ -728,8 +777,8 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         if (site >= N && err == 0) {
             sdone = 1;
             double accratio = (double)acc_count / (double)N;            // :3173
-            us->pub.lastAccRatio = accratio;
-            if (thermal) {
+            if (CDW != 2) us->pub.lastAccRatio = accratio;              // the cdwl pass's ratio is discarded (:2476-2477)
+            if (thermal && CDW != 2) {
                 // RunningAverage::addValue (RunningAverage.h:57-68), sampleSize = 100
                 const int sampleSize = 100;
                 double ra = us->pub.ra_runningAverage;
@@ -767,30 +816,30 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
 }
 
 void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, DevUpdateState* us,
-                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal) {
+                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal, int cdw_pass) {
     const int WD = hm.MSF * hm.D;
     size_t lds = ((size_t)WD * (WD + 1) + 6 * (size_t)hm.MSF * WD) * sizeof(cplx) + (size_t)hm.opdim * hm.N * sizeof(double);
+    const int cdw = hm.cdw_on ? (cdw_pass ? 2 : 1) : 0;
+    const void* f = nullptr;
+#define DECIDE_CASE(O, C) if (hm.opdim == O && cdw == C) f = (const void*)k_update_decide<O, C>;
+    DECIDE_CASE(1, 0) DECIDE_CASE(1, 1) DECIDE_CASE(1, 2) DECIDE_CASE(2, 0) DECIDE_CASE(2, 1) DECIDE_CASE(2, 2)
+    DECIDE_CASE(3, 0) DECIDE_CASE(3, 1) DECIDE_CASE(3, 2)
+#undef DECIDE_CASE
     if (lds > 48 * 1024) {     // deep delay blocks: raise the dynamic LDS limit of the instantiation to what is needed
         // the attribute belongs to (function, device); several contexts / host threads may get here at once
         static std::mutex mu;
-        static size_t raised_tab[64][4] = {};
+        static size_t raised_tab[64][12] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> lk(mu);
-        size_t* raised = raised_tab[dev & 63];
-        if (lds > raised[hm.opdim]) {
-            const void* f = hm.opdim == 1 ? (const void*)k_update_decide<1> : hm.opdim == 2 ? (const void*)k_update_decide<2>
-                                                                                           : (const void*)k_update_decide<3>;
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised[hm.opdim] = lds;
+        size_t& raised = raised_tab[dev & 63][(hm.opdim - 1) * 3 + cdw];
+        if (lds > raised) {
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised = lds;
             else (void)hipGetLastError();      // the launch below then reports the problem
         }
     }
-    if (hm.opdim == 1)
-        hipLaunchKernelGGL((k_update_decide<1>), dim3(1, 1, lc.nb), dim3(256), lds, lc.st, hm, us, uniforms, G, W, k, first, thermal, lc.cs);
-    else if (hm.opdim == 2)
-        hipLaunchKernelGGL((k_update_decide<2>), dim3(1, 1, lc.nb), dim3(256), lds, lc.st, hm, us, uniforms, G, W, k, first, thermal, lc.cs);
-    else
-        hipLaunchKernelGGL((k_update_decide<3>), dim3(1, 1, lc.nb), dim3(256), lds, lc.st, hm, us, uniforms, G, W, k, first, thermal, lc.cs);
+    void* args[] = {(void*)&hm, (void*)&us, (void*)&uniforms, (void*)&G, (void*)&W, (void*)&k, (void*)&first, (void*)&thermal, (void*)&lc.cs};
+    (void)hipLaunchKernel(f, dim3(1, 1, lc.nb), dim3(256), args, lds, lc.st);
 }
 
 // X[:, i'] = sum_i G[:, I_i] W[i, i']   (n_g x nI8, ld n_g);   GrT[:, i] = (G[I_i, :] - E)^T   (n_g x nI8, ld n_g)

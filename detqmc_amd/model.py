@@ -74,12 +74,12 @@ class KernelContext:
 
     def __init__(self, opdim, L, m, s, dtau, delaySteps=16, bc="pbc", weakZflux=False, r=-1.0, c=3.0, u=1.0,
                  lambda_=1.0, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, mux=-0.5, muy=-0.5,
-                 accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd", checkerboard=True, nchains=1):
+                 accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd", checkerboard=True, nchains=1, cdwU=0.0):
         self.lib = load()
         p = _lib.dqmc_params(opdim=opdim, L=L, m=m, s=s, delaySteps=delaySteps, bc=BC[bc],
                              weakZflux=int(weakZflux), phi2bosons=int(phi2bosons), device=device,
                              stabilisation=STABILISATION[stabilisation], cb_none=int(not checkerboard), dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
-                             tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio)
+                             tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio, cdwU=cdwU)
         h = C.c_void_p()
         check(self.lib.dqmc_create_batch(C.byref(p), nchains, C.byref(h)))
         self.h = h
@@ -114,6 +114,17 @@ class KernelContext:
     def set_fields(self, phi_kNd):
         ref = np.asfortranarray(np.transpose(np.asarray(phi_kNd, dtype=np.float64), (1, 2, 0)))
         check(self.lib.dqmc_set_fields_host(self.h, ref.ctypes.data_as(_lib._DP)))
+
+    # the discrete field of cdwU != 0: (m+1, N) int32, values +-1 / +-2 (slice 0 unused)
+    def set_cdwl(self, cdwl_kN):
+        a = np.ascontiguousarray(cdwl_kN, dtype=np.int32)
+        assert a.shape == (self.m + 1, self.N)
+        check(self.lib.dqmc_set_cdwl_host(self.h, a.ctypes.data))
+
+    def get_cdwl(self):
+        a = np.zeros((self.m + 1, self.N), dtype=np.int32)
+        check(self.lib.dqmc_get_cdwl_host(self.h, a.ctypes.data))
+        return a
 
     def get_fields(self):
         phi = np.zeros((self.N, self.opdim, self.m + 1), order="F")
@@ -383,6 +394,20 @@ class DetSDW:
         a = np.zeros((i.N, i.opdim, i.m + 1), order="F")
         check(self.lib.detsdw_get_phi(self.h, a.ctypes.data_as(_lib._DP)), host=True)
         return np.transpose(a, (2, 0, 1)).copy()
+
+    @property
+    def cdwl(self):
+        """(m+1, N) int32: the discrete field l_i(tau_k) of cdwU != 0 (drawn at set-up whatever cdwU is; slice 0 unused)."""
+        self._sel()
+        i = self.info
+        a = np.zeros((i.m + 1, i.N), dtype=np.int32)
+        check(self.lib.detsdw_get_cdwl(self.h, a.ctypes.data), host=True)
+        return a
+
+    def set_cdwl(self, cdwl_kN):
+        self._sel()
+        a = np.ascontiguousarray(cdwl_kN, dtype=np.int32)
+        check(self.lib.detsdw_set_cdwl(self.h, a.ctypes.data), host=True)
 
     def set_phi(self, phi_kNd):
         self._sel()

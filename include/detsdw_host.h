@@ -25,7 +25,7 @@ typedef struct detsdw_replica detsdw_replica;
 
 /* ModelParamsDetSDW (src/detsdwparams.h:24-120) + rngSeed/simindex of DetQMCParams
  * (src/detqmcparams.h) as far as the sweep path uses them.  Unsupported reference options
- * (cdwU != 0, turnoffFermions, rotate/scale proposals) are rejected by
+ * (turnoffFermions, rotate/scale proposals) are rejected by
  * detsdw_create with DQMC_EINVAL and a message naming the option. */
 typedef struct detsdw_params {
     int32_t opdim;
@@ -48,7 +48,7 @@ typedef struct detsdw_params {
     double txhor, txver, tyhor, tyver;
     double mu, mux, muy;
     double accRatio;
-    double cdwU;                 /* must be 0 */
+    double cdwU;                 /* != 0: discrete field l_i(tau) next to phi, updated in a second pass over each slice (detsdwopdim.cpp:2474-2485) */
     int32_t stabilisation;       /* 0 = SVD (as the reference), 1 = QR/UDT (same G to rounding, much faster) */
     int32_t cb_none;             /* 0 = checkerboard (default), 1 = checkerboard=false: dense B matrices (CB_NONE) */
     int32_t wolffClusterUpdate;       /* attemptWolffClusterUpdate every globalUpdateInterval sweeps (detsdwopdim.cpp:3488-3562) */
@@ -133,6 +133,10 @@ int detsdw_get_observable_vector(detsdw_replica* r, int which, double* out);
 /* phi in the reference layout (N, OPDIM, m+1) column-major */
 int detsdw_get_phi(detsdw_replica* r, double* phi);
 int detsdw_set_phi(detsdw_replica* r, const double* phi);      /* also rebuilds UdV storage and G */
+/* the discrete field cdwl(site, k) in the reference layout (N x (m+1) column-major, values +-1 / +-2, slice 0 unused);
+ * set needs cdwU != 0 and rebuilds UdV storage and G */
+int detsdw_get_cdwl(detsdw_replica* r, int32_t* cdwl);
+int detsdw_set_cdwl(detsdw_replica* r, const int32_t* cdwl);
 int detsdw_get_green(detsdw_replica* r, dqmc_cplx* g);
 int detsdw_get_green_inv_sv(detsdw_replica* r, double* sv);
 double detsdw_rng_rand01(detsdw_replica* r);                   /* draws from the replica's stream */

@@ -74,6 +74,8 @@ typedef struct dqmc_params {
     double txhor, txver, tyhor, tyver;
     double mux, muy;
     double accRatio;      /* target acceptance for the box step adaptation */
+    double cdwU;          /* != 0: the discrete field l_i(tau) in {+-1, +-2} next to phi (detsdwparams.h:61; evMatrix,
+                             detsdwopdim.cpp:3187-3229); dqmc_update_slice then runs the cdwl pass behind the phi pass (:2474-2485) */
 } dqmc_params;
 
 /* AdjustmentData + slice bookkeeping that lives on the device between calls
@@ -117,6 +119,11 @@ void* dqmc_stream(dqmc_ctx* ctx);
 /* upload phi and recompute cosh/sinh caches: updateCoshSinhTermsPhi (detsdwopdim.cpp:1175-1181) */
 int dqmc_set_fields_host(dqmc_ctx* ctx, const double* phi);
 int dqmc_get_fields_host(dqmc_ctx* ctx, double* phi, double* coshTermPhi, double* sinhTermPhi);
+/* cdwU != 0: the discrete field of the selected chain, cdwl[k * N + site] in {+-1, +-2} (slice 0 unused); set recomputes
+ * coshTermCDWl / sinhTermCDWl (updateCoshSinhTermsCDWl, detsdwopdim.cpp:1183-1190).  After dqmc_create the field is +1
+ * everywhere (setupConstantField, :1116-1128).  DQMC_EINVAL on a context created with cdwU == 0. */
+int dqmc_set_cdwl_host(dqmc_ctx* ctx, const int32_t* cdwl);
+int dqmc_get_cdwl_host(dqmc_ctx* ctx, int32_t* cdwl);
 /* all chains of a batched context in ONE transfer: phi_all = nchains cubes of (m+1) * opdim * N doubles, back to back */
 int dqmc_set_fields_all_host(dqmc_ctx* ctx, const double* phi_all);
 int dqmc_get_fields_all_host(dqmc_ctx* ctx, double* phi_all);

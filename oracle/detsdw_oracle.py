@@ -47,6 +47,7 @@ class SDWParams:
     muy: float = None
     accRatio: float = 0.5
     delaySteps: int = 16
+    cdwU: float = 0.0             # != 0: discrete four-valued field l_i(tau) coupled to the band-charge difference (detsdwparams.h:61)
     bc: str = "pbc"
     weakZflux: bool = False
     globalShift: bool = False
@@ -163,7 +164,7 @@ class DetSDWOracle:
     phiDeltaGrowFactor = 1.05
     phiDeltaShrinkFactor = 0.95
 
-    def __init__(self, pars: SDWParams, rng: RngWrapper = None, phi=None):
+    def __init__(self, pars: SDWParams, rng: RngWrapper = None, phi=None, cdwl=None):
         """DetSDW ctor, detsdwopdim.cpp:158-361."""
         p = pars.finalize() if pars.m == 0 else pars
         self.pars = p
@@ -177,6 +178,10 @@ class DetSDWOracle:
         self.phi = np.zeros((m + 1, N, self.OPDIM))
         self.coshTermPhi = np.zeros((m + 1, N))
         self.sinhTermPhi = np.zeros((m + 1, N))
+        # discrete field and its caches (ctor :176-209: cdwl.zeros(), coshTermCDWl.ones(), sinhTermCDWl.zeros())
+        self.cdwl = np.zeros((m + 1, N), dtype=np.int32)
+        self.coshTermCDWl = np.ones((m + 1, N))
+        self.sinhTermCDWl = np.zeros((m + 1, N))
         # AdjustmentData (detsdwopdim.h:481-577) and UpdateStatistics (:285-311)
         self.phiDelta = self.InitialPhiDelta
         self.targetAccRatioLocal_phi = p.accRatio
@@ -195,7 +200,10 @@ class DetSDWOracle:
             self.setupRandomField()
         else:
             self.phi[:] = phi
+            self.cdwl[1:] = 1 if cdwl is None else np.asarray(cdwl)[1:]
             self.updateCoshSinhTermsPhi()
+            if p.cdwU:
+                self.updateCoshSinhTermsCDWl()
         self._setup_hopping()
         self.g = np.zeros((self.ng, self.ng), dtype=complex)
         self.g_inv_sv = np.zeros(self.ng)
@@ -217,15 +225,53 @@ class DetSDWOracle:
             ((y - 1 + L) % L) * L + x,
         ])  # [dir, site]
 
+    @staticmethod
+    def cdwl_from_uniform(r):
+        """The four-way draw of setupRandomField (:1105-1109) and proposeNewCDWl (:4176-4180)."""
+        if r <= 0.25:
+            return +2
+        if r <= 0.5:
+            return -2
+        if r <= 0.75:
+            return +1
+        return -1
+
+    @staticmethod
+    def cdwl_gamma(l):
+        """detsdwopdim.h:1209-1220."""
+        return (3.0 + math.sqrt(6.0)) if abs(l) == 1 else ((3.0 - math.sqrt(6.0)) if abs(l) == 2 else 0.0)
+
+    @staticmethod
+    def cdwl_eta(l):
+        """detsdwopdim.h:1222-1235."""
+        if abs(l) == 1:
+            return math.copysign(math.sqrt(2.0 * (3.0 - math.sqrt(6.0))), l)
+        if abs(l) == 2:
+            return math.copysign(math.sqrt(2.0 * (3.0 + math.sqrt(6.0))), l)
+        return 0.0
+
+    def getCoshSinhTermCDWl(self, l):
+        """detsdwopdim.cpp:1138-1143."""
+        arg = math.sqrt(self.dtau) * self.pars.cdwU * self.cdwl_eta(int(l))
+        return math.cosh(arg), math.sinh(arg)
+
+    def updateCoshSinhTermsCDWl(self):
+        """detsdwopdim.cpp:1183-1190 (only called when cdwU != 0, :1148-1151)."""
+        for k in range(1, self.m + 1):
+            for site in range(self.N):
+                self.coshTermCDWl[k, site], self.sinhTermCDWl[k, site] = self.getCoshSinhTermCDWl(self.cdwl[k, site])
+
     def setupRandomField(self):
-        """detsdwopdim.cpp:1099-1113: k outer, site, dim; one extra rand01 per site for cdwl."""
+        """detsdwopdim.cpp:1099-1113: k outer, site, dim; one more rand01 per site sets cdwl (whatever cdwU is)."""
         rng = self.rng
         for k in range(1, self.m + 1):
             for site in range(self.N):
                 for dim in range(self.OPDIM):
                     self.phi[k, site, dim] = rng.randRange(-1.0, 1.0)
-                rng.rand01()  # cdwl draw (value unused while cdwU == 0)
+                self.cdwl[k, site] = self.cdwl_from_uniform(rng.rand01())
         self.updateCoshSinhTermsPhi()
+        if self.pars.cdwU:
+            self.updateCoshSinhTermsCDWl()
 
     def getCoshSinhTermPhi(self, phivec):
         """detsdwopdim.cpp:1132-1136."""
@@ -342,20 +388,21 @@ class DetSDWOracle:
         return R
 
     # ------------------------------------------------------------------ e^{sign dtau V} per site
-    def evMatrix(self, sign, phivec, coshT, sinhT):
-        """detsdwopdim.cpp:3188-3229 with cdwU == 0 (coshCDW=1, sinhCDW=0)."""
+    def evMatrix(self, sign, phivec, coshT, sinhT, coshC=1.0, sinhC=0.0):
+        """detsdwopdim.cpp:3188-3229 (coshC = 1, sinhC = 0 while cdwU == 0)."""
         M = self.MSF
         ev = np.zeros((M, M), dtype=complex)
         p0 = phivec[0]
         p1 = phivec[1] if self.OPDIM > 1 else 0.0
-        ev[0, 0] = coshT
-        ev[1, 1] = coshT
+        ev[0, 0] = coshT * coshC - sign * sinhC
+        ev[1, 1] = coshT * coshC + sign * sinhC
+        sinhT = sinhT * coshC
         ev[0, 1] = sign * (p0 - 1j * p1) * sinhT
         ev[1, 0] = sign * (p0 + 1j * p1) * sinhT
         if self.OPDIM == 3:
             p2 = phivec[2]
-            ev[2, 2] = coshT
-            ev[3, 3] = coshT
+            ev[2, 2] = ev[0, 0]
+            ev[3, 3] = ev[1, 1]
             ev[0, 3] = sign * p2 * sinhT
             ev[3, 0] = sign * p2 * sinhT
             ev[2, 1] = -sign * p2 * sinhT
@@ -371,18 +418,23 @@ class DetSDWOracle:
         V = np.zeros((M, M, N), dtype=complex)
         c = self.coshTermPhi[k]
         x = self.sinhTermPhi[k]
+        cd, cmd = c, c
+        if self.pars.cdwU:           # cd / cmd and the cosh factor of the off-diagonal vectors, :2003-2030
+            cd = c * self.coshTermCDWl[k] - sign * self.sinhTermCDWl[k]
+            cmd = c * self.coshTermCDWl[k] + sign * self.sinhTermCDWl[k]
+            x = x * self.coshTermCDWl[k]
         p0 = self.phi[k, :, 0]
         p1 = self.phi[k, :, 1] if self.OPDIM > 1 else np.zeros(N)
         b = (p0 - 1j * p1) * x
         bc = (p0 + 1j * p1) * x
-        V[0, 0] = c
-        V[1, 1] = c
+        V[0, 0] = cd
+        V[1, 1] = cmd
         V[0, 1] = sign * b
         V[1, 0] = sign * bc
         if self.OPDIM == 3:
             ax = self.phi[k, :, 2] * x
-            V[2, 2] = c
-            V[3, 3] = c
+            V[2, 2] = cd
+            V[3, 3] = cmd
             V[0, 3] = sign * ax
             V[3, 0] = sign * ax
             V[1, 2] = -sign * ax
@@ -590,11 +642,15 @@ class DetSDWOracle:
         delta3 = dtau * (0.5 * r * phiSqDiff + 0.25 * u * phiPow4Diff)
         return delta1 + delta2 + delta3
 
-    def get_delta_forsite(self, newphi, k, site):
+    def get_delta_forsite(self, newphi, k, site, new_cdwl=None):
         """detsdwopdim.cpp:3179-3289: e^{-dtau V_new} e^{+dtau V_old} - 1 at one site."""
-        evOld = self.evMatrix(+1, self.phi[k, site], self.coshTermPhi[k, site], self.sinhTermPhi[k, site])
+        cCo, sCo, cCn, sCn = 1.0, 0.0, 1.0, 0.0
+        if self.pars.cdwU:
+            cCo, sCo = self.coshTermCDWl[k, site], self.sinhTermCDWl[k, site]
+            cCn, sCn = self.getCoshSinhTermCDWl(self.cdwl[k, site] if new_cdwl is None else new_cdwl)
+        evOld = self.evMatrix(+1, self.phi[k, site], self.coshTermPhi[k, site], self.sinhTermPhi[k, site], cCo, sCo)
         cN, sN = self.getCoshSinhTermPhi(newphi)
-        emvNew = self.evMatrix(-1, newphi, cN, sN)
+        emvNew = self.evMatrix(-1, newphi, cN, sN, cCn, sCn)
         return emvNew @ evOld - np.eye(self.MSF)
 
     def proposeNewPhiBox(self, site, k):
@@ -604,8 +660,12 @@ class DetSDWOracle:
             newphi[d] += self.rng.randRange(-self.phiDelta, +self.phiDelta)
         return newphi
 
-    def updateInSlice_delayed(self, k):
-        """detsdwopdim.cpp:3023-3175."""
+    def proposeNewCDWl(self, site, k):
+        """detsdwopdim.cpp:4173-4182: one uniform, the field phi stays."""
+        return self.cdwl_from_uniform(self.rng.rand01())
+
+    def updateInSlice_delayed(self, k, what="phi"):
+        """detsdwopdim.cpp:3023-3175; what = "phi" (box proposals) or "cdwl" (proposeNewCDWl: changed == CDWL, probSPhi = 1)."""
         MSF, N, D = self.MSF, self.N, self.pars.delaySteps
         g = self.g
         accratio = 0.0
@@ -617,9 +677,15 @@ class DetSDWOracle:
             Y = np.zeros((MSF * delayStepsNow, MSF * N), dtype=complex)
             j = 0
             while j < delayStepsNow and site < N:
-                newphi = self.proposeNewPhiBox(site, k)
-                probSPhi = math.exp(-self.deltaSPhi(site, k, newphi))
-                delta = self.get_delta_forsite(newphi, k, site)
+                if what == "phi":
+                    newphi = self.proposeNewPhiBox(site, k)
+                    new_cdwl = int(self.cdwl[k, site])
+                    probSPhi = math.exp(-self.deltaSPhi(site, k, newphi))
+                else:
+                    newphi = self.phi[k, site].copy()
+                    new_cdwl = self.proposeNewCDWl(site, k)
+                    probSPhi = 1.0
+                delta = self.get_delta_forsite(newphi, k, site, new_cdwl)
                 idx = site + N * np.arange(MSF)
                 Rj = g[idx, :].copy()
                 if j > 0:
@@ -631,11 +697,23 @@ class DetSDWOracle:
                     probSFermion = det.real
                 else:
                     probSFermion = abs(det) ** 2
-                prob = probSPhi * probSFermion
+                prob_cdwl = self.cdwl_gamma(new_cdwl) / self.cdwl_gamma(int(self.cdwl[k, site]))     # :3110 (1 for a phi proposal)
+                prob = probSPhi * probSFermion * prob_cdwl
+                if what == "cdwl" and new_cdwl == int(self.cdwl[k, site]):
+                    # A proposal that draws the value the site already has (one in four): delta = 0 and prob = 1 in exact arithmetic, so
+                    # `prob > 1.0` is false, a uniform is drawn and the (null) update accepted.  In floating point the reference's
+                    # |det|^2 is 1 or 1 + 2^-52 depending on the last bit of e^{-dtau V} e^{+dtau V} - 1 and of G -- about one null
+                    # proposal in a hundred takes the other branch and skips the uniform; no independent implementation (or another BLAS
+                    # under the reference itself) can follow that.  The oracle and the HIP path take the exact-arithmetic branch; the
+                    # cdw fixtures use seeds on which the reference does too over their whole trajectory (oracle/make_golden.py).
+                    prob = 1.0
                 if prob > 1.0 or self.rng.rand01() < prob:
                     accratio += 1.0
                     self.phi[k, site] = newphi
+                    self.cdwl[k, site] = new_cdwl
                     self.coshTermPhi[k, site], self.sinhTermPhi[k, site] = self.getCoshSinhTermPhi(newphi)
+                    if self.pars.cdwU:
+                        self.coshTermCDWl[k, site], self.sinhTermCDWl[k, site] = self.getCoshSinhTermCDWl(new_cdwl)
                     Cj = g[:, idx].copy()
                     if j > 0:
                         Cj += X[:, :MSF * j] @ Y[:MSF * j, idx]
@@ -651,6 +729,8 @@ class DetSDWOracle:
     def updateInSlice(self, k):
         """detsdwopdim.cpp:2428-2489 (box proposals, delayed method, repeatUpdateInSlice=1)."""
         self.lastAccRatioLocal_phi = self.updateInSlice_delayed(k)
+        if self.pars.cdwU:                              # :2474-2485: second pass over the slice, its acceptance ratio is discarded
+            self.updateInSlice_delayed(k, "cdwl")
 
     def updateInSliceThermalization(self, k):
         """detsdwopdim.cpp:3294-3375 (ADAPT_BOX branch)."""

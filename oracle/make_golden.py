@@ -61,6 +61,18 @@ CASES = {
     "o2_L4_dense": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=3, checkerboard=0)),
     "o2_L4_dense_flux": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=2, checkerboard=0, weakZflux=1,
                                       bc="apbc-x", mux=-0.3, muy=-0.6)),
+    # round 3: cdwU != 0 -- the discrete four-valued field l_i(tau) next to phi (setupRandomField :1099-1113, evMatrix :3187-3229,
+    # proposeNewCDWl :4173-4182, the second updateInSlice pass :2474-2485)
+    # (the seeds: oracle/find_cdw_seeds.py -- trajectories on which the reference's last-bit decision at null cdwl proposals is the
+    #  exact-arithmetic one; for O(3) that decision is a coin flip per null proposal, so the O(3) fixture stops after one slice)
+    "o2_L4_cdw": dict(args=dict(rngSeed=1021, opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=2, cdwU=0.5, sliceTrace=0)),
+    "o1_L4_cdw": dict(args=dict(rngSeed=1006, opdim=1, L=4, beta=2, s=10, delaySteps=6, sweeps=2, cdwU=0.4, sliceTrace=0)),
+    "o2_L4_cdw_slice": dict(args=dict(rngSeed=1000, opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=0, cdwU=0.5, sliceTrace=2)),
+    "o3_L4_cdw_slice": dict(args=dict(rngSeed=1003, opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=0, cdwU=0.7, sliceTrace=2)),
+    "o3_L4_cdw": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=1, cdwU=0.7, sliceTrace=0)),
+    "o2_L4_cdw_gshift": dict(args=dict(rngSeed=1018, opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=2, cdwU=0.5, globalShift=1, globalUpdateInterval=1,
+                                       sliceTrace=0, weakZflux=1)),
+    "o2_L4_cdw_dense": dict(args=dict(rngSeed=1007, opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=1, cdwU=0.5, checkerboard=0, sliceTrace=0)),
     "o1_L4": dict(args=dict(opdim=1, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
     "o3_L4": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
     # BASELINE config 2 (bring-up size): full G only at a few points

@@ -174,6 +174,7 @@ static arma::Mat<cpx_t> test_matrix(uint32_t n) {
 template<class SDW>
 static void dump_state(SDW& rep, const std::string& tag) {
     dump(tag + "_phi", rep.phi);
+    if (rep.pars.cdwU) dump(tag + "_cdwl", arma::conv_to<arma::Mat<double>>::from(rep.cdwl));   // discrete field l_i(tau_k), N x (m+1)
     dump(tag + "_g", rep.g);
     dump(tag + "_g_inv_sv", rep.g_inv_sv);
     dump_scalar(tag + "_phiDelta", rep.ad.phiDelta);
@@ -243,6 +244,7 @@ static int run(const std::map<std::string, std::string>& kv) {
 
     // --- state right after construction: random field, caches, UdV storage, G(beta) ---
     dump("init_phi", rep->phi);
+    if (pars.cdwU) dump("init_cdwl", arma::conv_to<arma::Mat<double>>::from(rep->cdwl));
     dump("init_coshTermPhi", rep->coshTermPhi);
     dump("init_sinhTermPhi", rep->sinhTermPhi);
     dump("init_g", rep->g);
@@ -287,6 +289,7 @@ static int run(const std::map<std::string, std::string>& kv) {
     if (get<int>(kv, "sliceTrace", 1)) {
         rep->updateInSliceThermalization(m);   // detsdwopdim.cpp:3294 (calls updateInSlice + adaptation)
         dump("slice_phi_m", arma::Mat<double>(rep->phi.slice(m)));
+        if (pars.cdwU) dump("slice_cdwl_m", arma::conv_to<arma::Mat<double>>::from(rep->cdwl.col(m)));
         dump("slice_g", rep->g);
         dump_scalar("slice_accRatio", rep->ad.lastAccRatioLocal_phi);
         // finish that down-sweep by hand exactly as sweepDown would (detmodel.h:1364-1392)

@@ -30,7 +30,7 @@ def oracle_params(args):
     for k in ("opdim", "L", "s", "delaySteps", "globalUpdateInterval"):
         if k in a:
             kw[k] = int(a[k])
-    for k in ("beta", "dtau", "r", "c", "u", "txhor", "txver", "tyhor", "tyver", "mu", "mux", "muy", "accRatio"):
+    for k in ("beta", "dtau", "r", "c", "u", "txhor", "txver", "tyhor", "tyver", "mu", "mux", "muy", "accRatio", "cdwU"):
         if k in a:
             kw[k] = float(a[k])
     if "lambda" in a:

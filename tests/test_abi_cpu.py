@@ -65,8 +65,7 @@ def test_fails_loudly_without_gpu_or_with_bad_parameters(lib):
                       (dict(L=4, beta=2.0, m=20), "Only specify one"),
                       (dict(L=4), "either parameter m or beta"),
                       (dict(L=4, beta=2.0, delaySteps=17), "delaySteps"),
-                      (dict(L=4, beta=2.0, bc="weird"), "bc"),
-                      (dict(L=4, beta=2.0, cdwU=0.5), "cdwU")]:
+                      (dict(L=4, beta=2.0, bc="weird"), "bc")]:
         with pytest.raises(DqmcError) as e:
             detqmc_amd.DetSDW(SDWParams(**bad))
         assert e.value.code == -1 and frag in str(e.value), (bad, str(e.value))

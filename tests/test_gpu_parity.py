@@ -23,7 +23,7 @@ def _ctx_from_params(a, **over):
     kw = dict(opdim=op.opdim, L=op.L, m=op.m, s=op.s, dtau=op.dtau, delaySteps=op.delaySteps, bc=op.bc,
               weakZflux=op.weakZflux, r=op.r, c=op.c, u=op.u, lambda_=op.lambda_, txhor=op.txhor,
               txver=op.txver, tyhor=op.tyhor, tyver=op.tyver, mux=op.mux, muy=op.muy, accRatio=op.accRatio,
-              checkerboard=op.checkerboard)
+              checkerboard=op.checkerboard, cdwU=op.cdwU)
     kw.update(over)
     return KernelContext(**kw), op
 
@@ -37,7 +37,7 @@ def _sdw_params(a, **over):
               weakZflux=op.weakZflux, globalShift=op.globalShift, globalUpdateInterval=op.globalUpdateInterval,
               wolffClusterUpdate=op.wolffClusterUpdate, wolffClusterShiftUpdate=op.wolffClusterShiftUpdate,
               repeatWolffPerSweep=op.repeatWolffPerSweep, fermionMeasurements=not op.turnoffFermionMeasurements,
-              rngSeed=op.rngSeed, simindex=op.simindex, checkerboard=op.checkerboard)
+              rngSeed=op.rngSeed, simindex=op.simindex, checkerboard=op.checkerboard, cdwU=op.cdwU)
     kw.update(over)
     return SDWParams(**kw)
 
@@ -310,6 +310,138 @@ def test_replica_trajectory_vs_reference(name):
     nxt = np.array([rep.rand01() for _ in range(4)])
     assert np.array_equal(nxt, g["rng_next"]), "RNG stream position differs from the reference"
     assert info.n_g == g["init_g"].shape[0]
+    rep.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# cdwU != 0: the discrete field l_i(tau) in e^{dtau V} and its own update pass
+# ------------------------------------------------------------------------------------------------
+def _golden_cdwl(g, key):
+    return np.ascontiguousarray(g[key].T).astype(np.int32)          # (N, m+1) -> (m+1, N)
+
+
+@pytest.mark.parametrize("name", ["o2_L4_cdw_slice", "o3_L4_cdw_slice", "o1_L4_cdw", "o2_L4_cdw_dense", "o2_L4_cdw_gshift"])
+def test_cdw_bmult_green_and_one_slice_vs_reference(name):
+    """The reference's B-multiplies, G(beta) and (where the fixture has it) ONE updateInSlice -- phi pass, then the cdwl pass -- at
+    cdwU != 0, through the kernel-level ABI: fields set from the fixture, uniforms from the reference's stream."""
+    from detsdw_oracle import make_test_matrix
+    from dsfmt_oracle import RngWrapper
+    g = load_golden(name)
+    ctx, op = _ctx_from_params(g["params"])
+    assert op.cdwU != 0
+    ctx.set_fields(_golden_phi(g, "init_phi"))
+    l0 = _golden_cdwl(g, "init_cdwl")
+    l0[0] = 1                                                        # slice 0 is unused (0 in the reference's matrix)
+    ctx.set_cdwl(l0)
+    assert np.array_equal(ctx.get_cdwl()[1:], l0[1:])
+    A = make_test_matrix(ctx.ng)
+    if "bmult_left" in g:
+        k = int(g["bmult_k"][0])
+        assert relerr(ctx.leftMultiplyBmat(A, k, k - 1), g["bmult_left"]) < 1e-12
+        assert relerr(ctx.rightMultiplyBmat(A, k, k - 1), g["bmult_right"]) < 1e-12
+        assert relerr(ctx.leftMultiplyBmatInv(A, k, k - 1), g["bmult_leftinv"]) < 1e-12
+        assert relerr(ctx.rightMultiplyBmatInv(A, k, k - 1), g["bmult_rightinv"]) < 1e-12
+        k2 = int(g["bchain_k2"][0])
+        assert relerr(ctx.leftMultiplyBmat(A, k2, 0), g["bchain_left"]) < 1e-12
+        assert relerr(ctx.rightMultiplyBmatInv(A, k2, 0), g["bchain_rightinv"]) < 1e-12
+    ctx.setupUdVStorage_and_calculateGreen()
+    assert relerr(ctx.g, g["init_g"]) < TOL
+    assert relerr(ctx.g_inv_sv, g["init_g_inv_sv"]) < TOL
+    if "slice_cdwl_m" in g:
+        r = RngWrapper(op.rngSeed, op.simindex + 1)
+        for _ in range((op.opdim + 1) * op.N * op.m):
+            r.rand01()
+        ctx.push_uniforms(np.array([r.rand01() for _ in range((op.opdim + 3) * op.N)]))
+        ctx.updateInSlice(op.m, thermalization=True)
+        st = ctx.update_state()
+        assert np.array_equal(ctx.get_fields()[0][op.m], g["slice_phi_m"]), "phi pass: accept/reject decisions differ from the reference"
+        assert np.array_equal(ctx.get_cdwl()[op.m], g["slice_cdwl_m"].reshape(-1).astype(np.int32)), "cdwl pass differs from the reference"
+        assert relerr(ctx.g, g["slice_g"]) < TOL
+        assert abs(st.lastAccRatio - g["slice_accRatio"][0]) < 1e-15, "the cdwl pass must not touch the phi acceptance ratio"
+        assert st.ra_samplesAdded == 1
+        ctx.wrapDownGreen(op.m)
+        assert relerr(ctx.g, g["slice_g_wrapped"]) < TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["o2_L4_cdw", "o1_L4_cdw", "o2_L4_cdw_gshift", "o2_L4_cdw_dense"])
+def test_cdw_replica_trajectory_vs_reference(name):
+    """Whole sweeps at cdwU != 0 through the host layer: phi, the discrete field, G and the RNG position after every sweep are the
+    reference's (seeds: oracle/find_cdw_seeds.py -- the reference's last-bit branch at null cdwl proposals)."""
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    rep = DetSDW(_sdw_params(g["params"]))
+    assert np.array_equal(rep.phi[1:], _golden_phi(g, "init_phi")[1:])
+    assert np.array_equal(rep.cdwl[1:], _golden_cdwl(g, "init_cdwl")[1:])
+    assert relerr(rep.g, g["init_g"]) < TOL
+    i = 1
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}: phi trajectory diverged"
+        assert np.array_equal(rep.cdwl[1:], _golden_cdwl(g, f"sweep{i}_cdwl")[1:]), f"sweep {i}: cdwl trajectory diverged"
+        assert relerr(rep.g, g[f"sweep{i}_g"]) < TOL, f"sweep {i}"
+        inf = rep.info
+        assert inf.phiDelta == g[f"sweep{i}_phiDelta"][0]
+        assert abs(inf.lastAccRatioLocal_phi - g[f"sweep{i}_lastAccRatio"][0]) < 1e-15
+        assert inf.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert inf.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+        i += 1
+    assert i > 1
+    assert np.array_equal(np.array([rep.rand01() for _ in range(4)]), g["rng_next"]), "RNG stream position differs from the reference"
+    rep.close()
+
+
+@pytest.mark.parametrize("opdim,L,D", [(3, 4, 6), (2, 6, 8), (3, 6, 12)])
+def test_cdw_trajectory_vs_oracle(opdim, L, D):
+    """Sizes and O(3) trajectories the reference cannot pin (its null-proposal branch is a coin flip there): the HIP path against the
+    oracle, same seed => same chain, two sweeps, in a batch of two replicas with different r."""
+    from detsdw_oracle import DetSDWOracle, SDWParams as OP
+    from detqmc_amd import DetSDWBatch, SDWParams
+    common = dict(opdim=opdim, L=L, beta=1.2, s=5, delaySteps=D, cdwU=0.6, rngSeed=4711)
+    ps = [SDWParams(**common, r=-1.0, simindex=0), SDWParams(**common, r=-0.4, simindex=1)]
+    batch = DetSDWBatch(ps)
+    os_ = [DetSDWOracle(OP(**common, r=-1.0, simindex=0)), DetSDWOracle(OP(**common, r=-0.4, simindex=1))]
+    for sweep in range(2):
+        batch.sweepThermalization()
+        for b, o in enumerate(os_):
+            o.sweepThermalization()
+            rep = batch.chain(b)
+            assert np.array_equal(rep.phi[1:], o.phi[1:]), (sweep, b)
+            assert np.array_equal(rep.cdwl[1:], o.cdwl[1:]), (sweep, b)
+            assert relerr(rep.g, o.g) < TOL
+    for b, o in enumerate(os_):
+        assert np.array_equal(np.array([batch.chain(b).rand01() for _ in range(3)]), np.array([o.rng.rand01() for _ in range(3)]))
+    batch.close()
+
+
+def test_cdw_checkpoint_and_config_stream(tmp_path):
+    """The discrete field travels with the checkpoint (saved after an even number of sweeps, like the phi-only test further down) and
+    is written as configs-l.binarystream next to configs-phi.binarystream (detsdwopdim.cpp:5015-5037)."""
+    from detqmc_amd import DetSDW
+    g = load_golden("o2_L4_cdw")
+    rep = DetSDW(_sdw_params(g["params"]))
+    for _ in range(2):
+        rep.sweepThermalization()
+    path = str(tmp_path / "state.bin")
+    rep.save_state(path)
+    rep.saveConfigurationStreamBinary(str(tmp_path))
+    l1 = rep.cdwl
+    assert np.array_equal(l1[1:], _golden_cdwl(g, "sweep2_cdwl")[1:])
+    raw = np.fromfile(str(tmp_path / "configs-l.binarystream"), dtype=np.int32)
+    info = rep.info
+    Lx = info.L
+    want = np.array([l1[k, iy * Lx + ix] for ix in range(Lx) for iy in range(Lx) for k in range(1, info.m + 1)], dtype=np.int32)
+    assert np.array_equal(raw, want)
+    for _ in range(2):
+        rep.sweepThermalization()
+    phi2, l2, drawn = rep.phi, rep.cdwl, rep.info.rngDrawn
+    rep.close()
+    rep = DetSDW(_sdw_params(g["params"]))
+    rep.load_state(path)
+    assert np.array_equal(rep.cdwl[1:], l1[1:])
+    for _ in range(2):
+        rep.sweepThermalization()
+    assert np.array_equal(rep.phi[1:], phi2[1:]) and np.array_equal(rep.cdwl[1:], l2[1:]) and rep.info.rngDrawn == drawn
     rep.close()
 
 

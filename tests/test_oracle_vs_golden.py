@@ -10,7 +10,8 @@ from dsfmt_oracle import RngWrapper
 TOL = 1e-10   # BASELINE.json north_star: 1e-10 relative for fp64
 
 SMALL = ["o2_L4", "o2_L4_s7", "o2_L4_flux", "o2_L4_apbc", "o1_L4", "o3_L4", "o2_L6_seed",
-         "o2_L4_dense", "o2_L4_dense_flux"]      # *_dense: checkerboard=false (CB_NONE)
+         "o2_L4_dense", "o2_L4_dense_flux",      # *_dense: checkerboard=false (CB_NONE)
+         "o2_L4_cdw_slice", "o3_L4_cdw_slice"]   # cdwU != 0: the discrete field l_i(tau) and its second update pass (one slice)
 
 
 def test_rng_bit_exact():
@@ -34,6 +35,8 @@ def test_init_field_and_green(case):
     # phi fixture is (N, OPDIM, m+1) col-major -> ours (m+1, N, OPDIM)
     phi_ref = np.transpose(g["init_phi"], (2, 0, 1))
     assert np.array_equal(o.phi[1:], phi_ref[1:]), "random field must be bit-identical (same RNG stream)"
+    if "init_cdwl" in g:
+        assert np.array_equal(o.cdwl[1:], g["init_cdwl"].T[1:])
     if "init_coshTermPhi" in g:
         assert relerr(o.coshTermPhi[1:], g["init_coshTermPhi"].T[1:]) < 1e-14
         assert relerr(o.sinhTermPhi[1:], g["init_sinhTermPhi"].T[1:]) < 1e-14
@@ -69,11 +72,15 @@ def test_slice_and_sweeps(case):
     m, n, s = o.m, o.n, o.s
     o.updateInSliceThermalization(m)
     assert np.array_equal(o.phi[m], g["slice_phi_m"]), "accept/reject decisions must agree"
+    if "slice_cdwl_m" in g:
+        assert np.array_equal(o.cdwl[m], g["slice_cdwl_m"].reshape(-1)), "accept/reject decisions of the cdwl pass must agree"
     assert relerr(o.g, g["slice_g"]) < TOL
     assert abs(o.lastAccRatioLocal_phi - g["slice_accRatio"][0]) < 1e-15
     o.wrapDownGreen(m)
     if "slice_g_wrapped" in g:
         assert relerr(o.g, g["slice_g_wrapped"]) < TOL
+    if "adv_g" not in g:          # sliceTrace=2 fixtures end here
+        return
     for k in range(m - 1, (n - 1) * s, -1):
         o.updateInSliceThermalization(k)
         o.wrapDownGreen(k)
@@ -94,6 +101,8 @@ def test_slice_and_sweeps(case):
             o.sweepThermalization()
         phi_ref = np.transpose(g[f"sweep{i}_phi"], (2, 0, 1))
         assert np.array_equal(o.phi[1:], phi_ref[1:]), f"sweep {i}: field trajectory diverged"
+        if f"sweep{i}_cdwl" in g:
+            assert np.array_equal(o.cdwl[1:], g[f"sweep{i}_cdwl"].T[1:]), f"sweep {i}: cdwl trajectory diverged"
         assert relerr(o.g, g[f"sweep{i}_g"]) < TOL
         assert relerr(o.g_inv_sv, g[f"sweep{i}_g_inv_sv"]) < TOL
         assert o.phiDelta == g[f"sweep{i}_phiDelta"][0]
@@ -102,6 +111,27 @@ def test_slice_and_sweeps(case):
     assert abs(o.get_exchange_action_contribution() - g["exchange_action"][0]) < 1e-12 * abs(g["exchange_action"][0])
     nxt = np.array([o.rng.rand01() for _ in range(4)])
     assert np.array_equal(nxt, g["rng_next"]), "number of RNG draws consumed differs from the reference"
+
+
+@pytest.mark.parametrize("name", ["o2_L4_cdw", "o1_L4_cdw", "o2_L4_cdw_gshift", "o2_L4_cdw_dense"])
+def test_cdw_trajectory(name):
+    """cdwU != 0 over whole sweeps (with global shift moves, a flux, the dense propagator): phi, the discrete field, G and the number
+    of uniforms consumed.  Seeds: oracle/find_cdw_seeds.py (the reference's last-bit branch at null cdwl proposals)."""
+    g = load_golden(name)
+    o = DetSDWOracle(oracle_params(g["params"]))
+    assert np.array_equal(o.cdwl[1:], g["init_cdwl"].T[1:])
+    assert relerr(o.g, g["init_g"]) < TOL
+    i = 1
+    while f"sweep{i}_phi" in g:
+        o.sweepThermalization()
+        assert np.array_equal(o.phi[1:], np.transpose(g[f"sweep{i}_phi"], (2, 0, 1))[1:]), f"sweep {i}"
+        assert np.array_equal(o.cdwl[1:], g[f"sweep{i}_cdwl"].T[1:]), f"sweep {i}"
+        assert relerr(o.g, g[f"sweep{i}_g"]) < TOL
+        assert o.attemptedGlobalShifts == int(g[f"sweep{i}_attGlobalShifts"][0])
+        assert o.acceptedGlobalShifts == int(g[f"sweep{i}_accGlobalShifts"][0])
+        i += 1
+    assert i > 1
+    assert np.array_equal(np.array([o.rng.rand01() for _ in range(4)]), g["rng_next"])
 
 
 def test_global_shift_trajectory():
