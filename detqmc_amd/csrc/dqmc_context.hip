@@ -68,6 +68,7 @@ struct dqmc_ctx {
     QrWork qw{};
     int* qr_perm = nullptr;
     int* lu_swaps = nullptr;
+    cplx* lu_tneg = nullptr;       // -U12^T of the current LU panel (n_g x 32), operand of the trailing update on k_flush
     uint64_t lu_calls = 0;         // gather lists of the LU panels (kernels_lu.hip)
     int* qr_perm_inv = nullptr;      // inverse of qr_perm and 1/d of the last lazy UDT (triangular chaining product)
     double* qr_dinv = nullptr;
@@ -617,7 +618,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
         A_(dalloc(c, &c->qw.V, n2)); A_(dalloc(c, &c->qw.T, (size_t)np * 2 * 256));
         A_(dalloc(c, &c->qw.W, (size_t)16 * ng)); A_(dalloc(c, &c->qw.W2, (size_t)16 * ng)); A_(dalloc(c, &c->qw.Rneg, (size_t)32 * ng));
         if (ng > 1024) { c->qw.part_count = (size_t)ng * 64 * 8; A_(dalloc(c, &c->qw.part, c->qw.part_count)); }   // split-K scratch of the block Gram-Schmidt QR
-        A_(dalloc(c, &c->qr_perm, (size_t)ng)); A_(dalloc(c, &c->lu_swaps, (size_t)LU_SWAP_INTS)); A_(dalloc(c, &c->qr_perm_inv, (size_t)ng)); A_(dalloc(c, &c->qr_dinv, (size_t)ng));
+        A_(dalloc(c, &c->qr_perm, (size_t)ng)); A_(dalloc(c, &c->lu_swaps, (size_t)LU_SWAP_INTS)); A_(dalloc(c, &c->lu_tneg, (size_t)ng * 32)); A_(dalloc(c, &c->qr_perm_inv, (size_t)ng)); A_(dalloc(c, &c->qr_dinv, (size_t)ng));
         A_(dalloc(c, &c->rmax_inv, (size_t)ng)); A_(dalloc(c, &c->rmin, (size_t)ng));
         A_(dalloc(c, &c->lmax_inv, (size_t)ng)); A_(dalloc(c, &c->lmin, (size_t)ng));
     }
@@ -913,7 +914,7 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
     if (n <= 512 && !force_qr) {
         {
             ProfScope ps(c, FAM_JACOBI, 0);
-            int launches = run_lu(c->lc, n, c->T2, c->qr_perm, c->lu_swaps);                  // T2 = L \ U, qr_perm = row permutation
+            int launches = run_lu(c->lc, n, c->T2, c->qr_perm, c->lu_swaps, c->lu_tneg);                  // T2 = L \ U, qr_perm = row permutation
             launch_permute_scale_cols(c->lc, L.Vt, c->lmax_inv, nullptr, n, c->T3);
             launches += run_trsm_right_upper(c->lc, n, c->T2, c->T3, c->qw);                  // T3 = (V_l Dlmax^-1) U^-1
             launch_logdet_vector(c->lc, c->T2, c->rmax_inv, c->lmax_inv, n, c->sv);           // |det Z| = prod |U_kk|

@@ -142,7 +142,7 @@ void launch_gemm(const Launch& lc, const GemmArgs& a);
 // G += X GrT^T, K = min(Kmax, *Kdev * Kmul): the delayed-update flush as a register-only read-modify-write stream.  X and GrT are
 // n x K8 (K8 = K rounded up to a multiple of 8, columns K .. K8 - 1 zero), both with leading dimension ld
 void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx* G, int ldc, int n, int Kmax,
-                  const int* Kdev, int Kmul);
+                  const int* Kdev, int Kmul, int tag = 0);    // G (n x n) += X GrT^T, K = min(Kmax, *Kdev * Kmul) (Kdev may be null); tag 1: own kernel name
 
 // one-sided Jacobi SVD, M = U diag(d) V^H, d descending.  work: A (n*n), V (n*n), norms(n), rank(n),
 // flag (int).  Host-driven sweep loop with one flag read-back per sweep.  Returns sweeps used or <0.
@@ -210,7 +210,7 @@ bool qr_use_bgs(int n);
 int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);
 int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w, int trans = 0, int unit = 0);   // C <- C R^-1 (trans: R = (stored lower triangle)^H; unit: unit diagonal)
 #define LU_SWAP_INTS 128
-int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps);                                 // P A = L U in place (n <= 512, else -1), kernels_lu.hip
+int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps, cplx* tneg);    // tneg: scratch of n * 32 complex per chain                                 // P A = L U in place (n <= 512, else -1), kernels_lu.hip
 void launch_gather_scale_cols(const Launch& lc, const cplx* X, const double* cs, const int* perm, int n, cplx* Y);   // Y[:, j] = X[:, perm[j]] cs[perm[j]]
 void launch_udt_init(const Launch& lc, const cplx* M, int ldm, const double* cs, const double* rs, const int* perm,
                      int transpose, cplx* W, int n);

@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void k_zgemm(GemmArgs g, size_t cs, int nb)
 // were waited for at once, and the only overlap of memory and matrix cores came from the other resident waves.
 // ---------------------------------------------------------------------------------------------
 // FULL: n is a multiple of 32 -- every wave's 32 x 32 tile lies inside G or outside of it, no clamps or guards
-template<bool M3, bool FULL, int STAGE>
+// TAG only gives the launches of the LU factorisation (trailing updates, K = 32) their own kernel name in profiles
+template<bool M3, bool FULL, int STAGE, int TAG>
 __global__ __launch_bounds__(256, (FULL && STAGE == 1) ? 3 : 2) void k_flush(const cplx* __restrict__ X, const cplx* __restrict__ GrT, int ld,
                                                   cplx* __restrict__ G, int ldc, int n, int Kmax, const int* __restrict__ Kdev,
                                                   int Kmul, size_t cs, int nb) {
@@ -406,13 +407,14 @@ static bool use_4m() {
 }
 
 void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx* G, int ldc, int n, int Kmax,
-                  const int* Kdev, int Kmul) {
+                  const int* Kdev, int Kmul, int tag) {
     const int tn = (n + 63) / 64;
     const dim3 grid = (lc.nb % 8 == 0) ? dim3(tn * tn * lc.nb, 1, 1) : dim3(tn * tn, 1, lc.nb);
     static const bool force_ragged = getenv("DQMC_FLUSH_RAGGED") && atoi(getenv("DQMC_FLUSH_RAGGED")) != 0;   // developer knob (A/B)
     const bool full = n % 32 == 0 && !force_ragged;
     static const int stage = getenv("DQMC_FLUSH_STAGE") ? atoi(getenv("DQMC_FLUSH_STAGE")) : 1;                 // developer knob (A/B)
-#define FLUSH_LAUNCH(M3_, FULL_, ST_) hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb)
+#define FLUSH_LAUNCH(M3_, FULL_, ST_) do { if (tag) hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_, 1>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb); \
+                                           else hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_, 0>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb); } while (0)
     if (use_4m()) { if (full) FLUSH_LAUNCH(false, true, 1); else FLUSH_LAUNCH(false, false, 1); }
     else if (stage == 2) { if (full) FLUSH_LAUNCH(true, true, 2);  else FLUSH_LAUNCH(true, false, 2); }
     else          { if (full) FLUSH_LAUNCH(true, true, 1);  else FLUSH_LAUNCH(true, false, 1); }

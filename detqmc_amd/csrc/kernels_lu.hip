@@ -181,11 +181,13 @@ __device__ __forceinline__ cplx lu_shfl32(cplx v, int src) {
 
 // Every column outside the panel [j0, j0 + nbw): apply the panel's row interchanges; columns right of the panel also get
 // U12 = L11^-1 A12 (unit lower block of the panel).  32 lanes per column, 8 columns per workgroup.
+// Tneg (n x LU_NB, ld = lda): -U12^T, the second operand panel of the trailing update in the layout k_flush reads (both operand panels
+// n x K with contiguous columns): Tneg[k * lda + c] = -U12[k, c], c counted from the first column right of the panel.
 __global__ __launch_bounds__(256) void k_lu_rowswap_trsm(cplx* __restrict__ A, int lda, int n, int j0, int nbw,
-                                                          const int* __restrict__ swaps, size_t cs) {
+                                                          const int* __restrict__ swaps, cplx* __restrict__ Tneg, size_t cs) {
     __shared__ cplx sL[LU_NB][LU_NB + 1];
     __shared__ int sS[LU_SWAP_INTS];
-    CHAIN(A); CHAIN(swaps);
+    CHAIN(A); CHAIN(swaps); CHAIN(Tneg);
     for (int i = threadIdx.x; i < LU_SWAP_INTS; i += 256) sS[i] = swaps[i];
     for (int i = threadIdx.x; i < LU_NB * LU_NB; i += 256) {
         const int r = i % LU_NB, c = i / LU_NB;
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(256) void k_lu_rowswap_trsm(cplx* __restrict__ A, i
         }
     }
     if (live) {
+        if (r < nbw && col >= j0 + nbw) Tneg[(size_t)r * lda + (col - (j0 + nbw))] = make_double2(-ntop.x, -ntop.y);
         if (r < nbw) Ac[j0 + r] = ntop;
         if (r < ndisp) Ac[drow] = next;
     }
@@ -246,7 +249,7 @@ void launch_gather_scale_cols(const Launch& lc, const cplx* X, const double* cs,
 
 // A (n x n, ld n, n <= 512) -> L \ U in place; perm[i] = the row of the input that row i of L U is (P A = L U); swaps: workspace
 // of LU_SWAP_INTS ints per chain.  Returns the number of launches, or -1 when n is outside what the panel kernel holds.
-int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps) {
+int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps, cplx* tneg) {
     if (n > 512) return -1;
     int launches = 0;
     for (int j0 = 0; j0 < n; j0 += LU_NB) {
@@ -257,11 +260,19 @@ int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps) {
         else                  hipLaunchKernelGGL((k_lu_panel<512>), dim3(1, 1, lc.nb), dim3(512), 0, lc.st, A, n, n, j0, perm, swaps, lc.cs);
         ++launches;
         if (n - nbw > 0) {
-            hipLaunchKernelGGL(k_lu_rowswap_trsm, dim3((n - nbw + 7) / 8, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, nbw, swaps, lc.cs);
+            hipLaunchKernelGGL(k_lu_rowswap_trsm, dim3((n - nbw + 7) / 8, 1, lc.nb), dim3(256), 0, lc.st, A, n, n, j0, nbw, swaps, tneg, lc.cs);
             ++launches;
         }
         const int rest = n - j0 - nbw;
-        if (rest > 0) {
+        // Trailing update A22 -= L21 U12, K = 32: a read-modify-write stream over A22 with a thin product riding on it -- the shape of
+        // the delayed-update flush, so it runs on k_flush (operand fragments straight from global memory, tile read late, three
+        // workgroups per CU) instead of the LDS-staged k_zgemm, whose pipeline never fills at K = 32 (round 3: these launches moved
+        // 2.0 TB/s, profiles/r03_pmc_traffic_b128_d32.json "gemm_in_factorisation"; DQMC_LU_GEMM=1 keeps the old route)
+        static const bool lu_gemm = getenv("DQMC_LU_GEMM") && atoi(getenv("DQMC_LU_GEMM")) != 0;
+        if (rest > 0 && nbw == LU_NB && !lu_gemm) {
+            launch_flush(lc, A + (size_t)j0 * n + (j0 + nbw), tneg, n, A + (size_t)(j0 + nbw) * n + (j0 + nbw), n, rest, nbw, nullptr, 1, /*tag=*/1);
+            ++launches;
+        } else if (rest > 0) {
             GemmArgs g = GemmArgs();
             g.A = A + (size_t)j0 * n + (j0 + nbw); g.lda = n; g.opA = 0;                 // L21
             g.B = A + (size_t)(j0 + nbw) * n + j0; g.ldb = n; g.opB = 0;                 // U12

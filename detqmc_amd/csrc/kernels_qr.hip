@@ -434,8 +434,16 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
     // once per GROUP of panels.
     const int wi = tid & 15, wj = tid >> 4;
     for (int rf = 0; rf < refs.n; ++rf) {
-        const cplx* Vp = chain_ptr_i(refs.V[rf], cs, chain);
-        const cplx* Tn = chain_ptr_i(refs.Tn[rf], cs, chain);
+        // refs.V[rf] is a pointer picked from a by-value struct with a run-time index: the compiler cannot prove its address space and
+        // every load through it became flat_load (48 in the NCH = 8 instantiation; flat loads count on vmcnt AND lgkmcnt, so they
+        // also serialise with the LDS traffic of the reductions) -- say that it is global memory
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const cplx __attribute__((address_space(1)))* gcplx;
+#else
+        typedef const cplx* gcplx;             // host pass: the body is only parsed
+#endif
+        gcplx Vp = (gcplx)chain_ptr_i(refs.V[rf], cs, chain);
+        gcplx Tn = (gcplx)chain_ptr_i(refs.Tn[rf], cs, chain);
         const int nb = refs.nb[rf];
         // per-iteration copies of the bounds the compiler cannot see through: otherwise the 32 clamped row indices and
         // 32 lane masks of the passes are hoisted out of this loop and kept alive across it (spills at NCH = 8)
@@ -447,22 +455,29 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
             sT[wi][wj] = (wi < nb && wj < nb) ? t : make_double2(0.0, 0.0);
         }
         const bool vok = l15 < nb;
-        const cplx* Vcol = Vp + (size_t)(vok ? l15 : 0) * ldv;
+        gcplx Vcol = Vp + (size_t)(vok ? l15 : 0) * ldv;
         // ---- pass 1: W = V^H C over this wave's slab; V in chunks of CH elements, the next chunk's loads in flight while
         //      the matrix cores work on the current one (explicit double buffer: left alone the compiler keeps ONE
         //      register quad for v and waits for every load right after issuing it) ----
         // 3M complex products (kernels_gemm.hip): A = conj(v) = (v.x, -v.y), B = x:  w_re = P1 = v.x x.x,  w_p2 = P2 = -v.y x.y,
         // w_im = P3 = (v.x - v.y)(x.x + x.y);  W = (P1 - P2, P3 - P1 - P2)
         q_v4d w_re = (q_v4d)(0.0), w_im = (q_v4d)(0.0), w_p2 = (q_v4d)(0.0);
-        constexpr int CH = (NE < 8) ? 4 : 8;
+        constexpr int CH = 4;                      // 8 with unmasked loads spills at NCH = 8 (creg alone is 128 registers)
         cplx va[CH], vb[CH];
-        auto loadv = [&](const cplx* base, int e0, cplx (&dst)[CH]) {
+        // (the row index of an element is re-derived from an opaque copy of slab + l4 at every use: left to itself the compiler keeps
+        //  all 32 of them in registers across both passes -- with the 128 registers of creg that is what spilled at NCH = 8)
+        auto loadv = [&](gcplx base, int e0, cplx (&dst)[CH]) {
+            int rb = slab + l4;
+            asm volatile("" : "+v"(rb));
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 if (e0 + i >= NE) continue;                                                   // NE need not be a multiple of CH
-                const int row = slab + 4 * (e0 + i) + l4;
-                const cplx t = base[min(row, rl)];
-                dst[i] = (vok && row < rw) ? t : make_double2(0.0, 0.0);                      // A(m = i, k) = conj(v)
+                const int row = rb + 4 * (e0 + i);
+                // NO mask on the value: rows beyond the matrix meet creg = 0 (kept zero below), reflector columns >= nb give rows of
+                // W that the zero-padded T annihilates -- the address is clamped, so what is loaded is finite.  A select here
+                // (`ok ? load : 0`) compiles to a branch around the load and an s_waitcnt vmcnt(0) behind it: 68 of them in the
+                // NCH = 8 instantiation, one per fragment -- the double buffer never had two loads in flight (round 3, ISA).
+                dst[i] = base[min(row, rl)];                                                  // A(m = i, k) = conj(v)
             }
         };
         auto mac = [&](int e0, const cplx (&src)[CH]) {
@@ -476,15 +491,17 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
                 w_im = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x - v.y, x.x + x.y, w_im, 0, 0, 0);
             }
         };
-        const cplx* vbase = Vcol;
+        gcplx vbase = Vcol;
         loadv(vbase, 0, va);
         if (CH < NE) loadv(vbase, CH, vb);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < NE; c += 2 * CH) {
             mac(c, va);
-            if (c + 2 * CH < NE) { QR_TIE(w_re, vbase); loadv(vbase, c + 2 * CH, va); }
-            if (c + CH < NE) mac(c + CH, vb);
-            if (c + 3 * CH < NE) { QR_TIE(w_re, vbase); loadv(vbase, c + 3 * CH, vb); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 * CH < NE) { QR_TIE(w_re, vbase); loadv(vbase, c + 2 * CH, va); __builtin_amdgcn_sched_barrier(0); }
+            if (c + CH < NE) { mac(c + CH, vb); __builtin_amdgcn_sched_barrier(0); }
+            if (c + 3 * CH < NE) { QR_TIE(w_re, vbase); loadv(vbase, c + 3 * CH, vb); __builtin_amdgcn_sched_barrier(0); }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) sPart[wave][l4 + 4 * r][l15] = make_double2(w_re[r] - w_p2[r], (w_im[r] - w_re[r]) - w_p2[r]);   // D[m = l4 + 4r][n = l15]
@@ -513,14 +530,13 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) w2[ks] = sW[ks * 4 + l4][l15];           // B(k, n = column)
         cplx vfa[4], vfb[4];
-        auto loadvf = [&](const cplx* base, int t, cplx (&dst)[4]) {
+        auto loadvf = [&](gcplx base, int t, cplx (&dst)[4]) {
             const int vrow = slab + 16 * t + l15;                                // A(m = row, k)
             const int vr = min(vrow, rl);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int k = ks * 4 + l4;
-                const cplx tv = base[(size_t)min(k, nb - 1) * ldv + vr];
-                dst[ks] = (vrow < rw && k < nb) ? tv : make_double2(0.0, 0.0);
+                dst[ks] = base[(size_t)min(k, nb - 1) * ldv + vr];       // unmasked: W2 rows >= nb are zero, rows beyond the matrix are re-zeroed in put()
             }
         };
         double w2s[4];
@@ -537,23 +553,29 @@ __global__ __launch_bounds__(256, 2) void k_qr_apply_reg(QrRefs refs, int ldv, c
             }
         };
         auto put = [&](int t) {
+            int rb = slab + l4;
+            asm volatile("" : "+v"(rb));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                                                    // D[m = l4 + 4r][n = l15]
-                creg[4 * t + r].x += d_re[r] - d_p2[r];
-                creg[4 * t + r].y += (d_im[r] - d_re[r]) - d_p2[r];
+                const bool rin = rb + 16 * t + 4 * r < rw;                           // rows beyond the matrix stay ZERO in creg (pass 1 of the next reflector relies on it)
+                creg[4 * t + r].x = rin ? creg[4 * t + r].x + (d_re[r] - d_p2[r]) : 0.0;
+                creg[4 * t + r].y = rin ? creg[4 * t + r].y + ((d_im[r] - d_re[r]) - d_p2[r]) : 0.0;
             }
         };
-        const cplx* pbase = Vp;
+        gcplx pbase = Vp;
         loadvf(pbase, 0, vfa);
         if (NCH > 1) loadvf(pbase, 1, vfb);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NCH; t += 2) {
             upd(t, vfa);
-            if (t + 2 < NCH) { QR_TIE(d_re, pbase); loadvf(pbase, t + 2, vfa); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < NCH) { QR_TIE(d_re, pbase); loadvf(pbase, t + 2, vfa); __builtin_amdgcn_sched_barrier(0); }
             put(t);
             if (t + 1 < NCH) {
                 upd(t + 1, vfb);
-                if (t + 3 < NCH) { QR_TIE(d_re, pbase); loadvf(pbase, t + 3, vfb); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 3 < NCH) { QR_TIE(d_re, pbase); loadvf(pbase, t + 3, vfb); __builtin_amdgcn_sched_barrier(0); }
                 put(t + 1);
             }
         }

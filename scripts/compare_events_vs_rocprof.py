@@ -18,7 +18,7 @@ def stat(*keys):
     return calls, (tot / calls / 1e3 if calls else 0.0)
 
 
-names = {"flush": ("k_flush",), "gemm": ("k_zgemm<2, 2, true, 0", "k_zgemm<2, 2, false, 0", "k_zgemm<1, 1, true, 0", "k_zgemm<1, 1, false, 0"),
+names = {"flush": ("k_flush<true, true, 1, 0", "k_flush<true, false, 1, 0", "k_flush<false"), "gemm": ("k_zgemm<2, 2, true, 0", "k_zgemm<2, 2, false, 0", "k_zgemm<1, 1, true, 0", "k_zgemm<1, 1, false, 0"),
          "bmult": ("k_bmult_chain",), "qr_apply": ("k_qr_apply",), "gather": ("k_update_gather",), "decide": ("k_update_decide",)}
 print("%-10s %22s %26s" % ("family", "HIP events (JSON line)", "rocprofv3 --stats (all launches)"))
 for e in [d["roofline"]] + d["roofline_other_kernels"]:
