@@ -917,24 +917,45 @@ __global__ __launch_bounds__(256, 2) void k_update_gather(DevModel dm, const Dev
     u_v4d acc_re[2], acc_im[2], acc_p2[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) { acc_re[a] = (u_v4d)(0.0); acc_im[a] = (u_v4d)(0.0); acc_p2[a] = (u_v4d)(0.0); }
-    for (int k0 = 0; k0 < nI; k0 += 4) {
+    // Operands of one k-step.  Only W carries a mask (k >= nI or a padding column: the product must be zero there); G is read at
+    // clamped, always valid addresses and needs none -- a zero W entry annihilates whatever finite value sits there, rows past n_g
+    // are never stored.  The mask is an AND on the bit pattern: a select on a loaded value compiles to a branch around the load
+    // and a wait behind it.  Two operand sets in flight (ping-pong, written out twice: see k_flush).
+    const unsigned long long colmask = (c0 + l15 < nI) ? ~0ull : 0ull;
+    const cplx* wcol = Wg + (size_t)min(c0 + l15, nI - 1) * WD;
+    const int ra = min(r0 + l15, ng - 1), rb = min(r0 + 16 + l15, ng - 1);
+    auto ldk = [&](int k0, cplx& w, cplx (&g)[2]) {
         const int gk = k0 + l4;
-        const bool kok = gk < nI;
-        // first MFMA operand (m = column of X, k): W[k][c0 + l15];  second (k, n = row): G[r0 + a 16 + l15, I_k]
         const int gkc = min(gk, nI - 1);
-        const cplx wl = Wg[(size_t)min(c0 + l15, nI - 1) * WD + gkc];          // clamped address + select: no branch, no wait per load
-        const cplx w = (kok && c0 + l15 < nI) ? wl : make_double2(0.0, 0.0);
-        const size_t col = (size_t)sI[gkc] * ng;
-        cplx gl[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) gl[a] = G[col + min(r0 + a * 16 + l15, ng - 1)];
+        const unsigned long long m = (gk < nI) ? colmask : 0ull;
+        const cplx wl = wcol[gkc];
+        w = make_double2(__longlong_as_double(__double_as_longlong(wl.x) & m), __longlong_as_double(__double_as_longlong(wl.y) & m));
+        const cplx* gc = G + (size_t)sI[gkc] * ng;
+        g[0] = gc[ra]; g[1] = gc[rb];
+    };
+    auto mack = [&](const cplx& w, const cplx (&g)[2]) {
+        const double ws = w.x + w.y;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const int r = r0 + a * 16 + l15;
-            const cplx g = (kok && r < ng) ? gl[a] : make_double2(0.0, 0.0);
-            acc_re[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, g.x, acc_re[a], 0, 0, 0);
-            acc_p2[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, g.y, acc_p2[a], 0, 0, 0);
-            acc_im[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x + w.y, g.x + g.y, acc_im[a], 0, 0, 0);
+            acc_re[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, g[a].x, acc_re[a], 0, 0, 0);
+            acc_p2[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, g[a].y, acc_p2[a], 0, 0, 0);
+            acc_im[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(ws, g[a].x + g[a].y, acc_im[a], 0, 0, 0);
+        }
+    };
+    {
+        cplx wA, wB, gA[2], gB[2];
+        ldk(0, wA, gA);
+        ldk(4, wB, gB);                                   // k >= nI: masked to zero
+        __builtin_amdgcn_sched_barrier(0);
+        for (int k0 = 0; k0 < nI; k0 += 8) {
+            mack(wA, gA);
+            __builtin_amdgcn_sched_barrier(0);
+            ldk(k0 + 8, wA, gA);
+            __builtin_amdgcn_sched_barrier(0);
+            mack(wB, gB);
+            __builtin_amdgcn_sched_barrier(0);
+            ldk(k0 + 12, wB, gB);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
