@@ -785,14 +785,20 @@ __global__ __launch_bounds__(256) void k_trsm_block(cplx* __restrict__ C, int ld
             else if (trans) { const cplx t = R[(size_t)(j0 + r) * ldr + (j0 + c)]; v = make_double2(t.x, -t.y); }
             else v = R[(size_t)(j0 + c) * ldr + (j0 + r)];
         }
+        if (r == c && r < nb) {                 // the diagonal is stored as its reciprocal: one complex multiply per column and row instead of two divisions
+            const double dn = v.x * v.x + v.y * v.y;
+            v = make_double2(v.x / dn, -v.y / dn);
+        }
         sR[r][c] = v;
     }
     __syncthreads();
     int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= n) return;
     cplx y[TRSM_NB];
+    // all 32 loads go out together: clamped column instead of a select on the loaded value (which compiles to a branch around the
+    // load and a wait behind it: 66 s_waitcnt vmcnt(0) for 34 loads before); columns >= nb are loaded but never used
 #pragma unroll
-    for (int c = 0; c < TRSM_NB; ++c) y[c] = (c < nb) ? C[(size_t)(j0 + c) * ldc + row] : make_double2(0.0, 0.0);
+    for (int c = 0; c < TRSM_NB; ++c) y[c] = C[(size_t)(j0 + min(c, nb - 1)) * ldc + row];
 #pragma unroll
     for (int c = 0; c < TRSM_NB; ++c) {
         if (c < nb) {
@@ -804,9 +810,7 @@ __global__ __launch_bounds__(256) void k_trsm_block(cplx* __restrict__ C, int ld
                     acc.x -= t.x; acc.y -= t.y;
                 }
             }
-            cplx d = sR[c][c];
-            double dn = d.x * d.x + d.y * d.y;
-            y[c] = make_double2((acc.x * d.x + acc.y * d.y) / dn, (acc.y * d.x - acc.x * d.y) / dn);
+            y[c] = q_cmul(acc, sR[c][c]);
         }
     }
 #pragma unroll
