@@ -59,7 +59,7 @@ __device__ __forceinline__ void build_V(cplx (&V)[MSF][MSF], double sign, double
 }
 
 template<int MSF, bool RIGHT, bool INV>
-__global__ __launch_bounds__(512) void k_bmult_chain(DevModel dm, cplx* __restrict__ A, int lda, int nvec,
+__global__ __launch_bounds__(512, MSF == 2 ? 4 : 2) void k_bmult_chain(DevModel dm, cplx* __restrict__ A, int lda, int nvec,
                                                       int kfirst, int kstep, int kcount, int shift, size_t cs) {
     extern __shared__ cplx sm[];
     dm = chain_model(dm, cs); CHAIN(A);
