@@ -415,7 +415,8 @@ void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx
     static const int stage = getenv("DQMC_FLUSH_STAGE") ? atoi(getenv("DQMC_FLUSH_STAGE")) : 1;                 // developer knob (A/B)
 #define FLUSH_LAUNCH(M3_, FULL_, ST_) do { if (tag) hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_, 1>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb); \
                                            else hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_, 0>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb); } while (0)
-    if (use_4m()) { if (full) FLUSH_LAUNCH(false, true, 1); else FLUSH_LAUNCH(false, false, 1); }
+    static const bool flush_4m = getenv("DQMC_FLUSH_4M") && atoi(getenv("DQMC_FLUSH_4M")) != 0;               // developer knob (A/B): 4 MFMAs, 122 registers, 4 workgroups per CU
+    if (use_4m() || flush_4m) { if (full) FLUSH_LAUNCH(false, true, 1); else FLUSH_LAUNCH(false, false, 1); }
     else if (stage == 2) { if (full) FLUSH_LAUNCH(true, true, 2);  else FLUSH_LAUNCH(true, false, 2); }
     else          { if (full) FLUSH_LAUNCH(true, true, 1);  else FLUSH_LAUNCH(true, false, 1); }
 #undef FLUSH_LAUNCH
