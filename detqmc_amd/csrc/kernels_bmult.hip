@@ -58,7 +58,8 @@ __device__ __forceinline__ void build_V(cplx (&V)[MSF][MSF], double sign, double
     }
 }
 
-template<int MSF, bool RIGHT, bool INV>
+// CDW: cdwU != 0 (the discrete field's terms in e^{dtau V}); a template parameter so that the cdwU == 0 kernels are the round-2 code
+template<int MSF, bool RIGHT, bool INV, bool CDW>
 __global__ __launch_bounds__(512, MSF == 2 ? 4 : 2) void k_bmult_chain(DevModel dm, cplx* __restrict__ A, int lda, int nvec,
                                                       int kfirst, int kstep, int kcount, int shift, size_t cs) {
     extern __shared__ cplx sm[];
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(512, MSF == 2 ? 4 : 2) void k_bmult_chain(DevModel 
                                     const int i = site[q];
                                     const double c = dm.coshT[(size_t)k * N + i];
                                     double xs = dm.sinhT[(size_t)k * N + i], c0, c1;
-                                    cdw_site_terms(dm, (size_t)k * N + i, vsign, c, c0, c1, xs);
+                                    if constexpr (CDW) cdw_site_terms(dm, (size_t)k * N + i, vsign, c, c0, c1, xs); else { c0 = c; c1 = c; }
                                     const double p0 = ph[i];
                                     const double p1 = dm.opdim > 1 ? ph[N + i] : 0.0;
                                     const double p2 = dm.opdim > 2 ? ph[2 * N + i] : 0.0;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(512, MSF == 2 ? 4 : 2) void k_bmult_chain(DevModel 
                     inext = i + sid; vnext = v + svd;
                     if (inext >= N) { inext -= N; vnext += 1; }
                     double c = dm.coshT[(size_t)k * N + i], xs = dm.sinhT[(size_t)k * N + i], c0, c1;
-                    cdw_site_terms(dm, (size_t)k * N + i, vsign, c, c0, c1, xs);
+                    if constexpr (CDW) cdw_site_terms(dm, (size_t)k * N + i, vsign, c, c0, c1, xs); else { c0 = c; c1 = c; }
                     double p0 = ph[i];
                     double p1 = dm.opdim > 1 ? ph[N + i] : 0.0;
                     double p2 = dm.opdim > 2 ? ph[2 * N + i] : 0.0;
@@ -387,18 +388,18 @@ void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, 
     const size_t lds = (size_t)(side == DQMC_LEFT ? nvec : nvec + 1) * ng * sizeof(cplx);
     if (lds > 48 * 1024) {      // raise the dynamic-LDS limit of the instantiation once per device
         static std::mutex mu;
-        static size_t raised_tab[64][8] = {};
+        static size_t raised_tab[64][16] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
-        const int slot = (hm.MSF == 4 ? 4 : 0) + (side == DQMC_LEFT ? 0 : 2) + (inverse ? 1 : 0);
+        const int slot = (hm.cdw_on ? 8 : 0) + (hm.MSF == 4 ? 4 : 0) + (side == DQMC_LEFT ? 0 : 2) + (inverse ? 1 : 0);
         std::lock_guard<std::mutex> lk(mu);
         size_t& raised = raised_tab[dev & 63][slot];
         if (lds > raised) {
             const void* f = nullptr;
-            if (hm.MSF == 2) f = side == DQMC_LEFT ? (inverse ? (const void*)k_bmult_chain<2, false, true> : (const void*)k_bmult_chain<2, false, false>)
-                                                   : (inverse ? (const void*)k_bmult_chain<2, true, true> : (const void*)k_bmult_chain<2, true, false>);
-            else             f = side == DQMC_LEFT ? (inverse ? (const void*)k_bmult_chain<4, false, true> : (const void*)k_bmult_chain<4, false, false>)
-                                                   : (inverse ? (const void*)k_bmult_chain<4, true, true> : (const void*)k_bmult_chain<4, true, false>);
+#define BM_F(MSFV, R, I) (hm.cdw_on ? (const void*)k_bmult_chain<MSFV, R, I, true> : (const void*)k_bmult_chain<MSFV, R, I, false>)
+            if (hm.MSF == 2) f = side == DQMC_LEFT ? (inverse ? BM_F(2, false, true) : BM_F(2, false, false)) : (inverse ? BM_F(2, true, true) : BM_F(2, true, false));
+            else             f = side == DQMC_LEFT ? (inverse ? BM_F(4, false, true) : BM_F(4, false, false)) : (inverse ? BM_F(4, true, true) : BM_F(4, true, false));
+#undef BM_F
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised = lds;
             else (void)hipGetLastError();      // the launch below then reports the problem
         }
@@ -408,8 +409,10 @@ void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, 
     static const int env_t = getenv("DQMC_BMULT_THREADS_R") ? atoi(getenv("DQMC_BMULT_THREADS_R")) : 0;
     const int nthreads = (side == DQMC_LEFT) ? 256 : (env_t ? env_t : (nvec >= 8 ? 512 : 256));
 #define LAUNCH(MSFV, R, I)                                                                              \
-    hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I>), dim3(grid, 1, lc.nb), dim3(nthreads), lds, lc.st, hm, A, lda, nvec, \
-                       kfirst, kstep, kcount, shift, lc.cs)
+    do { if (hm.cdw_on) hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I, true>), dim3(grid, 1, lc.nb), dim3(nthreads), lds, lc.st, hm, A, lda, nvec, \
+                                           kfirst, kstep, kcount, shift, lc.cs);                        \
+         else hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I, false>), dim3(grid, 1, lc.nb), dim3(nthreads), lds, lc.st, hm, A, lda, nvec, \
+                                 kfirst, kstep, kcount, shift, lc.cs); } while (0)
     if (hm.MSF == 2) {
         if (side == DQMC_LEFT) { if (!inverse) LAUNCH(2, false, false); else LAUNCH(2, false, true); }
         else                   { if (!inverse) LAUNCH(2, true, false);  else LAUNCH(2, true, true); }
