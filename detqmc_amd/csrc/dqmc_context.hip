@@ -40,6 +40,11 @@ struct dqmc_ctx {
     dqmc_params p;
     DevModel hm;
     hipStream_t st = nullptr;
+    // pipelined local updates (dqmc_update_slice): the flush of block b runs on st2 while the decisions of block b + 1 run on st
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_win = nullptr, ev_flush = nullptr;
+    cplx* Gwin = nullptr;          // (MSF pbudget)^2: the next block's proposal window of G (k_update_window)
+    int pipe_P = 0;                // pbudget when the pipeline is possible, else 0
     // batched chains: nb chains in lockstep; per-chain buffers of chain b = chain 0's + b * cs (one arena)
     Launch lc{nullptr, 1, 0};
     int nb = 1, sel = 0;                // sel: chain the host-buffer entry points talk to (dqmc_select_chain)
@@ -508,6 +513,9 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
 static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     const int N = c->N, MSF = c->MSF, ng = c->n_g;
     HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_win, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_flush, hipEventDisableTiming));
 
     DevModel& hm = c->hm;
     memset(&hm, 0, sizeof(hm));
@@ -626,6 +634,18 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     const int WD = MSF * c->D;
     const int WD8 = (WD + 7) & ~7;          // X and GrT are zero padded to a multiple of 8 columns for the flush kernel
     A_(dalloc(c, &c->X, (size_t)ng * WD8)); A_(dalloc(c, &c->Gr, (size_t)WD8 * ng)); A_(dalloc(c, &c->W, (size_t)WD * WD));
+    {   // Pipelined updates (see dqmc_update_slice) need a bounded proposal window (pbudget) small enough for a compact copy.  OFF by
+        // default: measured on MI355X (round 3) the decisions of block b + 1 do overlap the flush of block b (88 % of their time,
+        // rocprofv3 time line), but the flush slows down next to them (165 -> 215 us), the window kernel and two cross-stream waits
+        // per block add ~ 35 us, and the next gather still waits for the flush: 307 vs 343 us per block for one context alone and no
+        // gain per sweep (213 vs 216 sweeps/s), while four contexts lose their overlap with each other (250 vs 285) and a single chain
+        // pays the extra launches (5.6 vs 6.2).  DQMC_PIPELINE=1 switches it on (tests keep both orders on the reference's chain).
+        const bool on = getenv("DQMC_PIPELINE") && atoi(getenv("DQMC_PIPELINE")) == 1;
+        if (on && p->model == DQMC_MODEL_SDW && hm.pbudget > 0 && MSF * hm.pbudget <= 512) {
+            c->pipe_P = hm.pbudget;
+            A_(dalloc(c, &c->Gwin, (size_t)MSF * hm.pbudget * MSF * hm.pbudget));
+        }
+    }
     c->uni_cap = (size_t)(p->opdim + 1 + (p->cdwU != 0.0 ? 2 : 0)) * N * p->m + 64;     // one sweep's worst case (+ the cdwl pass)
     A_(dalloc(c, &c->uniforms, c->uni_cap));
     A_(dalloc(c, &c->us, 1));
@@ -672,6 +692,9 @@ extern "C" void dqmc_destroy(dqmc_ctx* c) {
     if (c->jacobi_graph) (void)hipGraphExecDestroy(c->jacobi_graph);
     if (c->sw.hflag) (void)hipHostFree(c->sw.hflag);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_win) (void)hipEventDestroy(c->ev_win);
+    if (c->ev_flush) (void)hipEventDestroy(c->ev_flush);
+    if (c->st2) (void)hipStreamDestroy(c->st2);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
 }
@@ -1177,32 +1200,42 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     }
     const int rounds = (c->N + c->D - 1) / c->D;
     const int WD = c->MSF * c->D;
-    for (int r = 0; r < rounds; ++r) {
-        {
-            ProfScope ps(c, FAM_UPDATE, 1);
-            launch_update_decide(c->lc, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, thermalization);
+    // Pipelined form (proposal budget set, no per-launch profiling): decide(b + 1) needs G only inside its proposal window, so the
+    // window kernel hands it a compact, already updated copy and the flush of block b over the whole of G runs on the second stream
+    // next to the decisions of block b + 1; gather(b + 1) waits for it.  The first block of a pass reads G itself.
+    const bool pipe = c->pipe_P > 0 && !c->prof && !sync_check_on();
+    Launch lc2 = c->lc; lc2.st = c->st2;
+    auto pass = [&](int cdw_pass) -> int {
+        for (int r = 0; r < rounds; ++r) {
+            {
+                ProfScope ps(c, FAM_UPDATE, 1);
+                launch_update_decide(c->lc, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, cdw_pass ? 0 : thermalization, cdw_pass,
+                                     c->Gwin, (pipe && r > 0) ? c->pipe_P : 0);
+            }
+            if (pipe && r > 0) HIPCHK(hipStreamWaitEvent(c->st, c->ev_flush, 0));      // gather reads whole rows / columns of the flushed G
+            {
+                ProfScope ps(c, FAM_GATHER, 1);
+                launch_update_gather(c->lc, c->hm, c->us, c->G, c->W, c->X, c->Gr);
+            }
+            if (pipe) {
+                launch_update_window(c->lc, c->hm, c->us, c->G, c->X, c->Gr, c->Gwin, c->pipe_P);
+                HIPCHK(hipEventRecord(c->ev_win, c->st));
+                HIPCHK(hipStreamWaitEvent(c->st2, c->ev_win, 0));
+                c->fam_launches[FAM_FLUSH] += 1;
+                launch_flush(lc2, c->X, c->Gr, c->n_g, c->G, c->n_g, c->n_g, WD, &c->us->flush_k, 1);
+                HIPCHK(hipEventRecord(c->ev_flush, c->st2));
+            } else {
+                ProfScope ps(c, FAM_FLUSH, 1);
+                launch_flush(c->lc, c->X, c->Gr, c->n_g, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
+            }
         }
-        {
-            ProfScope ps(c, FAM_GATHER, 1);
-            launch_update_gather(c->lc, c->hm, c->us, c->G, c->W, c->X, c->Gr);
-        }
-        ProfScope ps(c, FAM_FLUSH, 1);
-        launch_flush(c->lc, c->X, c->Gr, c->n_g, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
-    }
+        if (pipe) HIPCHK(hipStreamWaitEvent(c->st, c->ev_flush, 0));                     // whatever comes next on the main stream sees the flushed G
+        return DQMC_OK;
+    };
+    { int rc = pass(0); if (rc) return rc; }
     // cdwU != 0: the second pass over the slice updates the discrete field (detsdwopdim.cpp:2474-2485); its acceptance ratio is
     // discarded there and here (no step-width adaptation)
-    for (int r = 0; c->hm.cdw_on && r < rounds; ++r) {
-        {
-            ProfScope ps(c, FAM_UPDATE, 1);
-            launch_update_decide(c->lc, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, 0, /*cdw_pass=*/1);
-        }
-        {
-            ProfScope ps(c, FAM_GATHER, 1);
-            launch_update_gather(c->lc, c->hm, c->us, c->G, c->W, c->X, c->Gr);
-        }
-        ProfScope ps(c, FAM_FLUSH, 1);
-        launch_flush(c->lc, c->X, c->Gr, c->n_g, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
-    }
+    if (c->hm.cdw_on) { int rc = pass(1); if (rc) return rc; }
     return finish(c, "dqmc_update_slice");
 }
 

@@ -103,6 +103,7 @@ struct DevUpdateState {
     int acc_count;           // accepted proposals in the current slice
     int block_j;             // accepted updates in the block the last decision launch produced
     int slice_done;
+    int flush_k;             // K = MSF j of the block whose flush is in flight (pipelined update: block_j already belongs to the next block)
     double r;                // this chain's exchange parameter (differs between the chains of a batch)
     int block_sites[DQMC_MAX_WDIM];
     unsigned long long blocks_nonempty;  // delayed-update blocks that accepted at least one update (-> real flushes)
@@ -174,7 +175,10 @@ __device__ __forceinline__ void cdw_site_terms(const DevModel& dm, size_t idx, d
 void launch_cdw_terms(const Launch& lc, const DevModel& hm);      // cdwC / cdwS from cdwl, all slices
 // cdw_mode 0: phi proposals (with the cdw terms in e^{dtau V} when cdw_on); 1: the cdwl pass (proposeNewCDWl, :4173-4182)
 void launch_update_decide(const Launch& lc, const DevModel* dm, const DevModel& hm, DevUpdateState* us,
-                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal, int cdw_pass = 0);
+                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal, int cdw_pass = 0,
+                          const cplx* Gwin = nullptr, int winP = 0);      // winP > 0: G entries from the window copy (k_update_window)
+void launch_update_window(const Launch& lc, const DevModel& hm, DevUpdateState* us, const cplx* G, const cplx* X, const cplx* GrT,
+                          cplx* Gw, int P);
 void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,
                           const cplx* W, cplx* X, cplx* GrT);
 

@@ -176,12 +176,13 @@ __device__ __forceinline__ double u_wave_total(double v) {
 // cdwl_gamma(new) / cdwl_gamma(old) joins the acceptance probability (:3110); its acceptance ratio is discarded.
 template<int OPDIM, int CDW>
 __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
-                                                       const cplx* __restrict__ G, cplx* __restrict__ Wout,
-                                                       int k, int first, int thermal, size_t cs) {
+                                                       const cplx* __restrict__ Gfull, cplx* __restrict__ Wout,
+                                                       int k, int first, int thermal, size_t cs,
+                                                       const cplx* __restrict__ Gwin, int winP) {
     constexpr int MSF = (OPDIM == 3) ? 4 : 2;
     constexpr int SLOTS = MSF * DQMC_MAX_WDIM / 64;
     constexpr int NPROP = (CDW == 2) ? 1 : OPDIM;      // uniforms a proposal draws
-    dm = chain_model(dm, cs); CHAIN(us); CHAIN(uni); CHAIN(G); CHAIN(Wout);
+    dm = chain_model(dm, cs); CHAIN(us); CHAIN(uni); CHAIN(Gfull); CHAIN(Wout); CHAIN(Gwin);
     dm.r = us->r;                         // the exchange parameter differs between the chains of a batch
     const int N = dm.N, ng = dm.ng, D = dm.D, m = dm.m;
     const int WD = MSF * D;
@@ -200,6 +201,12 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     const int L = dm.L;
 
     int site = first ? 0 : us->site_cursor;
+    // Every G entry a launch reads has both indices among the sites of its proposal window [site, site + pbudget) (x the MSF bands).
+    // winP > 0: those entries come from the compact copy k_update_window made of that window -- already holding the previous block's
+    // update, whose flush over the whole of G may still be running on the second stream (pipelined update, dqmc_update_slice).
+    // Index of (site s, band a): (s - goff) + a * gNB, leading dimension gld.
+    const cplx* G = winP > 0 ? Gwin : Gfull;
+    const int goff = winP > 0 ? site : 0, gNB = winP > 0 ? winP : dm.N, gld = winP > 0 ? MSF * winP : dm.ng;
     int acc_count = first ? 0 : us->acc_count;
     int done = first ? 0 : us->slice_done;
     if (done || site >= N) {
@@ -275,8 +282,8 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                 const int t = item - O_GCC;
                 const int blk = t / (2 * MSF * MSF), e = t % (2 * MSF * MSF);
                 const int part = e & 1, ab = e >> 1, a = ab / MSF, b = ab % MSF;
-                const int row = (blk == 2 ? prev : s) + a * N, col = (blk == 1 ? prev : s) + b * N;
-                if (blk == 0 || prev >= 0) addr = (const double*)G + 2 * ((size_t)col * ng + row) + part;
+                const int row = (blk == 2 ? prev : s) - goff + a * gNB, col = (blk == 1 ? prev : s) - goff + b * gNB;
+                if (blk == 0 || prev >= 0) addr = (const double*)G + 2 * ((size_t)col * gld + row) + part;
             }
             pre[q] = addr ? *addr : dflt;
         }
@@ -285,9 +292,9 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             const int t = tid + 64 * q;                   // (i, a): entry u[a][i] = G[c_a, I_i] and v[i][a] = G[I_i, c_a]
             if (t < MSF * nIknown) {
                 const int a = t % MSF, i = t / MSF;
-                const int Ii = isite[i / MSF] + (i % MSF) * N;
-                pu[q] = G[(size_t)Ii * ng + (s + a * N)];
-                pv[q] = G[(size_t)(s + a * N) * ng + Ii];
+                const int Ii = isite[i / MSF] - goff + (i % MSF) * gNB, sa = s - goff + a * gNB;
+                pu[q] = G[(size_t)Ii * gld + sa];
+                pv[q] = G[(size_t)sa * gld + Ii];
             }
         }
     };
@@ -816,7 +823,8 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
 }
 
 void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, DevUpdateState* us,
-                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal, int cdw_pass) {
+                          const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal, int cdw_pass,
+                          const cplx* Gwin, int winP) {
     const int WD = hm.MSF * hm.D;
     size_t lds = ((size_t)WD * (WD + 1) + 6 * (size_t)hm.MSF * WD) * sizeof(cplx) + (size_t)hm.opdim * hm.N * sizeof(double);
     const int cdw = hm.cdw_on ? (cdw_pass ? 2 : 1) : 0;
@@ -838,7 +846,8 @@ void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevMod
             else (void)hipGetLastError();      // the launch below then reports the problem
         }
     }
-    void* args[] = {(void*)&hm, (void*)&us, (void*)&uniforms, (void*)&G, (void*)&W, (void*)&k, (void*)&first, (void*)&thermal, (void*)&lc.cs};
+    void* args[] = {(void*)&hm, (void*)&us, (void*)&uniforms, (void*)&G, (void*)&W, (void*)&k, (void*)&first, (void*)&thermal, (void*)&lc.cs,
+                    (void*)&Gwin, (void*)&winP};
     (void)hipLaunchKernel(f, dim3(1, 1, lc.nb), dim3(256), args, lds, lc.st);
 }
 
@@ -967,6 +976,40 @@ __global__ __launch_bounds__(256, 2) void k_update_gather(DevModel dm, const Dev
             // columns nI .. nI8 - 1: W was masked to zero there, so the product IS the zero padding
             if (c < nI8 && r < ng) X[(size_t)c * ng + r] = make_double2(p1 - p2, (acc_im[a][rr] - p1) - p2);
         }
+}
+
+// The proposal window of the NEXT delayed-update block, with this block's update already in it:
+//   Gw[(b P + t') ldw + a P + t] = G[row, col] + sum_k X[row, k] GrT[col, k],   row = a N + s0 + t, col = b N + s0 + t',
+// s0 = the site the next decision launch starts at, P = pbudget sites, ldw = MSF P -- the (MSF P)^2 entries the next k_update_decide
+// launch can touch (see there).  With this copy the decisions of block b + 1 do not have to wait for the flush of block b over the
+// whole of G: the flush runs on a second stream meanwhile.  Also publishes K = MSF j for that flush (flush_k: the next decision
+// launch overwrites block_j while the flush may still be reading its K).  One thread per entry.
+__global__ __launch_bounds__(256) void k_update_window(DevModel dm, DevUpdateState* us, const cplx* __restrict__ G,
+                                                        const cplx* __restrict__ X, const cplx* __restrict__ GrT,
+                                                        cplx* __restrict__ Gw, int P, size_t cs) {
+    CHAIN(us); CHAIN(G); CHAIN(X); CHAIN(GrT); CHAIN(Gw);
+    const int MSF = dm.MSF, N = dm.N, ng = dm.ng;
+    const int j = us->block_j, s0 = us->site_cursor;
+    if (blockIdx.x == 0 && threadIdx.x == 0) us->flush_k = MSF * j;
+    if (us->slice_done || s0 >= N) return;
+    const int K8 = (MSF * j + 7) & ~7;
+    const int ldw = MSF * P;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ldw * ldw) return;
+    const int iw = e % ldw, jw = e / ldw;
+    const int a = iw / P, t = iw - a * P, b = jw / P, t2 = jw - b * P;
+    if (s0 + t >= N || s0 + t2 >= N) return;               // past the last site: never read
+    const int row = a * N + s0 + t, col = b * N + s0 + t2;
+    cplx acc = G[(size_t)col * ng + row];
+    const cplx* xr = X + row;
+    const cplx* gc = GrT + col;
+    for (int kk = 0; kk < K8; ++kk) acc = u_cfma(xr[(size_t)kk * ng], gc[(size_t)kk * ng], acc);
+    Gw[(size_t)jw * ldw + iw] = acc;
+}
+void launch_update_window(const Launch& lc, const DevModel& hm, DevUpdateState* us, const cplx* G, const cplx* X, const cplx* GrT,
+                          cplx* Gw, int P) {
+    const int ldw = hm.MSF * P;
+    hipLaunchKernelGGL(k_update_window, dim3((ldw * ldw + 255) / 256, 1, lc.nb), dim3(256), 0, lc.st, hm, us, G, X, GrT, Gw, P, lc.cs);
 }
 
 void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,

@@ -1355,6 +1355,40 @@ def test_lu_and_householder_green_functions_walk_the_same_chains(tmp_path):
         assert "same chains" in r.stdout
 
 
+@pytest.mark.parametrize("name", ["o2_L8_b5", "o3_L6", "o2_L6_seed"])
+def test_pipelined_and_sequential_updates_walk_the_same_chain(name):
+    """dqmc_update_slice overlaps the flush of a delayed-update block with the decisions of the next one (the decisions read a compact,
+    already updated copy of their proposal window); DQMC_PIPELINE=0 (read at dqmc_create) keeps the strictly sequential order.  Both
+    must walk the chain of the reference fixture; between themselves: identical fields and RNG position, G to rounding."""
+    import os
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    out = []
+    for pipeline in ("1", "0"):
+        old = os.environ.get("DQMC_PIPELINE")
+        os.environ["DQMC_PIPELINE"] = pipeline
+        try:
+            rep = DetSDW(_sdw_params(g["params"], stabilisation="qr"))
+        finally:
+            if old is None:
+                del os.environ["DQMC_PIPELINE"]
+            else:
+                os.environ["DQMC_PIPELINE"] = old
+        i = 1
+        while f"sweep{i}_phi" in g:
+            rep.sweepThermalization()
+            assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), (pipeline, i)
+            if f"sweep{i}_g" in g:
+                assert relerr(rep.g, g[f"sweep{i}_g"]) < TOL
+            else:                                   # larger fixtures keep a sub-sampled G and its diagonal
+                assert relerr(np.diag(rep.g), g[f"sweep{i}_g_diag"]) < TOL
+            i += 1
+        out.append((rep.phi, rep.g, rep.info.rngDrawn))
+        rep.close()
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][2] == out[1][2]
+    assert relerr(out[0][1], out[1][1]) < 1e-11
+
+
 def test_environment_cannot_change_the_markov_chain():
     """No environment variable may change what the decision kernel computes.  Rounds 1-2 shipped timing experiments behind
     DQMC_DBG (bit 2 skipped the p = W v / q = u W products and the bordering update, bit 4 replaced exp by 1 + x); they are gone,
