@@ -528,6 +528,11 @@ void DetSDW::attemptGlobalMove(Group& g, GlobalMoveKind kind) {
     check(dqmc_get_sv_all_host(ctx, old_sv.data()), "dqmc_get_sv_all_host");
     // The pure shift move never leaves the device: both bosonic actions are reductions over the resident field and the
     // displacement is a constant per component; the host only draws the displacement (the chain's RNG stream, reference order).
+    // Rounding: k_phi_action adds 256 strided partial sums and then a tree, the reference (phiAction, :4242-4300) adds slice by slice
+    // and site by site -- the two actions (~1e4) agree to ~1e-12 absolute, so exp(-(s_new - s_old)) agrees to ~1e-12 relative and a
+    // decision differs from the reference's only if its uniform falls within that distance of the probability (once in ~1e12 moves;
+    // the same holds for the fermionic ratio, a product of n_g singular-value quotients).  The host mirror c.phi is NOT touched here:
+    // it is valid only after syncPhiFromDevice (every reader calls it).
     const bool on_device = (kind == MoveShift);
     if (on_device) {
         std::vector<double> s_old(nb), s_new(nb), shifts((size_t)nb * opdim_);
