@@ -870,19 +870,25 @@ __global__ __launch_bounds__(256, 2) void k_update_gather(DevModel dm, const Dev
                                                            const cplx* __restrict__ G, const cplx* __restrict__ Wg,
                                                            cplx* __restrict__ X, cplx* __restrict__ GrT, size_t cs) {
     CHAIN(us); CHAIN(G); CHAIN(Wg); CHAIN(X); CHAIN(GrT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ONE round trip for the block's bookkeeping: the count and all DQMC_MAX_WDIM site slots are requested together (slots >= j hold
+    // sites of earlier blocks and are never used); round 3 before: count -> first / last site -> the list, three dependent trips
     const int j = us->block_j;
+    const int mysite = us->block_sites[tid & (DQMC_MAX_WDIM - 1)];
     if (j <= 0) return;
     const int MSF = dm.MSF, N = dm.N, ng = dm.ng, WD = MSF * dm.D;
     const int nI = MSF * j, nI8 = (nI + 7) & ~7;
+    __shared__ int ssite[DQMC_MAX_WDIM];
     __shared__ int sI[DQMC_MAX_WDIM];
     __shared__ short smap[GATHER_MAXSPAN];                 // site - first site of the block  ->  index among the accepted, or -1
     __shared__ cplx tile[DQMC_MAX_WDIM][33];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s_first = us->block_sites[0], span = us->block_sites[j - 1] - s_first + 1;
-    for (int t = tid; t < nI; t += 256) sI[t] = us->block_sites[t / MSF] + (t % MSF) * N;
+    if (tid < DQMC_MAX_WDIM) ssite[tid] = mysite;
+    __syncthreads();
+    const int s_first = ssite[0], span = ssite[j - 1] - s_first + 1;
+    for (int t = tid; t < nI; t += 256) sI[t] = ssite[t / MSF] + (t % MSF) * N;
     for (int t = tid; t < span; t += 256) smap[t] = -1;
     __syncthreads();
-    for (int t = tid; t < j; t += 256) smap[us->block_sites[t] - s_first] = (short)t;
+    for (int t = tid; t < j; t += 256) smap[ssite[t] - s_first] = (short)t;
     __syncthreads();
     const int r0 = blockIdx.x * 32;
     // ---- GrT, phase 1: coalesced runs of rows -> LDS tile ----
@@ -952,6 +958,9 @@ __global__ __launch_bounds__(256, 2) void k_update_gather(DevModel dm, const Dev
         }
     };
     {
+        // two operand sets in flight (ping-pong, written out twice: see k_flush).  A ring of four sets was measured and changed nothing
+        // (385 vs 377 ms per 10 steps of 128 chains): the launch moves 275 MB of physical HBM traffic in 47 us (5.8 TB/s, PMC) -- it is
+        // bound by the bytes it fetches, 1.39 x the algorithmic ones because of the row windows, not by the latency of this loop.
         cplx wA, wB, gA[2], gB[2];
         ldk(0, wA, gA);
         ldk(4, wB, gB);                                   // k >= nI: masked to zero
