@@ -52,7 +52,7 @@ CONFIGS = {
     "o2_L16_b20": dict(workload=dict(opdim=2, L=16, beta=20.0, delaySteps=32), batch=256, sub=4,
                        label="SDW-O2 L=16 beta=20", text="DetSDW O(2) L=16 beta=20 dtau=0.1 s=10"),
     # no magnetic flux: the reference refuses weakZflux for opdim = 3 (src/detsdwparams.cpp:57-60), and so does detsdw_create
-    "o3_L24_b20": dict(workload=dict(opdim=3, L=24, beta=20.0, delaySteps=16), batch=8, sub=1,
+    "o3_L24_b20": dict(workload=dict(opdim=3, L=24, beta=20.0, delaySteps=16), batch=8, sub=2,     # 8 chains in two contexts: 1.46 against 1.29 in one (round 3)
                        label="SDW-O3 L=24 beta=20", text="DetSDW O(3) L=24 beta=20 dtau=0.1 s=10 (no flux: the reference rejects O(3) + flux)",
                        ref_parts=True),
 }
@@ -563,10 +563,10 @@ def main():
     while B % S != 0:          # the contexts of a process hold the same number of chains
         S -= 1
 
-    def spawn(device, simindex, batch, steps, warmup, sub=None):
+    def spawn(device, simindex, batch, steps, warmup, sub=None, extra_env=None):
         cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--config", a.config, "--device", str(0 if one_device else device), "--simindex",
                str(simindex), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch), "--sub-batches", str(sub or S)]
-        return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
+        return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=dict(env, **(extra_env or {})))
 
     procs = []          # (gpu index, process)
     if a.inprocess:
@@ -634,7 +634,11 @@ def main():
         solo = json.loads(read_tag(pw, "SOLO"))
         pw.wait()
         nst = max(2, min(a.steps, 4))
-        sp = spawn(my_gpus[0], 9999, 1, nst, 1, sub=1)                                   # one context x ONE chain
+        # one context x ONE chain.  The delay depth is a performance knob (same chain for every depth): a batch amortises the flush of
+        # a deep block over many chains, a single chain is bound by the decisions, whose cost grows with the block -- 16 is its
+        # optimum at n_g = 512 (6.3 / 6.7 / 6.8 / 6.8 / 6.7 / 6.3 sweeps/s at 8 / 12 / 16 / 20 / 24 / 32, gpurun call 33 of round 3)
+        single_D = min(WORKLOAD["delaySteps"], 16)
+        sp = spawn(my_gpus[0], 9999, 1, nst, 1, sub=1, extra_env=None if os.environ.get("DQMC_DELAY_STEPS") else {"DQMC_DELAY_STEPS": str(single_D)})
         read_tag(sp, "READY")
         send(sp, "GO")
         sr = json.loads(read_tag(sp, "RESULT"))
@@ -682,6 +686,7 @@ def main():
             # ONE kernel context (dqmc_create_batch: one stream, one launch sequence) of chains_per_context chains alone on the GPU
             "one_context_sweeps_per_s": one_ctx,
             "single_chain_sweeps_per_s": single,
+            "single_chain_delaySteps": (int(os.environ["DQMC_DELAY_STEPS"]) if os.environ.get("DQMC_DELAY_STEPS") else min(WORKLOAD["delaySteps"], 16)),
             "acceptance": r0["acceptance"],
         }
         if solo and solo.get("prof"):
