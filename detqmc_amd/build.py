@@ -46,6 +46,7 @@ def build(force=False, verbose=True):
                os.path.join(HERE, "..", "include", "dethubbard_host.h")]
     hdr_time = max(os.path.getmtime(h) for h in headers)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    flags += os.environ.get("DQMC_BUILD_DEFINES", "").split()       # developer builds, e.g. -DDQMC_DECIDE_TIMING (use with force=True)
     objs = []
     procs = []
     for s in SOURCES:
