@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     constexpr int NPROP = (CDW == 2) ? 1 : OPDIM;      // uniforms a proposal draws
     dm = chain_model(dm, cs); CHAIN(us); CHAIN(uni); CHAIN(Gfull); CHAIN(Wout); CHAIN(Gwin);
     dm.r = us->r;                         // the exchange parameter differs between the chains of a batch
-    const int N = dm.N, ng = dm.ng, D = dm.D, m = dm.m;
+    const int N = dm.N, D = dm.D, m = dm.m;
     const int WD = MSF * D;
     extern __shared__ cplx smem[];
     const int WS = WD + 1;                // row stride of W in LDS: odd, so rows do not start on the same banks
