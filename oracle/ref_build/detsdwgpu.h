@@ -131,6 +131,16 @@ public:
                 for (uint32_t k = 1; k <= pars_.m; ++k)
                     for (uint32_t dim = 0; dim < pars_.opdim; ++dim)
                         out << phi[(iy * pars_.L + ix) + (size_t)pars_.N * (dim + (size_t)pars_.opdim * k)] << "\n";
+        if (pars_.cdwU) {                   // configs-l.textstream (src/detsdwopdim.cpp:4967-4986)
+            const fs::path pl = fs::path(directory) / fs::path("configs-l.textstream");
+            std::ofstream lout(pl.c_str(), std::ios::app);
+            if (!lout) { std::cerr << "Could not open file " << pl.string() << " for writing.\n"; return; }
+            std::vector<int32_t> l((size_t)pars_.N * (pars_.m + 1));
+            call(detsdw_get_cdwl(h_, l.data()), "detsdw_get_cdwl");
+            for (uint32_t ix = 0; ix < pars_.L; ++ix)
+                for (uint32_t iy = 0; iy < pars_.L; ++iy)
+                    for (uint32_t k = 1; k <= pars_.m; ++k) lout << l[(iy * pars_.L + ix) + (size_t)pars_.N * k] << "\n";
+        }
     }
     void saveConfigurationStreamTextHeader(const std::string& simInfoHeaderText, const std::string& directory = ".") {
         writeHeader(directory, "configs-phi.textstream", simInfoHeaderText, "## phi configuration stream\n");
@@ -168,6 +178,13 @@ public:
     DetSDW_SystemConfig getCurrentSystemConfiguration() {
         arma::Cube<num> phi(pars_.N, pars_.opdim, pars_.m + 1);                // reference layout == ABI layout
         call(detsdw_get_phi(h_, phi.memptr()), "detsdw_get_phi");
+        if (pars_.cdwU) {                   // src/detsdwopdim.cpp:5116-5122: the discrete field travels with phi
+            std::vector<int32_t> l((size_t)pars_.N * (pars_.m + 1));
+            call(detsdw_get_cdwl(h_, l.data()), "detsdw_get_cdwl");
+            MatInt cdwl(pars_.N, pars_.m + 1);
+            for (size_t i = 0; i < l.size(); ++i) cdwl[i] = l[i];
+            return DetSDW_SystemConfig(pars_, phi, cdwl);
+        }
         return DetSDW_SystemConfig(pars_, phi);
     }
     DetSDW_SystemConfig_FileHandle prepareSystemConfigurationStreamFileHandle(bool binaryStream, bool textStream,
@@ -187,6 +204,18 @@ public:
             if (fh.phi_output_text->fail()) std::cerr << "Could not open file " << p.string() << " for writing.\n";
             fh.phi_output_text->precision(14);
             fh.phi_output_text->setf(std::ios::scientific, std::ios::floatfield);
+        }
+        if (pars_.cdwU) {                   // src/detsdwopdim.cpp:5158-5181
+            if (binaryStream) {
+                const fs::path p = fs::path(directory) / fs::path("configs-l.binarystream");
+                fh.cdwl_output_binary = OfstreamPointer(new std::ofstream(p.c_str(), std::ios::binary | std::ios::app));
+                if (fh.cdwl_output_binary->fail()) std::cerr << "Could not open file " << p.string() << " for writing.\n";
+            }
+            if (textStream) {
+                const fs::path p = fs::path(directory) / fs::path("configs-l.textstream");
+                fh.cdwl_output_text = OfstreamPointer(new std::ofstream(p.c_str(), std::ios::app));
+                if (fh.cdwl_output_text->fail()) std::cerr << "Could not open file " << p.string() << " for writing.\n";
+            }
         }
         return fh;
     }

@@ -74,6 +74,44 @@ def test_detqmc_driver_with_gpu_model_writes_the_reference_output_tree(tmp_path)
     assert os.path.exists(tmp_path / "simulation.state") and os.path.exists(tmp_path / "info.dat")
 
 
+def test_detqmc_driver_with_gpu_model_and_cdwU(tmp_path):
+    """The reference's driver over the GPU model class at cdwU != 0: `cdwU` travels through ModelParamsDetSDW into the library, the
+    configuration streams gain configs-l.{binary,text}stream (src/detsdwopdim.cpp:4967-4986, :5015-5037) and hold the discrete field of the
+    same chain the Python view of the library walks for the same parameters.  (No comparison with the reference's CPU program here: its
+    own chain at cdwU != 0 depends on the last bit of a determinant at every null proposal)"""
+    from detqmc_amd import DetSDW, SDWParams
+    conf = open(os.path.join(CASE, "simulation.conf")).read()
+    conf = conf.replace("thermalization = 40", "thermalization = 4").replace("sweeps = 40", "sweeps = 4").replace("saveInterval = 20", "saveInterval = 2")
+    conf = conf.replace("saveConfigurationStreamText = false", "saveConfigurationStreamText = true").replace("jkBlocks = 5", "jkBlocks = 2")
+    conf = conf.replace("globalShift = true", "globalShift = false")
+    conf += "\ncdwU = 0.5\n"
+    (tmp_path / "simulation.conf").write_text(conf)
+    log = _run(str(tmp_path))
+    assert "Measurements finished" in log
+    L, m, N = 4, 20, 16
+    lb = np.fromfile(str(tmp_path / "configs-l.binarystream"), dtype=np.int32)
+    nconf = lb.size // (N * m)
+    assert nconf >= 1 and lb.size == nconf * N * m and set(np.unique(lb)) <= {-2, -1, 1, 2}
+    lt = np.loadtxt(str(tmp_path / "configs-l.textstream"), dtype=np.int64)
+    assert np.array_equal(lt.astype(np.int32), lb)
+    pb = np.fromfile(str(tmp_path / "configs-phi.binarystream"))
+    assert pb.size == nconf * N * m * 2
+    meta = "".join(_header(str(tmp_path / "results.values")))
+    assert "cdwU = 0.5" in meta
+    # the same parameters through the Python view: the first configuration is written behind the first measured sweep -- 4 thermalisation
+    # sweeps, sweep(false), sweep(true) with measureInterval = 2 (DetQMC::run, src/detqmc.h:435-505)
+    rep = DetSDW(SDWParams(opdim=2, L=4, beta=2.0, dtau=0.1, s=10, r=-0.5, c=1.0, u=1.0, lambda_=1.0, mu=-0.5, weakZflux=True, delaySteps=8, cdwU=0.5,   # c, u: the defaults of the reference option parser
+                           fermionMeasurements=True, rngSeed=1020304050, simindex=0))
+    for _ in range(4):
+        rep.sweepThermalization()
+    rep.sweep(False)
+    rep.sweep(True)
+    l = rep.cdwl
+    want = np.array([l[k, iy * L + ix] for ix in range(L) for iy in range(L) for k in range(1, m + 1)], dtype=np.int32)
+    assert np.array_equal(lb[:N * m], want), "driver and library walk different chains"
+    rep.close()
+
+
 def test_detqmc_driver_resumes_from_its_state_file(tmp_path):
     """DetQMC::saveState / the resume constructor (src/detqmc.h:121-135, 266-325) carry the replica through
     DetSDWGpu::saveContents / loadContents: 40 + 20 sweeps, then a second process continues to 40 measurement
