@@ -414,6 +414,41 @@ def test_cdw_trajectory_vs_oracle(opdim, L, D):
     batch.close()
 
 
+def test_cdw_headline_size_properties():
+    """cdwU != 0 at the headline lattice (L = 16, n_g = 512, delay depth 32, QR stabilisation, a batch of two replicas), checked through
+    properties that do not need the oracle at this size: B^-1 B = 1 with the discrete field in e^{-+dtau V}, the wrapped Green's function
+    against the one rebuilt from the fields after two sweeps, the field l stays in {+-1, +-2} and does change, the caches of phi stay exact,
+    and a second handle with the same seeds in a different delay depth walks the same chain."""
+    from detqmc_amd import DetSDWBatch, SDWParams
+    from detsdw_oracle import make_test_matrix
+    common = dict(opdim=2, L=16, beta=2.0, s=10, cdwU=0.45, stabilisation="qr", rngSeed=20262026)
+    out = []
+    for D in (32, 16):
+        batch = DetSDWBatch([SDWParams(**common, delaySteps=D, r=-1.0, simindex=0), SDWParams(**common, delaySteps=D, r=-0.6, simindex=1)])
+        l0 = batch.chain(1).cdwl
+        for _ in range(2):
+            batch.sweepThermalization()
+        rep = batch.chain(1)
+        l1, phi = rep.cdwl, rep.phi
+        assert set(np.unique(l1[1:])) <= {-2, -1, 1, 2} and np.any(l1[1:] != l0[1:])
+        ctx = rep.kernel_context
+        if D == 32:
+            A = make_test_matrix(512)
+            assert relerr(ctx.leftMultiplyBmatInv(ctx.leftMultiplyBmat(A, 10, 0), 10, 0), A) < 1e-10
+            assert relerr(ctx.rightMultiplyBmatInv(ctx.rightMultiplyBmat(A, 10, 0), 10, 0), A) < 1e-10
+            _, ch, sh = ctx.get_fields()
+            nrm = np.sqrt(np.sum(phi[1:] ** 2, axis=2))
+            assert relerr(ch[1:], np.cosh(0.1 * nrm)) < 1e-14 and relerr(sh[1:], np.sinh(0.1 * nrm) / nrm) < 1e-13
+        G = rep.g
+        out.append((phi, l1, G, rep.info.rngDrawn))
+        # G carried through two sweeps of wraps, updates and re-stabilisations against G rebuilt from the fields
+        ctx.setupUdVStorage_and_calculateGreen()
+        assert relerr(G, ctx.g) < 1e-8
+        batch.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][3] == out[1][3]
+    assert relerr(out[0][2], out[1][2]) < 1e-9
+
+
 def test_cdw_checkpoint_and_config_stream(tmp_path):
     """The discrete field travels with the checkpoint (saved after an even number of sweeps, like the phi-only test further down) and
     is written as configs-l.binarystream next to configs-phi.binarystream (detsdwopdim.cpp:5015-5037)."""
