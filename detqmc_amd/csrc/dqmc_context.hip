@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <atomic>
 
 void build_tournament(int nblk, std::vector<int>& out);   // kernels_svd.hip
 
@@ -45,6 +46,7 @@ struct dqmc_ctx {
     hipEvent_t ev_win = nullptr, ev_flush = nullptr;
     cplx* Gwin = nullptr;          // (MSF pbudget)^2: the next block's proposal window of G (k_update_window)
     int pipe_P = 0;                // pbudget when the pipeline is possible, else 0
+    int pipe_mode = 0;             // 1: always (DQMC_PIPELINE=1), 2: automatic (n_g > 1024 and at most two live contexts in the process)
     // batched chains: nb chains in lockstep; per-chain buffers of chain b = chain 0's + b * cs (one arena)
     Launch lc{nullptr, 1, 0};
     int nb = 1, sel = 0;                // sel: chain the host-buffer entry points talk to (dqmc_select_chain)
@@ -165,6 +167,8 @@ static hipError_t copy_sync(dqmc_ctx* c, void* dst, const void* src, size_t byte
 
 static void prof_collect(dqmc_ctx* c);
 enum { PROF_EVENT_CAP = 8192 };     // events alive at most: beyond that the finished pairs are collected and reused
+static std::atomic<int> g_live_contexts{0};      // kernel contexts alive in this process (the automatic pipelined update looks at it)
+
 struct ProfScope {
     dqmc_ctx* c; int fam; uint64_t launches; int idx = -1;     // idx: this scope's begin event (scopes may nest)
     ProfScope(dqmc_ctx* c_, int fam_, uint64_t launches_) : c(c_), fam(fam_), launches(launches_) {
@@ -499,6 +503,7 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     HIPCHK(hipSetDevice(p->device));
 
     dqmc_ctx* c = new dqmc_ctx();
+    g_live_contexts.fetch_add(1);           // dqmc_destroy takes it back (also on the failure path below)
     c->p = *p;
     c->nb = nchains;
     c->N = N; c->MSF = MSF; c->n_g = ng; c->m = p->m; c->s = p->s; c->D = p->delaySteps;
@@ -640,8 +645,13 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
         // per block add ~ 35 us, and the next gather still waits for the flush: 307 vs 343 us per block for one context alone and no
         // gain per sweep (213 vs 216 sweeps/s), while four contexts lose their overlap with each other (250 vs 285) and a single chain
         // pays the extra launches (5.6 vs 6.2).  DQMC_PIPELINE=1 switches it on (tests keep both orders on the reference's chain).
-        const bool on = getenv("DQMC_PIPELINE") && atoi(getenv("DQMC_PIPELINE")) == 1;
-        if (on && p->model == DQMC_MODEL_SDW && hm.pbudget > 0 && MSF * hm.pbudget <= 512) {
+        // Where it does pay: n_g = 2304 (config 5), where the flush is three quarters of an HBM-bound block and few contexts share
+        // the GPU -- 8 chains in one context 1.29 -> 1.40 sweeps/s, in two contexts 1.47 -> 1.56; 32 chains in four contexts lose again
+        // (1.83 -> 1.72).  So: automatic for n_g > 1024 while at most two contexts of this process are alive; DQMC_PIPELINE=0 / 1 forces.
+        const char* ev = getenv("DQMC_PIPELINE");
+        const int mode = ev ? (atoi(ev) == 1 ? 1 : 0) : ((ng > 1024 && c->nb >= 2) ? 2 : 0);       // a single chain loses 2 % (0.462 -> 0.452)
+        if (mode && p->model == DQMC_MODEL_SDW && hm.pbudget > 0 && MSF * hm.pbudget <= 512) {
+            c->pipe_mode = mode;
             c->pipe_P = hm.pbudget;
             A_(dalloc(c, &c->Gwin, (size_t)MSF * hm.pbudget * MSF * hm.pbudget));
         }
@@ -686,6 +696,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
 
 extern "C" void dqmc_destroy(dqmc_ctx* c) {
     if (!c) return;
+    g_live_contexts.fetch_sub(1);
     (void)hipSetDevice(c->p.device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     for (void* q : c->allocs) (void)hipFree(q);
@@ -1203,7 +1214,7 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     // Pipelined form (proposal budget set, no per-launch profiling): decide(b + 1) needs G only inside its proposal window, so the
     // window kernel hands it a compact, already updated copy and the flush of block b over the whole of G runs on the second stream
     // next to the decisions of block b + 1; gather(b + 1) waits for it.  The first block of a pass reads G itself.
-    const bool pipe = c->pipe_P > 0 && !c->prof && !sync_check_on();
+    const bool pipe = c->pipe_P > 0 && !c->prof && !sync_check_on() && (c->pipe_mode == 1 || g_live_contexts.load() <= 2);
     Launch lc2 = c->lc; lc2.st = c->st2;
     auto pass = [&](int cdw_pass) -> int {
         for (int r = 0; r < rounds; ++r) {
