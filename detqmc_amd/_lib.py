@@ -22,6 +22,17 @@ class dqmc_cplx(C.Structure):
     _fields_ = [("re", C.c_double), ("im", C.c_double)]
 
 
+class dqmc_tuning(C.Structure):
+    _fields_ = [("pipeline", C.c_int32), ("qr_variant", C.c_int32), ("green_variant", C.c_int32),
+                ("max_jacobi_sweeps", C.c_int32), ("proposal_budget", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class dqmc_schedule_info(C.Structure):
+    _fields_ = [("pipelined", C.c_int32), ("proposal_budget", C.c_int32), ("blocks_pipelined", C.c_uint64),
+                ("blocks_sequential", C.c_uint64), ("qr_block_gram_schmidt", C.c_int32), ("green_lu", C.c_int32),
+                ("cholqr_fallbacks", C.c_uint64)]
+
+
 class dqmc_params(C.Structure):
     _fields_ = [("opdim", C.c_int32), ("L", C.c_int32), ("m", C.c_int32), ("s", C.c_int32),
                 ("delaySteps", C.c_int32), ("bc", C.c_int32), ("weakZflux", C.c_int32),
@@ -30,7 +41,8 @@ class dqmc_params(C.Structure):
                 ("dtau", C.c_double), ("r", C.c_double), ("c", C.c_double), ("u", C.c_double),
                 ("lambda_", C.c_double),
                 ("txhor", C.c_double), ("txver", C.c_double), ("tyhor", C.c_double), ("tyver", C.c_double),
-                ("mux", C.c_double), ("muy", C.c_double), ("accRatio", C.c_double), ("cdwU", C.c_double)]
+                ("mux", C.c_double), ("muy", C.c_double), ("accRatio", C.c_double), ("cdwU", C.c_double),
+                ("tuning", dqmc_tuning)]
 
 
 class dqmc_update_state(C.Structure):
@@ -62,7 +74,8 @@ class detsdw_params(C.Structure):
                 ("accRatio", C.c_double), ("cdwU", C.c_double),
                 ("stabilisation", C.c_int32), ("cb_none", C.c_int32),
                 ("wolffClusterUpdate", C.c_int32), ("wolffClusterShiftUpdate", C.c_int32),
-                ("repeatWolffPerSweep", C.c_int32), ("fermionMeasurements", C.c_int32)]
+                ("repeatWolffPerSweep", C.c_int32), ("fermionMeasurements", C.c_int32),
+                ("tuning", dqmc_tuning)]
 
 
 class detsdw_info(C.Structure):
@@ -142,6 +155,7 @@ SYMBOLS = [
     ("dqmc_push_uniforms_host", C.c_int, [_P, _DP, C.c_size_t]),
     ("dqmc_push_uniforms_all_host", C.c_int, [_P, _DP, C.c_size_t]),
     ("dqmc_update_slice", C.c_int, [_P, C.c_int, C.c_int]),
+    ("dqmc_get_schedule_info", C.c_int, [_P, C.POINTER(dqmc_schedule_info)]),
     ("dqmc_get_update_states_all_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),
     ("dqmc_get_update_state_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),
     ("dqmc_set_update_state_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),

@@ -9,7 +9,6 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include <atomic>
 
 void build_tournament(int nblk, std::vector<int>& out);   // kernels_svd.hip
 
@@ -45,8 +44,11 @@ struct dqmc_ctx {
     hipStream_t st2 = nullptr;
     hipEvent_t ev_win = nullptr, ev_flush = nullptr;
     cplx* Gwin = nullptr;          // (MSF pbudget)^2: the next block's proposal window of G (k_update_window)
-    int pipe_P = 0;                // pbudget when the pipeline is possible, else 0
-    int pipe_mode = 0;             // 1: always (DQMC_PIPELINE=1), 2: automatic (n_g > 1024 and at most two live contexts in the process)
+    int pipe_P = 0;                // pbudget when the pipelined schedule is in effect, else 0
+    bool pipelined = false;        // latched at dqmc_create (dqmc_tuning::pipeline, n_g, chains): nothing else decides the schedule
+    uint64_t blocks_pipelined = 0, blocks_sequential = 0, cholqr_fallbacks = 0;
+    bool qr_bgs = false, green_lu = false;       // latched at dqmc_create (dqmc_tuning::qr_variant / green_variant)
+    std::vector<int> err_host;     // scratch of chol_failed()
     // batched chains: nb chains in lockstep; per-chain buffers of chain b = chain 0's + b * cs (one arena)
     Launch lc{nullptr, 1, 0};
     int nb = 1, sel = 0;                // sel: chain the host-buffer entry points talk to (dqmc_select_chain)
@@ -114,6 +116,10 @@ static const char* const kFamName[FAM_COUNT] = {"k_bmult_chain / site-local V", 
 static int finish(dqmc_ctx* c, const char* entry) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && sync_check_on()) e = hipStreamSynchronize(c->st);
+    if (e == hipSuccess && sync_check_on() && c->pipelined) {      // the flushes of a pipelined update run on the second stream
+        e = hipStreamSynchronize(c->st2);
+        if (e != hipSuccess && c->fault.empty()) c->fault = std::string("k_flush (second stream) (") + hipGetErrorString(e) + ")";
+    }
     if (e == hipSuccess && c->fault.empty()) return DQMC_OK;
     std::string msg = std::string(entry) + ": " + (e != hipSuccess ? hipGetErrorString(e) : "GPU fault");
     if (!c->fault.empty()) msg += " in " + c->fault;
@@ -167,11 +173,11 @@ static hipError_t copy_sync(dqmc_ctx* c, void* dst, const void* src, size_t byte
 
 static void prof_collect(dqmc_ctx* c);
 enum { PROF_EVENT_CAP = 8192 };     // events alive at most: beyond that the finished pairs are collected and reused
-static std::atomic<int> g_live_contexts{0};      // kernel contexts alive in this process (the automatic pipelined update looks at it)
 
 struct ProfScope {
     dqmc_ctx* c; int fam; uint64_t launches; int idx = -1;     // idx: this scope's begin event (scopes may nest)
-    ProfScope(dqmc_ctx* c_, int fam_, uint64_t launches_) : c(c_), fam(fam_), launches(launches_) {
+    hipStream_t st;                                            // the stream the scope's kernels are launched on (c->st, or c->st2 for a pipelined flush)
+    ProfScope(dqmc_ctx* c_, int fam_, uint64_t launches_, hipStream_t st_ = nullptr) : c(c_), fam(fam_), launches(launches_), st(st_ ? st_ : c_->st) {
         c->fam_launches[fam] += launches;
         if (!c->prof) return;
         if (c->ev_used + 2 > PROF_EVENT_CAP && c->prof_depth == 0) prof_collect(c);   // not while an outer scope is open
@@ -180,18 +186,18 @@ struct ProfScope {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
         }
         idx = (int)c->ev_used;
-        (void)hipEventRecord(c->ev_pool[idx], c->st);
+        (void)hipEventRecord(c->ev_pool[idx], st);
         c->ev_open.push_back({fam, idx});
         c->ev_used += 2;
     }
     ~ProfScope() {
         if (sync_check_on() && c->fault.empty()) {
             hipError_t e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(c->st);
-            if (e != hipSuccess) c->fault = std::string(kFamName[fam]) + " (" + hipGetErrorString(e) + ")";
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) c->fault = std::string(kFamName[fam]) + (st == c->st ? "" : " (second stream)") + " (" + hipGetErrorString(e) + ")";
         }
         if (idx < 0) return;
-        (void)hipEventRecord(c->ev_pool[idx + 1], c->st);
+        (void)hipEventRecord(c->ev_pool[idx + 1], st);
         --c->prof_depth;
     }
 };
@@ -503,7 +509,6 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     HIPCHK(hipSetDevice(p->device));
 
     dqmc_ctx* c = new dqmc_ctx();
-    g_live_contexts.fetch_add(1);           // dqmc_destroy takes it back (also on the failure path below)
     c->p = *p;
     c->nb = nchains;
     c->N = N; c->MSF = MSF; c->n_g = ng; c->m = p->m; c->s = p->s; c->D = p->delaySteps;
@@ -530,7 +535,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     // accRatio = 0.5), never below it (dqmc_update_slice launches ceil(N / D) rounds); DQMC_PROPOSAL_BUDGET overrides, 0 = no limit.
     // Shallow blocks (woodbury / iterative: D = 1) gain nothing from it.
     hm.pbudget = p->delaySteps >= 8 ? 2 * p->delaySteps : 0;
-    if (getenv("DQMC_PROPOSAL_BUDGET")) hm.pbudget = atoi(getenv("DQMC_PROPOSAL_BUDGET"));
+    if (p->tuning.proposal_budget != 0) hm.pbudget = p->tuning.proposal_budget < 0 ? 0 : p->tuning.proposal_budget;
     if (hm.pbudget > 0 && hm.pbudget < p->delaySteps) hm.pbudget = p->delaySteps;
 #ifdef DQMC_DECIDE_TIMING
     hm.dbg = (getenv("DQMC_DECIDE_TIMING") && atoi(getenv("DQMC_DECIDE_TIMING"))) ? 8 : 0;   // phase timers of k_update_decide; never changes a result
@@ -624,8 +629,11 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
         c->sw.rounds = d_rounds; c->sw.nrounds = nblk - 1; c->sw.nblk = nblk;
     }
     c->stab = p->stabilisation;
-    // test hook: a sweep budget the Jacobi SVD cannot meet makes the "SVD failed" path (udv.h:77-88 in the reference) reachable
-    if (getenv("DQMC_MAX_JACOBI_SWEEPS")) c->max_jacobi_sweeps = atoi(getenv("DQMC_MAX_JACOBI_SWEEPS"));
+    // a sweep budget the Jacobi SVD cannot meet makes the "SVD failed" path (udv.h:77-88 in the reference) reachable
+    if (p->tuning.max_jacobi_sweeps > 0) c->max_jacobi_sweeps = p->tuning.max_jacobi_sweeps;
+    // n_g > 1024: block Gram-Schmidt + Cholesky-QR2 on the GEMM kernel instead of 144 tall Householder panels (kernels_qr.hip)
+    c->qr_bgs = p->tuning.qr_variant == 2 || (p->tuning.qr_variant == 0 && ng > 1024);
+    c->green_lu = ng <= 512 && p->tuning.green_variant != 1;
     if (c->stab == DQMC_STAB_QR) {
         const int np = (ng + 15) / 16;
         A_(dalloc(c, &c->qw.V, n2)); A_(dalloc(c, &c->qw.T, (size_t)np * 2 * 256));
@@ -639,21 +647,22 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     const int WD = MSF * c->D;
     const int WD8 = (WD + 7) & ~7;          // X and GrT are zero padded to a multiple of 8 columns for the flush kernel
     A_(dalloc(c, &c->X, (size_t)ng * WD8)); A_(dalloc(c, &c->Gr, (size_t)WD8 * ng)); A_(dalloc(c, &c->W, (size_t)WD * WD));
-    {   // Pipelined updates (see dqmc_update_slice) need a bounded proposal window (pbudget) small enough for a compact copy.  OFF by
-        // default: measured on MI355X (round 3) the decisions of block b + 1 do overlap the flush of block b (88 % of their time,
-        // rocprofv3 time line), but the flush slows down next to them (165 -> 215 us), the window kernel and two cross-stream waits
-        // per block add ~ 35 us, and the next gather still waits for the flush: 307 vs 343 us per block for one context alone and no
-        // gain per sweep (213 vs 216 sweeps/s), while four contexts lose their overlap with each other (250 vs 285) and a single chain
-        // pays the extra launches (5.6 vs 6.2).  DQMC_PIPELINE=1 switches it on (tests keep both orders on the reference's chain).
-        // Where it does pay: n_g = 2304 (config 5), where the flush is three quarters of an HBM-bound block and few contexts share
-        // the GPU -- 8 chains in one context 1.29 -> 1.40 sweeps/s, in two contexts 1.47 -> 1.56; 32 chains in four contexts lose again
-        // (1.83 -> 1.72).  So: automatic for n_g > 1024 while at most two contexts of this process are alive; DQMC_PIPELINE=0 / 1 forces.
-        const char* ev = getenv("DQMC_PIPELINE");
-        const int mode = ev ? (atoi(ev) == 1 ? 1 : 0) : ((ng > 1024 && c->nb >= 2) ? 2 : 0);       // a single chain loses 2 % (0.462 -> 0.452)
-        if (mode && p->model == DQMC_MODEL_SDW && hm.pbudget > 0 && MSF * hm.pbudget <= 512) {
-            c->pipe_mode = mode;
+    {   // Pipelined updates (see dqmc_update_slice) need a bounded proposal window (pbudget) small enough for a compact copy.
+        // Measured on MI355X (round 3): at the headline size the decisions of block b + 1 do overlap the flush of block b (88 % of
+        // their time), but the flush slows down next to them (165 -> 215 us), the window kernel and two cross-stream waits per block
+        // add ~ 35 us, and the next gather still waits for the flush: no gain per sweep for one context (213 vs 216 sweeps/s), a loss
+        // for four overlapping contexts (250 vs 285) and for a single chain (5.6 vs 6.2).  Where it pays: n_g = 2304 (config 5), where
+        // the flush is three quarters of an HBM-bound block -- 8 chains in one context 1.29 -> 1.40 sweeps/s, in two contexts 1.47 ->
+        // 1.56.  So automatic means n_g > 1024 with at least two chains; the decision is latched HERE, from the parameters alone
+        // (callers that drive many contexts at once pass pipeline = -1, host/detsdw.cpp).
+        const int want = p->tuning.pipeline;
+        const bool on = want > 0 || (want == 0 && ng > 1024 && c->nb >= 2);
+        if (on && p->model == DQMC_MODEL_SDW && hm.pbudget > 0 && MSF * hm.pbudget <= 512) {
+            c->pipelined = true;
             c->pipe_P = hm.pbudget;
-            A_(dalloc(c, &c->Gwin, (size_t)MSF * hm.pbudget * MSF * hm.pbudget));
+            // one spare column: the decision kernel's look-ahead never fetches past the window (kernels_update.hip), the spare column
+            // keeps even a stray address inside this buffer
+            A_(dalloc(c, &c->Gwin, (size_t)MSF * hm.pbudget * (MSF * hm.pbudget + 1)));
         }
     }
     c->uni_cap = (size_t)(p->opdim + 1 + (p->cdwU != 0.0 ? 2 : 0)) * N * p->m + 64;     // one sweep's worst case (+ the cdwl pass)
@@ -665,7 +674,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     A_(dalloc(c, &c->macc, c->macc_n));
     A_(arena_commit(c));                    // from here on the per-chain pointers are real (chain 0) addresses, zero filled
 #undef A_
-    c->qw.err = &c->us->pub.error;
+    c->qw.err = &c->us->chol_fail;
     hm.phi = c->phi; hm.coshT = c->coshT; hm.sinhT = c->sinhT;
     if (p->cdwU != 0.0) {
         // cdwl_eta / cdwl_gamma (detsdwopdim.h:1209-1235), getCoshSinhTermCDWl (detsdwopdim.cpp:1138-1143)
@@ -696,7 +705,6 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
 
 extern "C" void dqmc_destroy(dqmc_ctx* c) {
     if (!c) return;
-    g_live_contexts.fetch_sub(1);
     (void)hipSetDevice(c->p.device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     for (void* q : c->allocs) (void)hipFree(q);
@@ -904,6 +912,19 @@ static int udv_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
 // ---------------------------------------------------------------------------------------------
 enum { KIND_R = 0, KIND_L = 1 };
 
+// Did a Cholesky-QR panel of the factorisation just enqueued fail its pivot test in any chain (k_chol64 sets DevUpdateState::chol_fail)?
+// Waits for the stream; clears the flags.
+static int chol_failed(dqmc_ctx* c, int* failed) {
+    c->err_host.assign((size_t)c->nb, 0);
+    int* flag = &c->us->chol_fail;
+    HIPCHK(hipMemcpy2DAsync(c->err_host.data(), sizeof(int), flag, c->lc.cs, sizeof(int), (size_t)c->nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    *failed = 0;
+    for (int b = 0; b < c->nb; ++b) if (c->err_host[b]) *failed = 1;
+    if (*failed) HIPCHK(hipMemset2DAsync(flag, c->lc.cs, 0, sizeof(int), (size_t)c->nb, c->st));
+    return DQMC_OK;
+}
+
 // lazy != 0: the non-unitary factor T^H = (D^-1 R P^T)^H is not formed; R stays in sw.A, 1/d and the inverse permutation
 // go to qr_dinv / qr_perm_inv for the triangular chaining product of decompose_chained
 static int udt_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const double* rowscale, int kind, UdVSlot out, int lazy = 0) {
@@ -916,8 +937,22 @@ static int udt_dev(dqmc_ctx* c, const cplx* M, const double* colscale, const dou
     cplx* Tt = transpose ? out.U : out.Vt;
     SvdProfHooks hk;
     c->qw.apply_hooks = qr_hooks(c, hk);
-    // n > 1024: block Gram-Schmidt + Cholesky-QR2 on the GEMM kernel instead of 144 tall Householder panels (kernels_qr.hip)
-    int launches = qr_use_bgs(n) ? run_qr_bgs(c->lc, n, c->sw.A, Q, c->qw) : run_qr(c->lc, n, c->sw.A, Q, c->qw);
+    // n > 1024: block Gram-Schmidt + Cholesky-QR2 on the GEMM kernel instead of 144 tall Householder panels (kernels_qr.hip).  A panel
+    // too ill conditioned for Cholesky-QR (pivot test in k_chol64) is not an error: the factorisation is redone right here with the
+    // unconditionally stable Householder panels, for all chains of the context (one stream synchronisation per factorisation,
+    // which at these sizes takes tens of milliseconds).
+    int launches;
+    if (c->qr_bgs) {
+        launches = run_qr_bgs(c->lc, n, c->sw.A, Q, c->qw);
+        int failed = 0;
+        { int rc = chol_failed(c, &failed); if (rc) return rc; }
+        if (failed) {
+            c->cholqr_fallbacks += 1;
+            qr_reset_workspace(c->lc, n, c->qw);
+            launch_udt_init(c->lc, M, n, colscale, rowscale, c->qr_perm, transpose, c->sw.A, n);
+            launches += 3 + run_qr(c->lc, n, c->sw.A, Q, c->qw);
+        }
+    } else launches = run_qr(c->lc, n, c->sw.A, Q, c->qw);
     launch_udt_diag(c->lc, c->sw.A, n, out.d);
     if (lazy) launch_udt_lazy(c->lc, out.d, c->qr_perm, n, c->qr_dinv, c->qr_perm_inv);
     else launch_udt_tmat(c->lc, c->sw.A, out.d, c->qr_perm, n, Tt);
@@ -943,9 +978,8 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
     gemm_dev(c, 1, 0, R.Vt, L.U, c->T2, nullptr, 0, c->rmin, c->lmin, 1);
     // Z^-1 from an LU factorisation with partial pivoting (kernels_lu.hip; n_g <= 512): P Z = L U, so
     //   G = [(V_l Dlmax^-1) U^-1] [L^-1 P Drmax^-1 U_r^H] = T3 T1^H  with  T1 = (U_r Drmax^-1 P^T) L^-H,
-    // both brackets as right-hand triangular solves.  DQMC_GREEN_QR=1 keeps the Householder route below (A/B, larger n_g).
-    static const bool force_qr = getenv("DQMC_GREEN_QR") && atoi(getenv("DQMC_GREEN_QR")) != 0;
-    if (n <= 512 && !force_qr) {
+    // both brackets as right-hand triangular solves.  dqmc_tuning::green_variant = 1 keeps the QR route below (A/B, larger n_g).
+    if (c->green_lu) {
         {
             ProfScope ps(c, FAM_JACOBI, 0);
             int launches = run_lu(c->lc, n, c->T2, c->qr_perm, c->lu_swaps, c->lu_tneg);                  // T2 = L \ U, qr_perm = row permutation
@@ -967,12 +1001,23 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
         SvdProfHooks hk;
         c->qw.apply_hooks = qr_hooks(c, hk);
         // the matrix inverted here is not a graded B-chain but the scale-split sum Z (entries O(1)); the block Gram-Schmidt QR holds
-        // on it as well (tests: every QR-mode fixture with DQMC_QR_BGS=1 DQMC_GREEN_QR=1, the reference's G at n_g = 2304); a panel
-        // that loses definiteness raises DQMC_ENOCONV.  DQMC_GREEN_BGS=0 keeps Householder panels for this one.
-        static const bool green_bgs = getenv("DQMC_GREEN_BGS") ? atoi(getenv("DQMC_GREEN_BGS")) != 0 : true;
-        const bool bgs = green_bgs && qr_use_bgs(n);
-        int launches = bgs ? run_qr_bgs(c->lc, n, c->sw.A, c->T4, c->qw)   // explicit Q in T4
-                           : run_qr(c->lc, n, c->sw.A, nullptr, c->qw);    // sw.A = R factor, Q stays in reflector form
+        // on it as well (tests: every QR-mode fixture with qr_variant = 2, green_variant = 1; the reference's G at n_g = 2304); a panel
+        // that fails the pivot test sends the factorisation to the Householder panels.
+        bool bgs = c->qr_bgs;
+        int launches = 0;
+        if (bgs) {
+            launches = run_qr_bgs(c->lc, n, c->sw.A, c->T4, c->qw);        // explicit Q in T4
+            int failed = 0;
+            { int rc = chol_failed(c, &failed); if (rc) return rc; }
+            if (failed) {
+                c->cholqr_fallbacks += 1;
+                bgs = false;
+                qr_reset_workspace(c->lc, n, c->qw);
+                launch_udt_init(c->lc, c->T2, n, nullptr, nullptr, c->qr_perm, 0, c->sw.A, n);
+                launches += 3;
+            }
+        }
+        if (!bgs) launches += run_qr(c->lc, n, c->sw.A, nullptr, c->qw);   // sw.A = R factor, Q stays in reflector form
         launch_permute_scale_cols(c->lc, L.Vt, c->lmax_inv, c->qr_perm, n, c->T3);
         launches += run_trsm_right_upper(c->lc, n, c->sw.A, c->T3, c->qw);   // T3 = (V_l Dlmax^-1 P) R^-1
         launch_logdet_vector(c->lc, c->sw.A, c->rmax_inv, c->lmax_inv, n, c->sv);
@@ -1194,8 +1239,7 @@ extern "C" int dqmc_get_update_states_all_host(dqmc_ctx* c, dqmc_update_state* o
     HIPCHK(hipMemcpy2DAsync(out, sizeof(dqmc_update_state), &c->us->pub, c->lc.cs, sizeof(dqmc_update_state), (size_t)c->nb, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     for (int b = 0; b < c->nb; ++b)
-        if (out[b].error) return fail(out[b].error, out[b].error == DQMC_ENOCONV ? "decomposition failed: Cholesky-QR panel lost definiteness (block Gram-Schmidt QR, n_g > 1024; DQMC_QR_BGS=0 selects Householder panels)"
-                                                                                   : "device ran out of pre-drawn uniforms");
+        if (out[b].error) return fail(out[b].error, "device ran out of pre-drawn uniforms");
     return DQMC_OK;
 }
 
@@ -1211,10 +1255,11 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     }
     const int rounds = (c->N + c->D - 1) / c->D;
     const int WD = c->MSF * c->D;
-    // Pipelined form (proposal budget set, no per-launch profiling): decide(b + 1) needs G only inside its proposal window, so the
-    // window kernel hands it a compact, already updated copy and the flush of block b over the whole of G runs on the second stream
-    // next to the decisions of block b + 1; gather(b + 1) waits for it.  The first block of a pass reads G itself.
-    const bool pipe = c->pipe_P > 0 && !c->prof && !sync_check_on() && (c->pipe_mode == 1 || g_live_contexts.load() <= 2);
+    // Pipelined form (latched at dqmc_create): decide(b + 1) needs G only inside its proposal window, so the window kernel hands it a
+    // compact, already updated copy and the flush of block b over the whole of G runs on the second stream next to the decisions of
+    // block b + 1; gather(b + 1) waits for it.  The first block of a pass reads G itself.  Profiling and DQMC_SYNC_CHECK keep the
+    // schedule: the flush is timed / checked on the stream it runs on.
+    const bool pipe = c->pipelined;
     Launch lc2 = c->lc; lc2.st = c->st2;
     auto pass = [&](int cdw_pass) -> int {
         for (int r = 0; r < rounds; ++r) {
@@ -1229,15 +1274,19 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
                 launch_update_gather(c->lc, c->hm, c->us, c->G, c->W, c->X, c->Gr);
             }
             if (pipe) {
-                launch_update_window(c->lc, c->hm, c->us, c->G, c->X, c->Gr, c->Gwin, c->pipe_P);
+                { ProfScope ps(c, FAM_OTHER, 1); launch_update_window(c->lc, c->hm, c->us, c->G, c->X, c->Gr, c->Gwin, c->pipe_P); }
                 HIPCHK(hipEventRecord(c->ev_win, c->st));
                 HIPCHK(hipStreamWaitEvent(c->st2, c->ev_win, 0));
-                c->fam_launches[FAM_FLUSH] += 1;
-                launch_flush(lc2, c->X, c->Gr, c->n_g, c->G, c->n_g, c->n_g, WD, &c->us->flush_k, 1);
+                {
+                    ProfScope ps(c, FAM_FLUSH, 1, c->st2);
+                    launch_flush(lc2, c->X, c->Gr, c->n_g, c->G, c->n_g, c->n_g, WD, &c->us->flush_k, 1);
+                }
                 HIPCHK(hipEventRecord(c->ev_flush, c->st2));
+                c->blocks_pipelined += 1;
             } else {
                 ProfScope ps(c, FAM_FLUSH, 1);
                 launch_flush(c->lc, c->X, c->Gr, c->n_g, c->G, c->n_g, c->n_g, WD, &c->us->block_j, c->MSF);
+                c->blocks_sequential += 1;
             }
         }
         if (pipe) HIPCHK(hipStreamWaitEvent(c->st, c->ev_flush, 0));                     // whatever comes next on the main stream sees the flushed G
@@ -1248,6 +1297,19 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     // discarded there and here (no step-width adaptation)
     if (c->hm.cdw_on) { int rc = pass(1); if (rc) return rc; }
     return finish(c, "dqmc_update_slice");
+}
+
+extern "C" int dqmc_get_schedule_info(dqmc_ctx* c, dqmc_schedule_info* out) {
+    if (!c || !out) return fail(DQMC_EINVAL, "null argument");
+    memset(out, 0, sizeof(*out));
+    out->pipelined = c->pipelined ? 1 : 0;
+    out->proposal_budget = c->hm.pbudget;
+    out->blocks_pipelined = c->blocks_pipelined;
+    out->blocks_sequential = c->blocks_sequential;
+    out->qr_block_gram_schmidt = (c->stab == DQMC_STAB_QR && c->qr_bgs) ? 1 : 0;
+    out->green_lu = (c->stab == DQMC_STAB_QR && c->green_lu) ? 1 : 0;
+    out->cholqr_fallbacks = c->cholqr_fallbacks;
+    return DQMC_OK;
 }
 
 extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
@@ -1264,7 +1326,7 @@ extern "C" int dqmc_get_update_state_host(dqmc_ctx* c, dqmc_update_state* out) {
     }
 #endif
     HIPCHK(copy_sync(c, out, &selp(c, c->us)->pub, sizeof(*out), hipMemcpyDeviceToHost));
-    if (out->error) return fail(out->error, out->error == DQMC_ENOCONV ? "decomposition failed: Cholesky-QR panel lost definiteness (block Gram-Schmidt QR)" : "device ran out of pre-drawn uniforms");
+    if (out->error) return fail(out->error, "device ran out of pre-drawn uniforms");
     return DQMC_OK;
 }
 extern "C" int dqmc_set_update_state_host(dqmc_ctx* c, const dqmc_update_state* in) {
@@ -1502,6 +1564,7 @@ extern "C" int dqmc_set_exchange_parameter(dqmc_ctx* c, double r) {
 // ---------------------------------------------------------------------------------------------
 static void prof_collect(dqmc_ctx* c) {
     (void)hipStreamSynchronize(c->st);
+    if (c->st2) (void)hipStreamSynchronize(c->st2);
     for (auto& o : c->ev_open) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_pool[o.second], c->ev_pool[o.second + 1]) == hipSuccess)

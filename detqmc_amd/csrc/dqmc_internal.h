@@ -5,6 +5,20 @@
 #include <stdint.h>
 #include "../../include/dqmc_hip.h"
 
+#include <stdlib.h>
+// Developer A/B switches of individual kernels (tile shapes, 3M vs 4M products, ...).  None changes a result.  They exist only in
+// builds with -DDQMC_DEV_KNOBS (DQMC_BUILD_DEFINES=-DDQMC_DEV_KNOBS python -m detqmc_amd.build --force); the shipped library reads
+// ONE environment variable, DQMC_SYNC_CHECK (debug mode, dqmc_context.hip) -- everything else that selects an execution variant is
+// a create-time parameter (dqmc_tuning, include/dqmc_hip.h).
+static inline const char* dev_knob(const char* name) {
+#ifdef DQMC_DEV_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 typedef double2 cplx;   // .x = re, .y = im; same bytes as dqmc_cplx / std::complex<double>
 
 #define DQMC_MAX_MSF 4
@@ -104,6 +118,7 @@ struct DevUpdateState {
     int block_j;             // accepted updates in the block the last decision launch produced
     int slice_done;
     int flush_k;             // K = MSF j of the block whose flush is in flight (pipelined update: block_j already belongs to the next block)
+    int chol_fail;           // set by k_chol64 when a Cholesky-QR panel fails its pivot test; read and cleared by the host after the factorisation
     double r;                // this chain's exchange parameter (differs between the chains of a batch)
     int block_sites[DQMC_MAX_WDIM];
     unsigned long long blocks_nonempty;  // delayed-update blocks that accepted at least one update (-> real flushes)
@@ -206,12 +221,12 @@ size_t measure_accum_doubles(int N, int L);
 
 // ---- QR / UDT building blocks (kernels_qr.hip) ------------------------------------------------
 struct SvdProfHooks;
-struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; const SvdProfHooks* apply_hooks; cplx* part; size_t part_count; int* err; };   // part: split-K scratch (n > 1024); err: per-chain error word (DevUpdateState::pub.error)   // hooks: optional timing of the k_qr_apply launches
+struct QrWork { cplx* V; cplx* T; cplx* W; cplx* W2; cplx* Rneg; const SvdProfHooks* apply_hooks; cplx* part; size_t part_count; int* err; };   // part: split-K scratch (n > 1024); err: per-chain failure flag of the Cholesky-QR panels (DevUpdateState::chol_fail)   // hooks: optional timing of the k_qr_apply launches
 int run_qr(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);                 // A -> R in place, Q explicit (Q == nullptr: reflectors only)
 int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans);
 // large n: QR by block Gram-Schmidt with reorthogonalisation + Cholesky-QR2 panels, all on the GEMM kernel (kernels_qr.hip); Q is always explicit
-bool qr_use_bgs(int n);
 int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);
+void qr_reset_workspace(const Launch& lc, int n, const QrWork& w);      // zero w.V / w.T before Householder panels follow a block Gram-Schmidt run
 int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w, int trans = 0, int unit = 0);   // C <- C R^-1 (trans: R = (stored lower triangle)^H; unit: unit diagonal)
 #define LU_SWAP_INTS 128
 int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps, cplx* tneg);    // tneg: scratch of n * 32 complex per chain                                 // P A = L U in place (n <= 512, else -1), kernels_lu.hip

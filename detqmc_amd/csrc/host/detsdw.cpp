@@ -136,6 +136,10 @@ DetSDW::DetSDW(const detsdw_params* in, int nchains, int sub_batches) {
     kp.mux = p.mux; kp.muy = p.muy; kp.accRatio = p.accRatio; kp.cdwU = p.cdwU;
     kp.stabilisation = p.stabilisation;
     kp.cb_none = p.cb_none ? 1 : 0;          // reference option checkerboard=false (DetSDW<CB_NONE, OPDIM>)
+    // result-neutral execution choices.  The pipelined update pays only while few contexts share the GPU (with more of them the
+    // contexts overlap each other instead): automatic here means at most two sub-batches.
+    kp.tuning = p.tuning;
+    if (kp.tuning.pipeline == 0 && S > 2) kp.tuning.pipeline = -1;
     groups_.resize(S);
     try {
         for (int g = 0; g < S; ++g) {

@@ -367,8 +367,8 @@ void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, 
     // 8 rows = one full 128-byte line of every column
     const size_t lds_cap = side == DQMC_LEFT ? 65536 : 144 * 1024;
     const int max_fit = (int)(lds_cap / ((size_t)ng * sizeof(cplx))) - (side == DQMC_LEFT ? 0 : 1);
-    static const int env_l = getenv("DQMC_BMULT_NVEC_L") ? atoi(getenv("DQMC_BMULT_NVEC_L")) : 0;   // developer knobs
-    static const int env_r = getenv("DQMC_BMULT_NVEC_R") ? atoi(getenv("DQMC_BMULT_NVEC_R")) : 0;
+    static const int env_l = dev_knob("DQMC_BMULT_NVEC_L") ? atoi(dev_knob("DQMC_BMULT_NVEC_L")) : 0;   // developer knobs
+    static const int env_r = dev_knob("DQMC_BMULT_NVEC_R") ? atoi(dev_knob("DQMC_BMULT_NVEC_R")) : 0;
     int nvec;
     if (side == DQMC_LEFT) {
         // aim at >= 256 workgroups, but give every thread a work item in the fused plaquette + V pass (nv P items, P = N / 4):
@@ -406,7 +406,7 @@ void launch_bmult(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, 
     }
     // 8-row tiles hold twice the work of a 4-row tile and leave room for two workgroups per CU: 512 threads keep the
     // number of resident waves (the only thing that hides the LDS / memory latency of this streaming kernel) the same
-    static const int env_t = getenv("DQMC_BMULT_THREADS_R") ? atoi(getenv("DQMC_BMULT_THREADS_R")) : 0;
+    static const int env_t = dev_knob("DQMC_BMULT_THREADS_R") ? atoi(dev_knob("DQMC_BMULT_THREADS_R")) : 0;
     const int nthreads = (side == DQMC_LEFT) ? 256 : (env_t ? env_t : (nvec >= 8 ? 512 : 256));
 #define LAUNCH(MSFV, R, I)                                                                              \
     do { if (hm.cdw_on) hipLaunchKernelGGL((k_bmult_chain<MSFV, R, I, true>), dim3(grid, 1, lc.nb), dim3(nthreads), lds, lc.st, hm, A, lda, nvec, \

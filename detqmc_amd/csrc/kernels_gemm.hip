@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, (FULL && STAGE == 1) ? 3 : 2) void k_flush(con
 
 // developer knob: DQMC_GEMM_4M=1 runs the 4-MFMA complex product (A/B measurements, rounding cross-checks)
 static bool use_4m() {
-    static const bool v = getenv("DQMC_GEMM_4M") && atoi(getenv("DQMC_GEMM_4M")) != 0;
+    static const bool v = dev_knob("DQMC_GEMM_4M") && atoi(dev_knob("DQMC_GEMM_4M")) != 0;
     return v;
 }
 
@@ -410,12 +410,12 @@ void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx
                   const int* Kdev, int Kmul, int tag) {
     const int tn = (n + 63) / 64;
     const dim3 grid = (lc.nb % 8 == 0) ? dim3(tn * tn * lc.nb, 1, 1) : dim3(tn * tn, 1, lc.nb);
-    static const bool force_ragged = getenv("DQMC_FLUSH_RAGGED") && atoi(getenv("DQMC_FLUSH_RAGGED")) != 0;   // developer knob (A/B)
+    static const bool force_ragged = dev_knob("DQMC_FLUSH_RAGGED") && atoi(dev_knob("DQMC_FLUSH_RAGGED")) != 0;   // developer knob (A/B)
     const bool full = n % 32 == 0 && !force_ragged;
-    static const int stage = getenv("DQMC_FLUSH_STAGE") ? atoi(getenv("DQMC_FLUSH_STAGE")) : 1;                 // developer knob (A/B)
+    static const int stage = dev_knob("DQMC_FLUSH_STAGE") ? atoi(dev_knob("DQMC_FLUSH_STAGE")) : 1;                 // developer knob (A/B)
 #define FLUSH_LAUNCH(M3_, FULL_, ST_) do { if (tag) hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_, 1>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb); \
                                            else hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_, 0>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb); } while (0)
-    static const bool flush_4m = getenv("DQMC_FLUSH_4M") && atoi(getenv("DQMC_FLUSH_4M")) != 0;               // developer knob (A/B): 4 MFMAs, 122 registers, 4 workgroups per CU
+    static const bool flush_4m = dev_knob("DQMC_FLUSH_4M") && atoi(dev_knob("DQMC_FLUSH_4M")) != 0;               // developer knob (A/B): 4 MFMAs, 122 registers, 4 workgroups per CU
     if (use_4m() || flush_4m) { if (full) FLUSH_LAUNCH(false, true, 1); else FLUSH_LAUNCH(false, false, 1); }
     else if (stage == 2) { if (full) FLUSH_LAUNCH(true, true, 2);  else FLUSH_LAUNCH(true, false, 2); }
     else          { if (full) FLUSH_LAUNCH(true, true, 1);  else FLUSH_LAUNCH(true, false, 1); }

@@ -268,7 +268,7 @@ int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps, cplx* tneg) 
         // the delayed-update flush, so it runs on k_flush (operand fragments straight from global memory, tile read late, three
         // workgroups per CU) instead of the LDS-staged k_zgemm, whose pipeline never fills at K = 32 (round 3: these launches moved
         // 2.0 TB/s, profiles/r03_pmc_traffic_b128_d32.json "gemm_in_factorisation"; DQMC_LU_GEMM=1 keeps the old route)
-        static const bool lu_gemm = getenv("DQMC_LU_GEMM") && atoi(getenv("DQMC_LU_GEMM")) != 0;
+        static const bool lu_gemm = dev_knob("DQMC_LU_GEMM") && atoi(dev_knob("DQMC_LU_GEMM")) != 0;
         if (rest > 0 && nbw == LU_NB && !lu_gemm) {
             launch_flush(lc, A + (size_t)j0 * n + (j0 + nbw), tneg, n, A + (size_t)(j0 + nbw) * n + (j0 + nbw), n, rest, nbw, nullptr, 1, /*tag=*/1);
             ++launches;

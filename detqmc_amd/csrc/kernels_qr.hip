@@ -871,9 +871,10 @@ int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const 
 // the column-EQUILIBRATED matrix -- a product of s = 10 slice matrices and a unitary factor, kappa ~ 10^2 - 10^3, far from the
 // 10^8 where Cholesky-QR's kappa^2 breaks down; the second pass of each stage restores orthogonality to rounding (BCGS2: Barlow &
 // Smoktunowicz 2013; CholQR2: Yamamoto et al. 2015).  Checked like the Householder path: tests/test_gpu_parity.py (Q unitary to
-// 1e-11, G against the reference's CPU construction at n_g = 2304 to 1e-10, DQMC_QR_BGS=1 forces it on the small fixtures).
+// 1e-11, G against the reference's CPU construction at n_g = 2304 to 1e-10, dqmc_tuning::qr_variant = 2 forces it on the small fixtures).
 // ---------------------------------------------------------------------------------------------
 #define BGS_NB 64
+#define CHOL_PIVOT_TOL 1e-12
 // Cholesky factor of the nb x nb Hermitian block at (j0, j0) of Gm (upper triangle read), R upper with R^H R = G written back in
 // place (strict lower part zeroed).  If R1m != nullptr its block at (j0, j0) is replaced by R R1 (second CholQR pass: R_jj = R2 R1).
 // One workgroup of four waves per chain, the block in LDS: thread (j, q) owns the rows i = q (mod 4) of column j; a step reads the
@@ -891,10 +892,14 @@ __global__ __launch_bounds__(256) void k_chol64(cplx* __restrict__ Gm, int ld, i
         if (R1m) s1[i][j] = in ? R1m[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
     }
     __syncthreads();
+    // Pivot test: the K-th pivot is the squared distance of column K from the span of the columns before it; relative to the
+    // column's own squared norm it is >= 1 / kappa^2 of the column-equilibrated panel.  Below CHOL_PIVOT_TOL (kappa > 10^6) the
+    // re-orthogonalising second pass can no longer be trusted to restore orthogonality to rounding (CholQR2 needs kappa^2 eps << 1):
+    // the panel is flagged -- also when the pivot is not positive at all -- and the host redoes the factorisation with Householder
+    // panels (udt_dev / green_qr, dqmc_context.hip).  Never papered over: the flag is per chain and counted (dqmc_get_schedule_info).
+    const double g_orig = (j < nb) ? s[j][j].x : 1.0;          // the thread of column j keeps its own diagonal entry (rows q == j mod 4 ... every q holds it)
     for (int K = 0; K < nb; ++K) {
-        // a pivot that is not positive: the Gram matrix has lost definiteness -- the panel is too ill conditioned for Cholesky-QR.
-        // Reported like a failed decomposition (reference: "SVD failed", udv.h:77-88), never papered over.
-        if (!(s[K][K].x > 0.0) && threadIdx.x == 0 && err) *err = DQMC_ENOCONV;
+        if (threadIdx.x == K && err && !(s[K][K].x > CHOL_PIVOT_TOL * g_orig)) *err = 1;
         const double d = sqrt(fmax(s[K][K].x, 1e-300)), id = 1.0 / d;
         if (j > K && j < nb) {
             const cplx rkj = make_double2(s[K][j].x * id, s[K][j].y * id);
@@ -943,9 +948,13 @@ __global__ void k_zero(cplx* __restrict__ A, size_t count, size_t cs) {
     CHAIN(A);
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < count; idx += (size_t)gridDim.x * blockDim.x) A[idx] = make_double2(0.0, 0.0);
 }
-bool qr_use_bgs(int n) {
-    static const int env = getenv("DQMC_QR_BGS") ? atoi(getenv("DQMC_QR_BGS")) : -1;      // 1 / 0: force on / off (tests, A/B)
-    return env >= 0 ? env != 0 : n > 1024;
+// The Householder kernels rely on the parts of w.V / w.T they never write being zero (the strict upper part of every reflector
+// panel, the padding of T); run_qr_bgs uses w.V as scratch.  Called before a Householder factorisation that follows a block
+// Gram-Schmidt one on the same workspace (the fallback of udt_dev / green_qr).
+void qr_reset_workspace(const Launch& lc, int n, const QrWork& w) {
+    const int np = (n + QR_NB - 1) / QR_NB;
+    hipLaunchKernelGGL(k_zero, dim3(1024, 1, lc.nb), dim3(256), 0, lc.st, w.V, (size_t)n * n, lc.cs);
+    hipLaunchKernelGGL(k_zero, dim3(64, 1, lc.nb), dim3(256), 0, lc.st, w.T, (size_t)np * 2 * QR_NB * QR_NB, lc.cs);
 }
 // A (n x n, ld n) -> R in place (upper triangular, positive diagonal), Q explicit (n x n); w.V is scratch.  Returns the launch count.
 int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {

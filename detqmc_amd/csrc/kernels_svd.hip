@@ -26,11 +26,11 @@
 #include <cstring>
 #include <vector>
 
-static const bool g_svd_debug = getenv("DQMC_DEBUG_SVD") != nullptr;
-static const int g_jacobi_npass = getenv("DQMC_JACOBI_NPASS") ? atoi(getenv("DQMC_JACOBI_NPASS")) : 1;
-static const bool g_jacobi_graph = getenv("DQMC_JACOBI_GRAPH") ? atoi(getenv("DQMC_JACOBI_GRAPH")) != 0 : false;  // off by default: no measured gain, and rocprofv3 (ROCm 7.2) crashes on replayed graphs
-static const int g_jacobi_transpose = getenv("DQMC_JACOBI_TRANSPOSE") ? atoi(getenv("DQMC_JACOBI_TRANSPOSE")) : -1;
-static const bool g_jacobi_sort = getenv("DQMC_JACOBI_SORT") ? atoi(getenv("DQMC_JACOBI_SORT")) != 0 : true;
+static const bool g_svd_debug = dev_knob("DQMC_DEBUG_SVD") != nullptr;
+static const int g_jacobi_npass = dev_knob("DQMC_JACOBI_NPASS") ? atoi(dev_knob("DQMC_JACOBI_NPASS")) : 1;
+static const bool g_jacobi_graph = dev_knob("DQMC_JACOBI_GRAPH") ? atoi(dev_knob("DQMC_JACOBI_GRAPH")) != 0 : false;  // off by default: no measured gain, and rocprofv3 (ROCm 7.2) crashes on replayed graphs
+static const int g_jacobi_transpose = dev_knob("DQMC_JACOBI_TRANSPOSE") ? atoi(dev_knob("DQMC_JACOBI_TRANSPOSE")) : -1;
+static const bool g_jacobi_sort = dev_knob("DQMC_JACOBI_SORT") ? atoi(dev_knob("DQMC_JACOBI_SORT")) != 0 : true;
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

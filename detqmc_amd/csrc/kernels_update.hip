@@ -371,7 +371,9 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         __syncthreads();                              // barrier 1 of 2: scalars, u, v (and last proposal's W update) visible
         TICK(1);
         // ---- C: start the loads of the NEXT candidate now; they complete while this decision is computed ----
-        const bool have_next = (site + 1 < N);
+        // not behind the last proposal of the budget: that candidate belongs to the next launch, and with a window copy (winP > 0)
+        // its entries lie outside the (MSF P)^2 window this launch may read
+        const bool have_next = (site + 1 < N) && (it + 1 < budget);
         if (have_next) fetch(pre, pu, pv, site + 1, site, cur + NPROP, nI);
         // ---- the waves split the work between the two barriers: wave 0 does the scalar Metropolis arithmetic of this
         //      proposal (D) and hands delta, exp(-dS), the acceptance uniform and G[c,c] to the others through LDS; waves

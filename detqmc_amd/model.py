@@ -62,6 +62,17 @@ class SDWParams:
     device: int = 0
     stabilisation: str = "svd"   # "svd": UdV = SVD like the reference; "qr": pre-pivoted Householder UDT
     checkerboard: bool = True    # False = CB_NONE: dense B_k = e^{-dtau V_k} e^{-dtau K} (reference option checkerboard=false)
+    # result-neutral execution choices (dqmc_tuning, include/dqmc_hip.h); 0 = automatic
+    pipeline: int = 0            # 1 / -1: pipelined delayed updates on / off
+    qrVariant: int = 0           # 1: Householder panels, 2: block Gram-Schmidt + Cholesky-QR2
+    greenVariant: int = 0        # 1: QR instead of LU inside greenFromUdV
+    maxJacobiSweeps: int = 0     # SVD mode: sweep budget of the Jacobi SVD (0 = 80)
+    proposalBudget: int = 0      # proposals per delayed-update block (-1: no limit)
+
+
+def _tuning(pipeline=0, qrVariant=0, greenVariant=0, maxJacobiSweeps=0, proposalBudget=0):
+    return _lib.dqmc_tuning(pipeline=int(pipeline), qr_variant=int(qrVariant), green_variant=int(greenVariant),
+                            max_jacobi_sweeps=int(maxJacobiSweeps), proposal_budget=int(proposalBudget))
 
 
 def _fmat(a):
@@ -74,12 +85,14 @@ class KernelContext:
 
     def __init__(self, opdim, L, m, s, dtau, delaySteps=16, bc="pbc", weakZflux=False, r=-1.0, c=3.0, u=1.0,
                  lambda_=1.0, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, mux=-0.5, muy=-0.5,
-                 accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd", checkerboard=True, nchains=1, cdwU=0.0):
+                 accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd", checkerboard=True, nchains=1, cdwU=0.0,
+                 pipeline=0, qrVariant=0, greenVariant=0, maxJacobiSweeps=0, proposalBudget=0):
         self.lib = load()
         p = _lib.dqmc_params(opdim=opdim, L=L, m=m, s=s, delaySteps=delaySteps, bc=BC[bc],
                              weakZflux=int(weakZflux), phi2bosons=int(phi2bosons), device=device,
                              stabilisation=STABILISATION[stabilisation], cb_none=int(not checkerboard), dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
-                             tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio, cdwU=cdwU)
+                             tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio, cdwU=cdwU,
+                             tuning=_tuning(pipeline, qrVariant, greenVariant, maxJacobiSweeps, proposalBudget))
         h = C.c_void_p()
         check(self.lib.dqmc_create_batch(C.byref(p), nchains, C.byref(h)))
         self.h = h
@@ -269,6 +282,12 @@ class KernelContext:
     def synchronize(self):
         check(self.lib.dqmc_synchronize(self.h))
 
+    def schedule_info(self):
+        """which execution variants this context latched at create time, and how many update blocks ran through each schedule"""
+        si = _lib.dqmc_schedule_info()
+        check(self.lib.dqmc_get_schedule_info(self.h, C.byref(si)))
+        return si
+
     def profile_enable(self, on=True):
         check(self.lib.dqmc_profile_enable(self.h, int(on)))
 
@@ -311,7 +330,8 @@ def _host_params(pars: SDWParams):
         mu=pars.mu, mux=pars.mux or 0.0, muy=pars.muy or 0.0, accRatio=pars.accRatio, cdwU=pars.cdwU,
         stabilisation=STABILISATION[pars.stabilisation], cb_none=int(not pars.checkerboard),
         wolffClusterUpdate=int(pars.wolffClusterUpdate), wolffClusterShiftUpdate=int(pars.wolffClusterShiftUpdate),
-        repeatWolffPerSweep=int(pars.repeatWolffPerSweep), fermionMeasurements=int(pars.fermionMeasurements))
+        repeatWolffPerSweep=int(pars.repeatWolffPerSweep), fermionMeasurements=int(pars.fermionMeasurements),
+        tuning=_tuning(pars.pipeline, pars.qrVariant, pars.greenVariant, pars.maxJacobiSweeps, pars.proposalBudget))
 
 
 class DetSDW:

@@ -56,6 +56,9 @@ typedef struct detsdw_params {
     int32_t repeatWolffPerSweep;      /* cluster flips per attempt, 0 is read as 1 */
     int32_t fermionMeasurements;      /* 1: sweep(takeMeasurements) also takes the G-dependent observables (the reference's
                                          default, i.e. turnoffFermionMeasurements = false); 0: bosonic observables only */
+    dqmc_tuning tuning;               /* result-neutral execution choices handed to every kernel context (dqmc_hip.h); all zero =
+                                         automatic.  With pipeline = 0 the host layer switches the pipelined update on only for
+                                         handles of at most two kernel contexts (more contexts overlap each other instead) */
 } detsdw_params;
 
 typedef struct detsdw_info {

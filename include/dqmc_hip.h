@@ -51,6 +51,24 @@ enum { DQMC_UP = +1, DQMC_DOWN = -1 };
 enum { DQMC_STAB_SVD = 0, DQMC_STAB_QR = 1 };
 enum { DQMC_MODEL_SDW = 0, DQMC_MODEL_HUBBARD = 1 };
 
+/* Execution choices that change NO result (the parity tests hold for every value); 0 = automatic everywhere.  They are
+ * create-time parameters of a context: nothing about a context's launch schedule depends on the environment or on other
+ * contexts of the process. */
+typedef struct dqmc_tuning {
+    int32_t pipeline;          /* delayed updates: the flush of block b on a second stream next to the decisions of block b + 1
+                                  (which read a compact, already updated copy of their proposal window).  0: automatic (n_g > 1024
+                                  and at least two chains), 1: on, -1: off.  dqmc_get_schedule_info tells what ran */
+    int32_t qr_variant;        /* QR mode, chain factorisations: 0 automatic (Householder panels up to n_g = 1024, block
+                                  Gram-Schmidt + Cholesky-QR2 above), 1: Householder, 2: block Gram-Schmidt */
+    int32_t green_variant;     /* QR mode, inverse inside greenFromUdV: 0 automatic (LU with partial pivoting for n_g <= 512,
+                                  QR above), 1: QR */
+    int32_t max_jacobi_sweeps; /* SVD mode: sweep budget of the one-sided Jacobi SVD, 0 = 80; exhausting it is DQMC_ENOCONV
+                                  ("SVD failed", udv.h:77-88) */
+    int32_t proposal_budget;   /* proposals per delayed-update block: 0 automatic (2 delaySteps for delaySteps >= 8), -1 no
+                                  limit, > 0 that many (at least delaySteps) */
+    int32_t reserved[3];
+} dqmc_tuning;
+
 /* ModelParamsDetSDW fields the kernels depend on (src/detsdwparams.h:24-120) */
 typedef struct dqmc_params {
     int32_t opdim;        /* 1, 2 or 3 */
@@ -76,6 +94,7 @@ typedef struct dqmc_params {
     double accRatio;      /* target acceptance for the box step adaptation */
     double cdwU;          /* != 0: the discrete field l_i(tau) in {+-1, +-2} next to phi (detsdwparams.h:61; evMatrix,
                              detsdwopdim.cpp:3187-3229); dqmc_update_slice then runs the cdwl pass behind the phi pass (:2474-2485) */
+    dqmc_tuning tuning;   /* all zero = automatic */
 } dqmc_params;
 
 /* AdjustmentData + slice bookkeeping that lives on the device between calls
@@ -163,6 +182,18 @@ int dqmc_push_uniforms_all_host(dqmc_ctx* ctx, const double* u, size_t n);
  * deltaSPhi :4186-4239, get_delta_forsite :3179-3289); thermalization != 0 adds the step-size
  * adaptation of updateInSliceThermalization (:3294-3375) */
 int dqmc_update_slice(dqmc_ctx* ctx, int k, int thermalization);
+/* Which schedule dqmc_update_slice runs for this context (latched at dqmc_create from dqmc_tuning::pipeline and the shape of the
+ * context) and how many delayed-update blocks have gone through each since dqmc_create. */
+typedef struct dqmc_schedule_info {
+    int32_t pipelined;              /* 1: flush on the second stream next to the next block's decisions; 0: strictly sequential */
+    int32_t proposal_budget;        /* proposals per block in effect (0: no limit) */
+    uint64_t blocks_pipelined;      /* decide / gather / flush rounds launched in the pipelined form */
+    uint64_t blocks_sequential;     /* ... in the sequential form */
+    int32_t qr_block_gram_schmidt;  /* 1: chain factorisations by block Gram-Schmidt + CholQR2, 0: Householder panels */
+    int32_t green_lu;               /* 1: inverse inside greenFromUdV by LU, 0: by QR */
+    uint64_t cholqr_fallbacks;      /* factorisations in which a CholQR panel lost definiteness and was redone with Householder panels */
+} dqmc_schedule_info;
+int dqmc_get_schedule_info(dqmc_ctx* ctx, dqmc_schedule_info* out);
 int dqmc_get_update_state_host(dqmc_ctx* ctx, dqmc_update_state* out);
 int dqmc_get_update_states_all_host(dqmc_ctx* ctx, dqmc_update_state* out /* [nchains] */);
 int dqmc_set_update_state_host(dqmc_ctx* ctx, const dqmc_update_state* in);

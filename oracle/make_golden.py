@@ -73,6 +73,20 @@ CASES = {
     "o2_L4_cdw_gshift": dict(args=dict(rngSeed=1018, opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=2, cdwU=0.5, globalShift=1, globalUpdateInterval=1,
                                        sliceTrace=0, weakZflux=1)),
     "o2_L4_cdw_dense": dict(args=dict(rngSeed=1007, opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=1, cdwU=0.5, checkerboard=0, sliceTrace=0)),
+    # round 4: flux / antiperiodic boundaries on an 8 x 8 lattice -- 16 plaquettes per subgroup, Landau-gauge phases e^{-+2 pi i zmag y}
+    # for y = 0 .. 7, the boundary-crossing vertical phase e^{+-2 pi i zmag L x} on 4 plaquettes per band (detsdwopdim.cpp:1598-1684),
+    # APBC sign flips on both boundary rows of plaquettes (:1809-1816), mu_x != mu_y; m = 23 with s = 10 (s does not divide m)
+    "o2_L8_flux": dict(args=dict(opdim=2, L=8, beta=2.3, s=10, delaySteps=12, sweeps=2, weakZflux=1, mux=-0.4, muy=-0.7, mu=-0.5),
+                       drop=("bdense", "init_coshTermPhi", "init_sinhTermPhi")),
+    "o2_L8_apbc_flux": dict(args=dict(opdim=2, L=8, beta=2, s=10, delaySteps=16, sweeps=2, weakZflux=1, bc="apbc-xy", r=0.5, c=2.0, u=0.7),
+                            drop=("bdense", "init_coshTermPhi", "init_sinhTermPhi")),
+    "o2_L8_apbc": dict(args=dict(opdim=2, L=8, beta=2, s=10, delaySteps=16, sweeps=2, bc="apbc-xy", mux=-0.4, muy=-0.7, mu=-0.5),
+                       drop=("bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi")),
+    "o2_L8_dense_flux": dict(args=dict(opdim=2, L=8, beta=2, s=10, delaySteps=16, sweeps=2, checkerboard=0, weakZflux=1, bc="apbc-y"),
+                             drop=("bchain_", "bmult_leftinv", "bmult_rightinv", "init_coshTermPhi", "init_sinhTermPhi", "slice_g_wrapped")),
+    "o2_L8_fmeas_apbc_flux": dict(args=dict(opdim=2, L=8, beta=2, s=10, delaySteps=16, sweeps=1, measureSweeps=1, fermionMeas=1,
+                                            sliceTrace=0, bc="apbc-y", weakZflux=1),
+                                  drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi", "init_udv")),
     "o1_L4": dict(args=dict(opdim=1, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
     "o3_L4": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
     # BASELINE config 2 (bring-up size): full G only at a few points

@@ -1,7 +1,7 @@
 """Developer check: the Markov chains of a batch with the LU-based Green's function (default) and with the Householder route
-(DQMC_GREEN_QR=1) must be the same chains.  The switch is read once per process, so the script is run twice and the records compared:
+(SDWParams.greenVariant = 1) must be the same chains.  Run twice and compare the records:
 
-    python scripts/check_lu_vs_qr.py 16 10 30 8 > lu.txt;  DQMC_GREEN_QR=1 python scripts/check_lu_vs_qr.py 16 10 30 8 > qr.txt
+    python scripts/check_lu_vs_qr.py 16 10 30 8 > lu.txt;  python scripts/check_lu_vs_qr.py 16 10 30 8 qr > qr.txt
     python scripts/check_lu_vs_qr.py --compare lu.txt qr.txt
 
 Per sweep and chain: SHA-256 of the field, accepted / attempted global shifts (their decision uses log det from diag U resp. diag R)
@@ -25,7 +25,9 @@ if sys.argv[1] == "--compare":
 
 from detqmc_amd import DetSDWBatch, SDWParams
 L, beta, nsw, B = int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-p0 = SDWParams(opdim=2, L=L, beta=beta, s=10, delaySteps=32, stabilisation="qr", globalShift=True, globalUpdateInterval=3)
+green_variant = 1 if (len(sys.argv) > 5 and sys.argv[5] == "qr") else 0
+p0 = SDWParams(opdim=2, L=L, beta=beta, s=10, delaySteps=32, stabilisation="qr", globalShift=True, globalUpdateInterval=3,
+               greenVariant=green_variant)
 batch = DetSDWBatch([dataclasses.replace(p0, simindex=b, r=p0.r + 0.02 * b) for b in range(B)], sub_batches=1)
 for sw in range(nsw):
     batch.sweepThermalization()

@@ -53,3 +53,18 @@ def relerr(a, b):
     a = np.asarray(a)
     b = np.asarray(b)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def relerr_blocks(a, b, bs=16, floor=1e-6):
+    """Block-wise relative error of two matrices: the largest, over all bs x bs blocks, of max|a - b| in the block divided by the
+    block's own scale max|b| (not below floor x the global scale).  relerr() above is relative to the largest entry of the whole
+    matrix, which for a Green's function sits on the diagonal: an error confined to the small far-off-diagonal blocks would pass it."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    n0, n1 = b.shape
+    p0, p1 = (-n0) % bs, (-n1) % bs
+    d = np.pad(np.abs(a - b), ((0, p0), (0, p1)))
+    s = np.pad(np.abs(b), ((0, p0), (0, p1)))
+    D = d.reshape(d.shape[0] // bs, bs, d.shape[1] // bs, bs).max(axis=(1, 3))
+    S = s.reshape(s.shape[0] // bs, bs, s.shape[1] // bs, bs).max(axis=(1, 3))
+    return float(np.max(D / np.maximum(S, floor * max(np.max(S), 1e-300))))

@@ -8,13 +8,18 @@ Nothing here reads /root/reference.
 import numpy as np
 import pytest
 
-from conftest import load_golden, oracle_params, relerr
+from conftest import load_golden, oracle_params, relerr, relerr_blocks
 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
 SMALL = ["o2_L4", "o2_L4_s7", "o2_L4_flux", "o2_L4_apbc", "o1_L4", "o3_L4", "o2_L6_seed",
          "o2_L4_dense", "o2_L4_dense_flux"]     # *_dense: checkerboard=false (CB_NONE)
+# round 4: flux / antiperiodic boundaries at L = 8 -- 16 plaquettes per subgroup, Landau-gauge phases for y = 0 .. 7, the
+# boundary-crossing vertical phases, APBC sign flips, mu_x != mu_y, s not dividing m, CB_NONE + flux
+# (/root/reference/src/detsdwopdim.cpp:1598-1684, 1788-1826)
+L8FLUX = ["o2_L8_flux", "o2_L8_apbc_flux", "o2_L8_dense_flux"]
+L8 = L8FLUX + ["o2_L8_apbc"]
 
 
 def _ctx_from_params(a, **over):
@@ -72,7 +77,7 @@ def test_gemm_all_ops(L):
 # ------------------------------------------------------------------------------------------------
 # checkerboard B-multiplies (a10-a14)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"])
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"] + L8FLUX)
 def test_bmult_vs_reference(name):
     from detsdw_oracle import make_test_matrix
     g = load_golden(name)
@@ -146,7 +151,7 @@ def test_udv_decompose(L, opdim):
 # ------------------------------------------------------------------------------------------------
 # stabilised Green's function from scratch and through advance / wrap (a3-a8)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"])
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"] + L8)
 def test_green_from_scratch_vs_reference(name):
     g = load_golden(name)
     ctx, op = _ctx_from_params(g["params"])
@@ -210,7 +215,7 @@ def test_wrap_advance_without_updates_vs_oracle(name):
 # ------------------------------------------------------------------------------------------------
 # local updates of one slice (a17-a20)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"])
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"] + L8)
 def test_update_slice_vs_reference(name):
     from dsfmt_oracle import RngWrapper
     g = load_golden(name)
@@ -229,6 +234,7 @@ def test_update_slice_vs_reference(name):
     phi, ch, sh = ctx.get_fields()
     assert np.array_equal(phi[op.m], g["slice_phi_m"]), "accept/reject decisions differ from the reference"
     assert relerr(ctx.g, g["slice_g"]) < TOL
+    assert relerr_blocks(ctx.g, g["slice_g"]) < 1e-9       # every 16 x 16 block on its own scale
     assert abs(st.lastAccRatio - g["slice_accRatio"][0]) < 1e-15
     assert st.ra_samplesAdded == 1
     # cosh/sinh caches consistent with the new field (reference consistencyCheck, detsdwopdim.cpp:4617-4667)
@@ -282,7 +288,7 @@ def test_rng_window_exhaustion_is_reported():
 # ------------------------------------------------------------------------------------------------
 # whole sweeps through the C++ host layer (a9) -- identical Markov chain as the reference
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5", "o2_L4_gshift"])
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5", "o2_L4_gshift"] + L8)
 def test_replica_trajectory_vs_reference(name):
     from detqmc_amd import DetSDW
     g = load_golden(name)
@@ -297,6 +303,7 @@ def test_replica_trajectory_vs_reference(name):
         rep.sweepThermalization()
         assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}: trajectory diverged"
         assert relerr(rep.g, g[f"sweep{i}_g"]) < TOL, f"sweep {i}"
+        assert relerr_blocks(rep.g, g[f"sweep{i}_g"]) < 1e-9, f"sweep {i}"
         assert relerr(rep.g_inv_sv, g[f"sweep{i}_g_inv_sv"]) < TOL
         inf = rep.info
         assert inf.phiDelta == g[f"sweep{i}_phiDelta"][0]
@@ -566,7 +573,7 @@ def test_qr_udt_decompose(L, opdim):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"])
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"] + L8)
 def test_qr_mode_green_from_scratch_vs_reference(name):
     g = load_golden(name)
     ctx, op = _ctx_from_params(g["params"], stabilisation="qr")
@@ -578,7 +585,7 @@ def test_qr_mode_green_from_scratch_vs_reference(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5", "o2_L4_gshift"])
+@pytest.mark.parametrize("name", SMALL + ["o2_L8_b5", "o2_L4_gshift"] + L8)
 def test_qr_mode_replica_trajectory_vs_reference(name):
     from detqmc_amd import DetSDW
     g = load_golden(name)
@@ -588,6 +595,7 @@ def test_qr_mode_replica_trajectory_vs_reference(name):
         rep.sweepThermalization()
         assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}: trajectory diverged"
         assert relerr(rep.g, g[f"sweep{i}_g"]) < TOL, f"sweep {i}"
+        assert relerr_blocks(rep.g, g[f"sweep{i}_g"]) < 1e-9, f"sweep {i}"
         assert abs(np.sum(np.log(rep.g_inv_sv)) - np.sum(np.log(g[f"sweep{i}_g_inv_sv"]))) < 1e-9 * rep.info.n_g
         inf = rep.info
         assert inf.phiDelta == g[f"sweep{i}_phiDelta"][0]
@@ -882,7 +890,7 @@ def test_measurement_sweeps_vs_reference(name, stab):
 # ------------------------------------------------------------------------------------------------
 # fermionic measurements on the device: shiftGreenSymmetric + G-dependent observables
 # ------------------------------------------------------------------------------------------------
-FMEAS = ["o2_L4_fmeas", "o2_L4_fmeas_apbc_flux", "o3_L4_fmeas", "o1_L4_fmeas"]
+FMEAS = ["o2_L4_fmeas", "o2_L4_fmeas_apbc_flux", "o3_L4_fmeas", "o1_L4_fmeas", "o2_L8_fmeas_apbc_flux"]
 
 
 @pytest.mark.parametrize("stab", ["svd", "qr"])
@@ -1289,10 +1297,9 @@ def test_replica_exchange_across_two_processes_with_real_chains(tmp_path):
 
 def test_decomposition_failure_is_reported_not_swallowed(monkeypatch):
     """udvDecompose throws "SVD failed" in the reference (src/udv.h:77-88); here the Jacobi SVD reports DQMC_ENOCONV through the
-    C ABI when it cannot converge within its sweep budget (budget forced to 1 through the test hook DQMC_MAX_JACOBI_SWEEPS)."""
+    C ABI when it cannot converge within its sweep budget (budget set to 1 through dqmc_tuning::max_jacobi_sweeps)."""
     from detqmc_amd import DqmcError, KernelContext, DetSDW, SDWParams
-    monkeypatch.setenv("DQMC_MAX_JACOBI_SWEEPS", "1")
-    ctx = KernelContext(2, 6, 20, 10, 0.1, delaySteps=4, stabilisation="svd")
+    ctx = KernelContext(2, 6, 20, 10, 0.1, delaySteps=4, stabilisation="svd", maxJacobiSweeps=1)
     rng = np.random.default_rng(1)
     M = rng.standard_normal((ctx.ng, ctx.ng)) + 1j * rng.standard_normal((ctx.ng, ctx.ng))
     with pytest.raises(DqmcError) as e:
@@ -1300,9 +1307,8 @@ def test_decomposition_failure_is_reported_not_swallowed(monkeypatch):
     assert e.value.code == -3 and "SVD failed" in str(e.value)
     ctx.close()
     with pytest.raises(DqmcError) as e2:           # the host layer turns it into the reference's GeneralError
-        DetSDW(SDWParams(opdim=2, L=6, beta=2.0, s=10, stabilisation="svd"))
+        DetSDW(SDWParams(opdim=2, L=6, beta=2.0, s=10, stabilisation="svd", maxJacobiSweeps=1))
     assert e2.value.code == -3
-    monkeypatch.delenv("DQMC_MAX_JACOBI_SWEEPS")
     ctx = KernelContext(2, 6, 20, 10, 0.1, delaySteps=4, stabilisation="svd")
     U, d, Vt, sweeps = ctx.udvDecompose(M)
     assert sweeps > 1 and relerr((U * d[None, :]) @ Vt.conj().T, M) < 1e-12
@@ -1366,9 +1372,9 @@ def test_device_phi_action_and_batched_transfers_vs_oracle():
 
 def test_lu_and_householder_green_functions_walk_the_same_chains(tmp_path):
     """greenFromUdV in QR mode inverts its scale-split matrix by LU with partial pivoting (kernels_lu.hip, n_g <= 512);
-    DQMC_GREEN_QR=1 keeps the Householder route of round 1 (and n_g > 512 uses it).  Both must give the chains the fixtures pin:
-    same fields, same global-move decisions (log det from diag U resp. diag R), same G -- the switch is read once per process, so two
-    child processes run scripts/check_lu_vs_qr.py (L = 8 with n_g = 128 = four 32-wide panels, L = 6 with n_g = 72: a ragged last one)."""
+    greenVariant = 1 (dqmc_tuning::green_variant) keeps the Householder route of round 1 (and n_g > 512 uses it).  Both must give the
+    chains the fixtures pin: same fields, same global-move decisions (log det from diag U resp. diag R), same G -- two child processes
+    run scripts/check_lu_vs_qr.py (L = 8 with n_g = 128 = four 32-wide panels, L = 6 with n_g = 72: a ragged last one)."""
     import os
     import subprocess
     import sys
@@ -1376,11 +1382,8 @@ def test_lu_and_householder_green_functions_walk_the_same_chains(tmp_path):
     for L, beta, sweeps in ((8, 10.0, 6), (6, 20.0, 4)):
         outs = []
         for force_qr in (False, True):
-            env = dict(os.environ)
-            env.pop("DQMC_GREEN_QR", None)
-            if force_qr:
-                env["DQMC_GREEN_QR"] = "1"
-            r = subprocess.run([sys.executable, script, str(L), str(beta), str(sweeps), "4"], env=env, capture_output=True, text=True, timeout=300)
+            r = subprocess.run([sys.executable, script, str(L), str(beta), str(sweeps), "4"] + (["qr"] if force_qr else []),
+                               capture_output=True, text=True, timeout=300)
             assert r.returncode == 0, r.stderr[-2000:]
             f = tmp_path / ("L%d_%s.txt" % (L, "qr" if force_qr else "lu"))
             f.write_text(r.stdout)
@@ -1392,23 +1395,15 @@ def test_lu_and_householder_green_functions_walk_the_same_chains(tmp_path):
 
 @pytest.mark.parametrize("name", ["o2_L8_b5", "o3_L6", "o2_L6_seed"])
 def test_pipelined_and_sequential_updates_walk_the_same_chain(name):
-    """dqmc_update_slice overlaps the flush of a delayed-update block with the decisions of the next one (the decisions read a compact,
-    already updated copy of their proposal window); DQMC_PIPELINE=0 (read at dqmc_create) keeps the strictly sequential order.  Both
-    must walk the chain of the reference fixture; between themselves: identical fields and RNG position, G to rounding."""
-    import os
+    """dqmc_update_slice can overlap the flush of a delayed-update block with the decisions of the next one (the decisions read a compact,
+    already updated copy of their proposal window; dqmc_tuning::pipeline = 1, latched at dqmc_create); pipeline = -1 keeps the strictly
+    sequential order.  Both must walk the chain of the reference fixture; between themselves: identical fields and RNG position, G to
+    rounding.  dqmc_get_schedule_info tells which schedule really ran."""
     from detqmc_amd import DetSDW
     g = load_golden(name)
     out = []
-    for pipeline in ("1", "0"):
-        old = os.environ.get("DQMC_PIPELINE")
-        os.environ["DQMC_PIPELINE"] = pipeline
-        try:
-            rep = DetSDW(_sdw_params(g["params"], stabilisation="qr"))
-        finally:
-            if old is None:
-                del os.environ["DQMC_PIPELINE"]
-            else:
-                os.environ["DQMC_PIPELINE"] = old
+    for pipeline in (1, -1):
+        rep = DetSDW(_sdw_params(g["params"], stabilisation="qr", pipeline=pipeline))
         i = 1
         while f"sweep{i}_phi" in g:
             rep.sweepThermalization()
@@ -1418,10 +1413,146 @@ def test_pipelined_and_sequential_updates_walk_the_same_chain(name):
             else:                                   # larger fixtures keep a sub-sampled G and its diagonal
                 assert relerr(np.diag(rep.g), g[f"sweep{i}_g_diag"]) < TOL
             i += 1
+        si = rep.kernel_context.schedule_info()
+        assert si.pipelined == (1 if pipeline == 1 else 0)
+        assert (si.blocks_pipelined > 0 and si.blocks_sequential == 0) if pipeline == 1 else (si.blocks_pipelined == 0 and si.blocks_sequential > 0)
         out.append((rep.phi, rep.g, rep.info.rngDrawn))
         rep.close()
     assert np.array_equal(out[0][0], out[1][0]) and out[0][2] == out[1][2]
     assert relerr(out[0][1], out[1][1]) < 1e-11
+
+
+def test_config5_auto_pipelined_batch_slice_vs_reference():
+    """The path `bench.py --config o3_L24_b20` times: a BATCH of config-5 replicas (n_g = 2304), for which dqmc_create switches the
+    pipelined delayed update on by itself (dqmc_tuning::pipeline = 0: n_g > 1024 and at least two chains) -- flush of block b on the
+    second stream, decisions of block b + 1 from the k_update_window copy (MSF = 4, 32-site window, 128 x 128 entries).  Chain 0 carries
+    the fixture's parameters: all 576 accept / reject decisions of the reference's ONE updateInSlice at n_g = 2304, the updated G and
+    the wrapped G (/root/reference/src/detsdwopdim.cpp:3023-3175, /root/reference/src/detmodel.h:1066-1095); dqmc_get_schedule_info
+    proves that the pipelined branch was the one that ran (36 blocks, none sequential)."""
+    import dataclasses
+    from detqmc_amd import DetSDWBatch
+    from dsfmt_oracle import RngWrapper
+    g = load_golden("o3_L24_b20_init")
+    p0 = _sdw_params(g["params"], stabilisation="qr")
+    pars = [p0, dataclasses.replace(p0, simindex=p0.simindex + 1, r=p0.r - 0.05)]
+    batch = DetSDWBatch(pars)
+    ctx = batch.kernel_context
+    si = ctx.schedule_info()
+    assert si.pipelined == 1 and si.qr_block_gram_schmidt == 1 and si.blocks_pipelined == 0 and si.blocks_sequential == 0
+    c0 = batch.chain(0)
+    assert np.array_equal(_sha_phi(c0.phi), g["init_phi_sha256"])
+    G = c0.g
+    assert relerr(G[::64, ::64], g["init_g_sub64"]) < TOL and relerr(np.diag(G), g["init_g_diag"]) < TOL
+    op = oracle_params(g["params"]).finalize()
+    m = op.m
+    for b, p in enumerate(pars):
+        r = RngWrapper(p.rngSeed, p.simindex + 1)
+        for _ in range((op.opdim + 1) * op.N * op.m):           # the draws that went into the random field
+            r.rand01()
+        ctx.select_chain(b)
+        ctx.push_uniforms(np.array([r.rand01() for _ in range((op.opdim + 1) * op.N)]))
+    ctx.updateInSlice(m, thermalization=True)
+    si = ctx.schedule_info()
+    assert si.blocks_pipelined == (op.N + op.delaySteps - 1) // op.delaySteps and si.blocks_sequential == 0
+    ctx.select_chain(0)
+    st = ctx.update_state()
+    assert np.array_equal(ctx.get_fields()[0][m], g["slice_phi_m"]), "accept / reject decisions of the pipelined batch differ from the reference"
+    assert abs(st.lastAccRatio - g["slice_accRatio"][0]) < 1e-15
+    Gs = ctx.g
+    assert relerr(Gs[::64, ::64], g["slice_g_sub64"]) < TOL and relerr(np.diag(Gs), g["slice_g_diag"]) < TOL
+    assert abs(np.linalg.norm(Gs) - g["slice_g_fro"][0]) < TOL * g["slice_g_fro"][0]
+    ctx.wrapDownGreen(m)
+    Gw = ctx.g
+    assert relerr(Gw[::64, ::64], g["slice_g_wrapped_sub64"]) < TOL and relerr(np.diag(Gw), g["slice_g_wrapped_diag"]) < TOL
+    assert abs(np.linalg.norm(Gw) - g["slice_g_wrapped_fro"][0]) < TOL * g["slice_g_wrapped_fro"][0]
+    # chain 1 went through the same launches with its own field and uniforms: its own single-replica twin, sequential schedule
+    ctx.select_chain(1)
+    phi1, G1 = ctx.get_fields()[0][m].copy(), ctx.g
+    batch.close()
+    from detqmc_amd import DetSDW
+    twin = DetSDW(dataclasses.replace(pars[1], pipeline=-1))
+    tctx = twin.kernel_context
+    assert tctx.schedule_info().pipelined == 0
+    r = RngWrapper(pars[1].rngSeed, pars[1].simindex + 1)
+    for _ in range((op.opdim + 1) * op.N * op.m):
+        r.rand01()
+    tctx.push_uniforms(np.array([r.rand01() for _ in range((op.opdim + 1) * op.N)]))
+    tctx.updateInSlice(m, thermalization=True)
+    assert np.array_equal(tctx.get_fields()[0][m], phi1)
+    tctx.wrapDownGreen(m)
+    assert relerr(tctx.g, G1) < 1e-11
+    twin.close()
+
+
+def test_headline_size_pipelined_vs_reference_checksums():
+    """The pipelined update schedule forced on at the headline size (dqmc_tuning::pipeline = 1, window copy of 64 sites x 2 bands)
+    against the reference's fixture: fields after two sweeps bit-identical, G checksums 1e-10."""
+    from detqmc_amd import DetSDW
+    g = load_golden("o2_L16_b10")
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr", delaySteps=32, pipeline=1))
+    for i in (1, 2):
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}"
+        G = rep.g
+        assert relerr(G[::16, ::16], g[f"sweep{i}_g_sub16"]) < TOL and relerr(np.diag(G), g[f"sweep{i}_g_diag"]) < TOL
+        assert rep.info.phiDelta == g[f"sweep{i}_phiDelta"][0]
+    si = rep.kernel_context.schedule_info()
+    assert si.pipelined == 1 and si.blocks_sequential == 0 and si.blocks_pipelined == 2 * 100 * 8
+    rep.close()
+
+
+@pytest.mark.parametrize("name", ["o2_L8_b5", "o3_L6", "o2_L8_apbc_flux", "o2_L4_gshift"])
+def test_block_gram_schmidt_qr_walks_the_reference_chains(name):
+    """The factorisation of config 5 (block Gram-Schmidt + Cholesky-QR2, automatic for n_g > 1024) forced on small lattices
+    (dqmc_tuning::qr_variant = 2) together with the QR route of the Green's function (green_variant = 1, what n_g > 512 uses):
+    same chains as the reference fixtures, no panel sent to the Householder fallback."""
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr", qrVariant=2, greenVariant=1))
+    si = rep.kernel_context.schedule_info()
+    assert si.qr_block_gram_schmidt == 1 and si.green_lu == 0
+    i = 1
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        assert np.array_equal(rep.phi[1:], _golden_phi(g, f"sweep{i}_phi")[1:]), f"sweep {i}: trajectory diverged"
+        if f"sweep{i}_g" in g:
+            assert relerr(rep.g, g[f"sweep{i}_g"]) < TOL
+        else:
+            assert relerr(np.diag(rep.g), g[f"sweep{i}_g_diag"]) < TOL
+        i += 1
+    assert rep.kernel_context.schedule_info().cholqr_fallbacks == 0
+    rep.close()
+
+
+def test_cholesky_qr_failure_falls_back_to_householder_panels():
+    """A panel too ill conditioned for Cholesky-QR (pivot test of k_chol64) is not an error and needs no restart: the factorisation
+    is redone inside the same call with Householder panels (udt_dev, dqmc_context.hip) and counted.  Matrix: 128 x 128 with two
+    column pairs that agree to 1e-9 (kappa of the column-equilibrated panel ~ 1e9, beyond what CholQR2 can orthogonalise).  The
+    result must be as good as the Householder variant's own: U unitary to rounding, U d V^H = M to 1e-12."""
+    from detqmc_amd import KernelContext
+    rng = np.random.default_rng(5)
+    n = 128
+    M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    M[:, 17] = M[:, 3] + 1e-9 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    # equal norms: the norm pre-pivoting puts each pair side by side, so at least one pair shares a 64-column panel
+    M[:, 90] = M[:, 77] * np.exp(0.7j) + 1e-9 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = {}
+    for variant in (2, 1):
+        ctx = KernelContext(2, 8, 20, 10, 0.1, delaySteps=8, stabilisation="qr", qrVariant=variant)
+        U, d, Vt, _ = ctx.udvDecompose(M)
+        si = ctx.schedule_info()
+        assert si.qr_block_gram_schmidt == (1 if variant == 2 else 0)
+        assert si.cholqr_fallbacks == (1 if variant == 2 else 0), "the ill-conditioned panel must be detected and redone"
+        assert relerr(U.conj().T @ U, np.eye(n)) < 1e-12
+        assert relerr((U * d[None, :]) @ Vt.conj().T, M) < 1e-12
+        out[variant] = (U * d[None, :]) @ Vt.conj().T
+        # a well-conditioned matrix right afterwards: no fallback, the flag was cleared
+        M2 = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        U2, d2, Vt2, _ = ctx.udvDecompose(M2)
+        assert ctx.schedule_info().cholqr_fallbacks == si.cholqr_fallbacks
+        assert relerr((U2 * d2[None, :]) @ Vt2.conj().T, M2) < 1e-12 and relerr(U2.conj().T @ U2, np.eye(n)) < 1e-12
+        ctx.close()
+    assert relerr(out[2], out[1]) < 1e-12
 
 
 def test_environment_cannot_change_the_markov_chain():

@@ -23,7 +23,11 @@ def test_rng_bit_exact():
         assert np.array_equal(mine, z[key]), key
 
 
-@pytest.fixture(scope="module", params=SMALL + ["o2_L8_b5"])
+# round 4: flux / antiperiodic boundaries at L = 8 (Landau-gauge phases for y = 0 .. 7, boundary-crossing plaquettes, CB_NONE + flux)
+L8 = ["o2_L8_flux", "o2_L8_apbc_flux", "o2_L8_apbc", "o2_L8_dense_flux"]
+
+
+@pytest.fixture(scope="module", params=SMALL + ["o2_L8_b5"] + L8)
 def case(request):
     g = load_golden(request.param)
     o = DetSDWOracle(oracle_params(g["params"]))
@@ -48,6 +52,8 @@ def test_init_field_and_green(case):
 
 def test_bmult(case):
     name, g, o = case
+    if "bmult_k" not in g:
+        pytest.skip("fixture keeps no B-multiply results")
     A = make_test_matrix(o.ng)
     k = int(g["bmult_k"][0])
     assert relerr(o.leftMultiplyBmat(A, k, k - 1), g["bmult_left"]) < 1e-13
@@ -199,7 +205,7 @@ def test_measurement_sweeps(name):
     assert j > 2
 
 
-@pytest.mark.parametrize("name", ["o2_L4_fmeas", "o2_L4_fmeas_apbc_flux", "o3_L4_fmeas", "o1_L4_fmeas"])
+@pytest.mark.parametrize("name", ["o2_L4_fmeas", "o2_L4_fmeas_apbc_flux", "o3_L4_fmeas", "o1_L4_fmeas", "o2_L8_fmeas_apbc_flux"])
 def test_fermionic_measurements(name):
     """shiftGreenSymmetric (detsdwopdim.cpp:4507-4612) and the G-dependent observables of measure / finishMeasurements
     (:545-899, :923-1015): greenK0, greenLocal, k-space occupation, pairing correlators, occDiffSq"""
