@@ -20,6 +20,7 @@
 // Workgroup = 4 waves in a 2x2 arrangement, each wave TMxTN MFMA tiles: 32x32 block tiles when
 // n_g = 512 (256 workgroups = one per CU), 64x64 for the large O(3) lattices.
 #include "dqmc_internal.h"
+#include <mutex>
 #include <algorithm>
 #include <cstdlib>
 
@@ -400,6 +401,129 @@ __global__ __launch_bounds__(256, (FULL && STAGE == 1) ? 3 : 2) void k_flush(con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: the flush with LDS-shared operand panels (n a multiple of 32).  The four waves of a workgroup (64 x 64 tile of G) used to
+// pull the SAME operand rows from the L2 twice each (8.9 TB/s of L2 -> CU traffic per launch against 4.4 TB/s of G traffic) and, having
+// to wait for fragment loads with the in-order vmcnt counter in every trip, could not have their tile of G in flight behind the MFMAs.
+// Now: the workgroup's panels X[64 rows, <= 32 k] and GrT[64 rows, <= 32 k] are copied ONCE into LDS by LDS-DMA (global_load_lds_dwordx4:
+// one wave-instruction = the 64 rows of one k = 1 KB contiguous on both sides, no staging registers), the tile of G is requested right
+// behind the first barrier -- the fragment reads of the MFMA loop are LDS reads (lgkmcnt), so the tile's loads (vmcnt) stay in flight
+// until the epilogue -- and K > 32 runs in phases of 32 through the same 64 KB (two workgroups per CU).  Same MFMAs in the same order as
+// k_flush: bit-identical G.  scripts/micro/flush_r4.hip, profiles/r04_flush_micro.log: 128 chains, n = 512, K ~ 2 Binomial(32, 0.47):
+// 214 -> 198 us per launch (5.0 -> 5.4 TB/s of read-modify-write traffic); K = 32: 216 -> 187 us; K = 56 / 64: 272 / 297 us, unchanged
+// (there the MFMA pipe binds).  Measured and dropped in the same harness: the tile requested behind the loop (no gain over k_flush: what
+// pays is the overlap, not the halved L2 traffic), two LDS buffers of 16 or 8 k with the next phase's DMA in flight (216 / 232 us: the
+// extra barriers cost more than the exposed DMA of a phase), all of K in LDS at one workgroup per CU (227 us).
+// ---------------------------------------------------------------------------------------------
+#define FLUSH_KH 32
+template<int TAG>
+__global__ __launch_bounds__(256, 2) void k_flush_lds(const cplx* __restrict__ X, const cplx* __restrict__ GrT, int ld,
+                                                       cplx* __restrict__ G, int ldc, int n, int Kmax, const int* __restrict__ Kdev,
+                                                       int Kmul, size_t cs, int nb) {
+    extern __shared__ cplx flush_sm[];            // Xs[FLUSH_KH][64], Gs[FLUSH_KH][64]
+    cplx* Xs = flush_sm;
+    cplx* Gs = flush_sm + FLUSH_KH * 64;
+    const int tn = (n + 63) / 64;
+    int chain, tile;
+    xcd_chain_tile(tn * tn, nb, chain, tile);
+    X = chain_ptr_i(X, cs, chain); GrT = chain_ptr_i(GrT, cs, chain); G = chain_ptr_i(G, cs, chain); Kdev = chain_ptr_i(Kdev, cs, chain);
+    int K = Kmax;
+    if (Kdev) { int kd = (*Kdev) * Kmul; K = kd < K ? kd : K; }
+    if (K <= 0) return;                                               // uniform over the workgroup
+    const int K8 = (K + 7) & ~7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ti = (tile % tn) * 64, tj = (tile / tn) * 64;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    // n = 32 (mod 64): the last tile row / column holds 32 valid rows -- the waves beyond them stage and meet the barriers, nothing else
+    const bool active = (ti + wi < n) && (tj + wj < n);
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int ri = min(ti + lane, n - 1), rj = min(tj + lane, n - 1);     // rows past n: a valid address, the values are never used
+    auto stage = [&](int kb, int kc) {
+        for (int kl = wave; kl < kc; kl += 4) {
+            const size_t k = (size_t)(kb + kl);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(X + k * ld + ri), (lds_ptr)(Xs + kl * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(GrT + k * ld + rj), (lds_ptr)(Gs + kl * 64), 16, 0, 0);
+        }
+    };
+    auto loadf = [&](int kl, cplx (&f)[4]) {
+        const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+        const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+        f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+    };
+    auto mac = [&](const cplx (&f)[4]) {
+        double asum[2], bsum[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+            }
+    };
+    cplx c[2][2][4];
+    cplx* base = G + (size_t)(tj + wj + l4) * ldc + ti + wi + l15;
+    for (int kb = 0; kb < K8; kb += FLUSH_KH) {
+        const int kc = min(FLUSH_KH, K8 - kb);
+        if (kb > 0) __syncthreads();              // everybody has read the previous phase's panels
+        stage(kb, kc);
+        __syncthreads();                          // the panels have landed (the barrier drains the LDS-DMA)
+        if (!active) continue;
+        if (kb == 0) {
+            // the tile of G: all 16 loads of the 32 x 32 sub-tile go out together, nontemporal (G is streamed once per launch and must
+            // not evict the operand panels of its chain from the L2); they are waited for in the epilogue only
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                        c[a][b][r].x = __builtin_nontemporal_load(&p->x); c[a][b][r].y = __builtin_nontemporal_load(&p->y);
+                    }
+        }
+        cplx s[4], t[4];
+        loadf(0, s);
+        for (int k0 = 0; k0 < kc; k0 += 8) {
+            loadf(k0 + 4, t);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(s);
+            __builtin_amdgcn_sched_barrier(0);
+            loadf(min(k0 + 8, kc - 4), s);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+            acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
+        }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y);
+            }
+}
+
 // developer knob: DQMC_GEMM_4M=1 runs the 4-MFMA complex product (A/B measurements, rounding cross-checks)
 static bool use_4m() {
     static const bool v = dev_knob("DQMC_GEMM_4M") && atoi(dev_knob("DQMC_GEMM_4M")) != 0;
@@ -416,6 +540,27 @@ void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx
 #define FLUSH_LAUNCH(M3_, FULL_, ST_) do { if (tag) hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_, 1>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb); \
                                            else hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_, 0>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb); } while (0)
     static const bool flush_4m = dev_knob("DQMC_FLUSH_4M") && atoi(dev_knob("DQMC_FLUSH_4M")) != 0;               // developer knob (A/B): 4 MFMAs, 122 registers, 4 workgroups per CU
+    static const bool flush_reg = dev_knob("DQMC_FLUSH_LDS") && atoi(dev_knob("DQMC_FLUSH_LDS")) == 0;            // developer knob (A/B): the register-fragment kernel of round 3
+    if (full && !use_4m() && !flush_4m && stage != 2 && !flush_reg) {
+        // LDS-shared operand panels; 64 KB of dynamic LDS: the attribute belongs to (function, device)
+        const size_t lds = (size_t)2 * FLUSH_KH * 64 * sizeof(cplx);
+        static std::mutex mu;
+        static bool raised[64][2] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            bool& r = raised[dev & 63][tag ? 1 : 0];
+            if (!r) {
+                const void* f = tag ? (const void*)k_flush_lds<1> : (const void*)k_flush_lds<0>;
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) r = true;
+                else (void)hipGetLastError();      // the launch below then reports the problem
+            }
+        }
+        if (tag) hipLaunchKernelGGL((k_flush_lds<1>), grid, dim3(256), lds, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb);
+        else     hipLaunchKernelGGL((k_flush_lds<0>), grid, dim3(256), lds, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb);
+        return;
+    }
     if (use_4m() || flush_4m) { if (full) FLUSH_LAUNCH(false, true, 1); else FLUSH_LAUNCH(false, false, 1); }
     else if (stage == 2) { if (full) FLUSH_LAUNCH(true, true, 2);  else FLUSH_LAUNCH(true, false, 2); }
     else          { if (full) FLUSH_LAUNCH(true, true, 1);  else FLUSH_LAUNCH(true, false, 1); }

@@ -466,11 +466,16 @@ def write_timeseries(router, directory, parameter_name, meta_model, meta_mc, met
                     f.write("%s\n" % num_to_string(float(row[i])))
 
 
-def write_config_infoheader(directory, meta_model, meta_mc, meta_pt):
-    """configs-phi.infoheader next to a configuration stream (src/detsdwsystemconfig.cpp:60-96)"""
+def write_config_infoheader(directory, meta_model, meta_mc, meta_pt, cdw=False):
+    """configs-phi.infoheader next to a configuration stream and, with cdwU != 0 (cdw = True), configs-l.infoheader next to the
+    stream of the discrete field (src/detsdwopdim.cpp:5073-5108)"""
     import os
-    with open(os.path.join(directory, "configs-phi.infoheader"), "w") as f:
-        for meta in (meta_model, meta_mc, meta_pt):
-            for k in sorted(meta):
-                f.write("#%s = %s\n" % (k, meta[k]))
-        f.write("## binary phi configuration stream (64 bit double precision floats) in file configs-phi.binarystream\n")
+    files = [("configs-phi.infoheader", "## binary phi configuration stream (64 bit double precision floats) in file configs-phi.binarystream\n")]
+    if cdw:
+        files.append(("configs-l.infoheader", "## binary l configuration stream (32 bit signed integers) in file configs-l.binarystream\n"))
+    for name, last in files:
+        with open(os.path.join(directory, name), "w") as f:
+            for meta in (meta_model, meta_mc, meta_pt):
+                for k in sorted(meta):
+                    f.write("#%s = %s\n" % (k, meta[k]))
+            f.write(last)

@@ -144,10 +144,15 @@ public:
     }
     void saveConfigurationStreamTextHeader(const std::string& simInfoHeaderText, const std::string& directory = ".") {
         writeHeader(directory, "configs-phi.textstream", simInfoHeaderText, "## phi configuration stream\n");
+        if (pars_.cdwU)                     // src/detsdwopdim.cpp:5055-5070
+            writeHeader(directory, "configs-l.textstream", simInfoHeaderText, "## l configuration stream\n");
     }
     void saveConfigurationStreamBinaryHeaderfile(const std::string& simInfoHeaderText, const std::string& directory = ".") {
         writeHeader(directory, "configs-phi.infoheader", simInfoHeaderText,
                     "## binary phi configuration stream (64 bit double precision floats) in file configs-phi.binarystream\n");
+        if (pars_.cdwU)                     // src/detsdwopdim.cpp:5092-5108
+            writeHeader(directory, "configs-l.infoheader", simInfoHeaderText,
+                        "## binary l configuration stream (32 bit signed integers) in file configs-l.binarystream\n");
     }
 
     // ---- replica-exchange surface (src/detsdwopdim.h:116-153), what DetQMCPT<Model> needs on top ----

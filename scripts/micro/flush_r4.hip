@@ -1,0 +1,593 @@
+// Developer microbenchmark (round 4): the delayed-update flush G += X GrT^T at the bench's shape -- 128 chains, n = 512, K per chain
+// drawn like the accepted-update count of a block (2 * Binomial(32, 0.47)), or fixed -- production kernel (register fragments straight
+// from global memory / L2, tile of G requested behind the MFMA loop) against LDS-shared operand panels:
+//   var 1: the workgroup's 64 x 64 tile shares ONE copy of its operand panels X[64 rows, K8], GrT[64 rows, K8] in LDS (each L2 byte
+//          fetched once per workgroup instead of twice), the tile of G is requested BEFORE the MFMA loop (fragment waits are lgkmcnt,
+//          the tile's vmcnt is only waited for in the epilogue) -- 2 workgroups per CU (64 KB of LDS each, K in halves of 32)
+//   var 2: var 1 with the tile requested behind the loop (separates the two effects)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/flush_r4.hip -o /tmp/flush_r4 && /tmp/flush_r4 [1 = random operands]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+typedef double2 cplx;
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__device__ __forceinline__ void chain_tile(int tiles, int nb, int& chain, int& tile) {
+    const int id = blockIdx.x, xcd = id & 7, t = id >> 3;
+    chain = (t / tiles) * 8 + xcd;
+    tile = t % tiles;
+}
+
+// ---- production kernel (k_flush<true, true, 1> of kernels_gemm.hip at the time of writing) ----
+__global__ __launch_bounds__(256, 3) void k_flush_prod(const cplx* __restrict__ X, const cplx* __restrict__ GrT, int ld,
+                                                        cplx* __restrict__ G, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb) {
+    const int tn = n / 64;
+    int chain, tile;
+    chain_tile(tn * tn, nb, chain, tile);
+    X += chain * cs; GrT += chain * cs; G += chain * cs;
+    const int K = Kdev[chain];
+    if (K <= 0) return;
+    const int K8 = (K + 7) & ~7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int i0 = (tile % tn) * 64 + (wave >> 1) * 32, j0 = (tile / tn) * 64 + (wave & 1) * 32;
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+    const int ia = i0 + l15, ia2 = ia + 16, jb = j0 + l15, jb2 = jb + 16;
+    const cplx* xa = X + (size_t)l4 * ld;
+    const cplx* gb = GrT + (size_t)l4 * ld;
+    auto loadf = [&](int k0, cplx (&f)[4]) {
+        const size_t o = (size_t)k0 * ld;
+        f[0] = xa[o + ia]; f[1] = xa[o + ia2]; f[2] = gb[o + jb]; f[3] = gb[o + jb2];
+    };
+    auto mac = [&](const cplx (&f)[4]) {
+        double asum[2], bsum[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+            }
+    };
+    {
+        cplx s[4], t[4];
+        loadf(0, s);
+        for (int k0 = 0; k0 < K8; k0 += 8) {
+            loadf(k0 + 4, t);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(s);
+            __builtin_amdgcn_sched_barrier(0);
+            loadf(min(k0 + 8, K8 - 4), s);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+            acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
+        }
+    cplx c[2][2][4];
+    cplx* base = G + (size_t)(j0 + l4) * ldc + i0 + l15;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                c[a][b][r].x = __builtin_nontemporal_load(&p->x); c[a][b][r].y = __builtin_nontemporal_load(&p->y);
+            }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y);
+            }
+}
+
+// ---- LDS-shared operand panels ----
+// EARLY: 1 = the tile of G is requested before the MFMA loop, 0 = behind it.  KH = k values staged per phase (32: 64 KB of LDS).
+template<int EARLY, int KH, int MINB, int SKEW = 0>
+__global__ __launch_bounds__(256, MINB) void k_flush_lds(const cplx* __restrict__ X, const cplx* __restrict__ GrT, int ld,
+                                                          cplx* __restrict__ G, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb) {
+    extern __shared__ cplx sm[];                  // Xs[KH][64], Gs[KH][64]
+    cplx* Xs = sm;
+    cplx* Gs = sm + KH * 64;
+    const int tn = n / 64;
+    int chain, tile;
+    chain_tile(tn * tn, nb, chain, tile);
+    X += chain * cs; GrT += chain * cs; G += chain * cs;
+    const int K = Kdev[chain];
+    if (K <= 0) return;
+    // SKEW: the second workgroup of every CU (dispatch order: ids 256 .. 511 of the first round) starts late, so that the two
+    // workgroups of a CU run out of phase -- one in its MFMA loop while the other waits for memory
+    if (SKEW > 0 && blockIdx.x >= 256 && blockIdx.x < 512) { for (int i = 0; i < SKEW; ++i) __builtin_amdgcn_s_sleep(32); }
+    const int K8 = (K + 7) & ~7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ti = (tile % tn) * 64, tj = (tile / tn) * 64;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+    // stage k values [kb, kb + kc) of both panels: item = (k, row), 64 consecutive rows = 1 KB contiguous in global memory and in LDS
+    auto stage = [&](int kb, int kc) {
+        // LDS-DMA (global_load_lds_dwordx4): one wave-instruction copies the 64 rows of one k value (1 KB contiguous in global memory)
+        // to 1 KB of LDS, lane = row; no staging registers
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+        for (int kl = wave; kl < kc; kl += 4) {
+            const size_t k = (size_t)(kb + kl);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(X + k * ld + ti + lane), (lds_ptr)(Xs + kl * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(GrT + k * ld + tj + lane), (lds_ptr)(Gs + kl * 64), 16, 0, 0);
+        }
+    };
+    auto loadf = [&](int kl, cplx (&f)[4]) {
+        const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+        const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+        f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+    };
+    auto mac = [&](const cplx (&f)[4]) {
+        double asum[2], bsum[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+            }
+    };
+    cplx c[2][2][4];
+    cplx* base = G + (size_t)(tj + wj + l4) * ldc + ti + wi + l15;
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                    c[a][b][r].x = __builtin_nontemporal_load(&p->x); c[a][b][r].y = __builtin_nontemporal_load(&p->y);
+                }
+    };
+    for (int kb = 0; kb < K8; kb += KH) {
+        const int kc = min(KH, K8 - kb);
+        if (kb > 0) __syncthreads();              // everybody has read the previous phase's panels
+        stage(kb, kc);
+        __syncthreads();
+        if (EARLY && kb == 0) load_tile();
+        cplx s[4], t[4];
+        loadf(0, s);
+        for (int k0 = 0; k0 < kc; k0 += 8) {
+            loadf(k0 + 4, t);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(s);
+            __builtin_amdgcn_sched_barrier(0);
+            loadf(min(k0 + 8, kc - 4), s);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+            acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
+        }
+    if (!EARLY) load_tile();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y);
+            }
+}
+
+// var 3: LDS panels in TWO buffers of KH k values: the LDS-DMA of phase p + 1 is in flight while the MFMAs of phase p run
+template<int KH, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_flush_lds2(const cplx* __restrict__ X, const cplx* __restrict__ GrT, int ld,
+                                                           cplx* __restrict__ G, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb) {
+    extern __shared__ cplx sm[];                  // [2][ Xs[KH][64], Gs[KH][64] ]
+    const int tn = n / 64;
+    int chain, tile;
+    chain_tile(tn * tn, nb, chain, tile);
+    X += chain * cs; GrT += chain * cs; G += chain * cs;
+    const int K = Kdev[chain];
+    if (K <= 0) return;
+    const int K8 = (K + 7) & ~7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ti = (tile % tn) * 64, tj = (tile / tn) * 64;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    auto stage = [&](int buf, int kb, int kc) {
+        cplx* Xs = sm + buf * 2 * KH * 64;
+        cplx* Gs = Xs + KH * 64;
+        for (int kl = wave; kl < kc; kl += 4) {
+            const size_t k = (size_t)(kb + kl);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(X + k * ld + ti + lane), (lds_ptr)(Xs + kl * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(GrT + k * ld + tj + lane), (lds_ptr)(Gs + kl * 64), 16, 0, 0);
+        }
+    };
+    auto mac = [&](const cplx (&f)[4]) {
+        double asum[2], bsum[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+            }
+    };
+    cplx c[2][2][4];
+    cplx* base = G + (size_t)(tj + wj + l4) * ldc + ti + wi + l15;
+    stage(0, 0, min(KH, K8));
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                c[a][b][r].x = __builtin_nontemporal_load(&p->x); c[a][b][r].y = __builtin_nontemporal_load(&p->y);
+            }
+    int buf = 0;
+    for (int kb = 0; kb < K8; kb += KH, buf ^= 1) {
+        const int kc = min(KH, K8 - kb);
+        if (kb + KH < K8) stage(buf ^ 1, kb + KH, min(KH, K8 - kb - KH));
+        const cplx* Xs = sm + buf * 2 * KH * 64;
+        const cplx* Gs = Xs + KH * 64;
+        auto loadf = [&](int kl, cplx (&f)[4]) {
+            const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+            const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+            f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+        };
+        cplx s[4], t[4];
+        loadf(0, s);
+        for (int k0 = 0; k0 < kc; k0 += 8) {
+            loadf(k0 + 4, t);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(s);
+            __builtin_amdgcn_sched_barrier(0);
+            loadf(min(k0 + 8, kc - 4), s);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kb + KH < K8) __syncthreads();        // next buffer landed (vmcnt(0): also the tile of G), this one free to be overwritten
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+            acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
+        }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y);
+            }
+}
+
+// var 4: PERSISTENT workgroups (one or two per CU) walk a list of tiles; the LDS-DMA of the NEXT 32-k chunk (the next phase of this tile or
+// the first phase of the next tile) is in flight while the MFMAs of the current chunk run -- memory and matrix cores overlap inside ONE
+// workgroup instead of relying on a second workgroup that tends to run in phase with the first.
+template<int KH, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_flush_pipe(const cplx* __restrict__ X0, const cplx* __restrict__ GrT0, int ld,
+                                                           cplx* __restrict__ G0, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb) {
+    extern __shared__ cplx sm[];                  // [2][ Xs[KH][64], Gs[KH][64] ]
+    __shared__ int sK[128];
+    const int tn = n / 64, tiles = tn * tn;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int per = nb >> 3;                      // chains per XCD: chain = 8 q + xcd
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    for (int q = tid; q < per; q += 256) sK[q] = Kdev[q * 8 + xcd];
+    __syncthreads();
+    const int T = per * tiles;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    // next work item with K > 0 at or after u
+    auto skip = [&](int u) { while (u < T && sK[u / tiles] <= 0) u += W; return u; };
+    auto dma = [&](int buf, int u, int kb) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const size_t off = (size_t)(q * 8 + xcd) * cs;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        const int ti = (tile % tn) * 64, tj = (tile / tn) * 64;
+        cplx* Xs = sm + buf * 2 * KH * 64;
+        cplx* Gs = Xs + KH * 64;
+        const cplx* X = X0 + off; const cplx* GrT = GrT0 + off;
+        for (int kl = wave; kl < kc; kl += 4) {
+            const size_t k = (size_t)(kb + kl);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(X + k * ld + ti + lane), (lds_ptr)(Xs + kl * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(GrT + k * ld + tj + lane), (lds_ptr)(Gs + kl * 64), 16, 0, 0);
+        }
+    };
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+    };
+    auto mac = [&](const cplx (&f)[4]) {
+        double asum[2], bsum[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+            }
+    };
+    zero();
+    cplx c[2][2][4];
+    int u = skip(w), kb = 0, buf = 0;
+    if (u >= T) return;
+    dma(0, u, 0);
+    cplx* pbase = nullptr;                        // tile whose epilogue (add + store) is still due: it runs BEHIND the next barrier, so that
+                                                  // the barrier's vmcnt(0) never waits for stores that were issued a moment ago
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+                acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cplx* p = pbase + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                    __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                    __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y);
+                }
+        zero();
+    };
+    while (u < T) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        const bool last = kb + KH >= K8;
+        // the chunk after this one
+        int un = u, kbn = kb + KH;
+        if (last) { un = skip(u + W); kbn = 0; }
+        __syncthreads();                          // this chunk's panels have landed (the barrier drains the LDS-DMA); everybody is done with the other buffer
+        // the deferred epilogue comes BEFORE the next DMA is issued: hipcc drains every outstanding LDS-DMA (vmcnt(0)) at the next use
+        // of an ordinary load's result, and the epilogue uses the tile loaded one chunk ago
+        if (kb == 0 && pbase) epilogue();
+        if (un < T) dma(buf ^ 1, un, kbn);
+        if (kb == 0) {
+            cplx* base = G0 + (size_t)(q * 8 + xcd) * cs + (size_t)((tile / tn) * 64 + wj + l4) * ldc + (tile % tn) * 64 + wi + l15;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                        c[a][b][r].x = __builtin_nontemporal_load(&p->x); c[a][b][r].y = __builtin_nontemporal_load(&p->y);
+                    }
+            pbase = base;
+        }
+        {
+            const cplx* Xs = sm + buf * 2 * KH * 64;
+            const cplx* Gs = Xs + KH * 64;
+            auto loadf = [&](int kl, cplx (&f)[4]) {
+                const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+                const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+                f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+            };
+            cplx s[4], t[4];
+            loadf(0, s);
+            for (int k0 = 0; k0 < kc; k0 += 8) {
+                loadf(k0 + 4, t);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(s);
+                __builtin_amdgcn_sched_barrier(0);
+                loadf(min(k0 + 8, kc - 4), s);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        u = un; kb = kbn; buf ^= 1;
+    }
+    epilogue();
+}
+
+__global__ void k_rmw(cplx* __restrict__ G, int ldc, int n, size_t cs, int nb) {
+    const int tn = n / 64;
+    int chain, tile;
+    chain_tile(tn * tn, nb, chain, tile);
+    G += chain * cs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int i0 = (tile % tn) * 64 + (wave >> 1) * 32, j0 = (tile / tn) * 64 + (wave & 1) * 32;
+    cplx* base = G + (size_t)(j0 + l4) * ldc + i0 + l15;
+    cplx c[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const cplx* p = base + (size_t)((q >> 1) * 4) * ldc + (q & 1) * 16; c[q].x = __builtin_nontemporal_load(&p->x); c[q].y = __builtin_nontemporal_load(&p->y); }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { cplx* p = base + (size_t)((q >> 1) * 4) * ldc + (q & 1) * 16; __builtin_nontemporal_store(c[q].x + 1.0, &p->x); __builtin_nontemporal_store(c[q].y, &p->y); }
+}
+
+__global__ void k_fill(double* p, size_t count, unsigned seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+        p[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+__global__ void k_diff(const cplx* a, const cplx* b, size_t count, double* out) {
+    double m = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        m = fmax(m, fmax(fabs(a[i].x - b[i].x), fabs(a[i].y - b[i].y)));
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(m));
+}
+
+struct Bufs { cplx *G, *X, *GrT; int* Kd; int n, nb; size_t cs; hipEvent_t a, b; };
+template<class F> static float timeit(const Bufs&, hipEvent_t a, hipEvent_t b, F f, int reps = 20) {
+    f(); f();
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i) f();
+    (void)hipEventRecord(b, 0);
+    (void)hipEventSynchronize(b);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+    const float us = ms * 1000.f / reps;
+    printf("%9.1f us", us);
+    return us;
+}
+
+int main(int argc, char** argv) {
+    const int n = 512, nb = 128;
+    const size_t cs = (size_t)24 * 1024 * 1024 / 16;       // 24 MiB between the chains
+    cplx* p; int* Kd;
+    CK(hipMalloc(&p, cs * nb * 16)); CK(hipMemset(p, 0, cs * nb * 16));
+    cplx* G2; CK(hipMalloc(&G2, (size_t)n * n * nb * 16));
+    double* dmax; CK(hipMalloc(&dmax, 8));
+    const bool rnd = argc > 1 && atoi(argv[1]) == 1;
+    CK(hipMalloc(&Kd, nb * 4));
+    Bufs B; B.n = n; B.nb = nb; B.cs = cs; B.G = p; B.X = p + (size_t)n * n; B.GrT = B.X + (size_t)n * 64; B.Kd = Kd;
+    CK(hipEventCreate(&B.a)); CK(hipEventCreate(&B.b));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds<0, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 32, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 32, 2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 32, 2, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds2<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds2<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_rmw, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    const dim3 grid(64 * nb), blk(256);
+    for (int mode = 0; mode < 5; ++mode) {
+        std::vector<int> hk(nb);
+        double ksum = 0;
+        srand(7);
+        for (int i = 0; i < nb; ++i) {
+            int acc = 0;
+            for (int t = 0; t < 32; ++t) acc += (rand() % 100) < 47;
+            int acc2 = acc;
+            for (int t = 0; t < 32; ++t) acc2 += (rand() % 100) < 47;
+            if (acc2 > 32) acc2 = 32;
+            hk[i] = mode == 0 ? 2 * acc : mode == 1 ? 64 : mode == 2 ? 56 : mode == 3 ? 32 : ((i % 5) < 3 ? 2 * acc2 : 0);   // mode 4: the bench at delaySteps 32 -- K ~ 2 Bin(64, 0.47), 2 of 5 chains idle
+            ksum += hk[i];
+        }
+        CK(hipMemcpy(Kd, hk.data(), nb * 4, hipMemcpyHostToDevice));
+        const double bytes = 2.0 * 16 * n * n * nb, flops = 8.0 * n * n * ksum;
+        printf("---- mode %d: mean K %.1f, %.0f MB RMW, %.2f GFLOP (8 n^2 K) ----\n", mode, ksum / nb, bytes / 1e6, flops / 1e9);
+        auto rep = [&](const char* name, float us) { printf("  <- %-44s %.2f TB/s, %.1f TFLOP/s\n", name, bytes / us / 1e6, flops / us / 1e6); };
+        // correctness: production vs LDS variants on random operands
+        if (rnd || mode == 0) {
+            hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (double*)p, cs * nb * 2, 1u + mode);
+            for (int c = 0; c < nb; ++c) {       // zero padding columns K .. K8-1 as the gather kernel leaves them
+                const int K = hk[c], K8 = (K + 7) & ~7;
+                if (K8 > K) {
+                    CK(hipMemsetAsync(B.X + c * cs + (size_t)K * n, 0, (size_t)(K8 - K) * n * 16, 0));
+                    CK(hipMemsetAsync(B.GrT + c * cs + (size_t)K * n, 0, (size_t)(K8 - K) * n * 16, 0));
+                }
+            }
+            std::vector<cplx> ref((size_t)n * n), got((size_t)n * n);
+            auto snapshot = [&](cplx* dst) { for (int c = 0; c < nb; ++c) (void)hipMemcpyAsync(dst + (size_t)c * n * n, B.G + c * cs, (size_t)n * n * 16, hipMemcpyDeviceToDevice, 0); };
+            cplx* G0; CK(hipMalloc(&G0, (size_t)n * n * nb * 16));
+            snapshot(G0);
+            auto restore = [&]() { for (int c = 0; c < nb; ++c) (void)hipMemcpyAsync(B.G + c * cs, G0 + (size_t)c * n * n, (size_t)n * n * 16, hipMemcpyDeviceToDevice, 0); };
+            hipLaunchKernelGGL(k_flush_prod, grid, blk, 0, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb);
+            snapshot(G2);
+            auto check = [&](const char* nm) {
+                cplx* G3; (void)hipMalloc(&G3, (size_t)n * n * nb * 16);
+                snapshot(G3);
+                (void)hipMemset(dmax, 0, 8);
+                hipLaunchKernelGGL(k_diff, dim3(1024), dim3(256), 0, 0, G2, G3, (size_t)n * n * nb, dmax);
+                double d; (void)hipMemcpy(&d, dmax, 8, hipMemcpyDeviceToHost);
+                printf("  max |%s - production| = %.3e\n", nm, d);
+                (void)hipFree(G3);
+            };
+            restore(); hipLaunchKernelGGL((k_flush_lds<1, 32, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("lds early KH32");
+            restore(); hipLaunchKernelGGL((k_flush_lds<0, 32, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("lds late KH32");
+            restore(); hipLaunchKernelGGL((k_flush_lds<1, 64, 1>), grid, blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("lds early KH64");
+            restore(); hipLaunchKernelGGL((k_flush_lds2<16, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("lds2 KH16");
+            restore(); hipLaunchKernelGGL((k_flush_pipe<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe KH32 256 WG");
+            restore(); hipLaunchKernelGGL((k_flush_pipe<16, 2>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe KH16 512 WG");
+            restore(); hipLaunchKernelGGL((k_flush_lds2<8, 2>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("lds2 KH8");
+            CK(hipDeviceSynchronize());
+            CK(hipFree(G0));
+            if (!rnd) CK(hipMemset(p, 0, cs * nb * 16));
+        }
+        rep("rmw only", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL(k_rmw, grid, blk, 0, 0, B.G, n, n, cs, nb); }));
+        rep("rmw only, 2 WG/CU (64 KB LDS each)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL(k_rmw, grid, blk, 64 * 1024, 0, B.G, n, n, cs, nb); }));
+        rep("rmw only, 4 WG/CU (32 KB LDS each)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL(k_rmw, grid, blk, 32 * 1024, 0, B.G, n, n, cs, nb); }));
+        rep("production (register fragments, 3 WG/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL(k_flush_prod, grid, blk, 0, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS panels KH 32, tile early, 2 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 32, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS panels KH 32, early, skew 3 (~2.5 us)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 32, 2, 3>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS panels KH 32, early, skew 6 (~5 us)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 32, 2, 6>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS panels KH 32, early, skew 10 (~8 us)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 32, 2, 10>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS panels KH 32, tile late, 2 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<0, 32, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS panels KH 16, tile early, 2 WG/CU hint", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 16, 2>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS 2 buffers KH 16, tile early, 2 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds2<16, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS 2 buffers KH 8, tile early, 2 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds2<8, 2>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("persistent pipeline KH 32, 256 WG (1/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("persistent pipeline KH 16, 512 WG (2/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe<16, 2>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("persistent pipeline KH 16, 256 WG (1/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe<16, 1>), dim3(256), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS panels KH 64, tile early, 1 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 64, 1>), grid, blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+    }
+    return 0;
+}

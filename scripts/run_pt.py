@@ -227,7 +227,7 @@ def run_conf(a):
             for cpi in range(nproc):
                 mm = dict(meta_model)
                 mm["r"] = PT.num_to_string(rvals[cpi])
-                PT.write_config_infoheader(subdir(cpi), mm, meta_mc, meta_pt)
+                PT.write_config_infoheader(subdir(cpi), mm, meta_mc, meta_pt, cdw=kw["cdwU"] != 0.0)
         print("Measurements finished", flush=True)
     batch.close()
     if dist is not None:

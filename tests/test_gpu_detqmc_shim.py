@@ -98,6 +98,14 @@ def test_detqmc_driver_with_gpu_model_and_cdwU(tmp_path):
     assert pb.size == nconf * N * m * 2
     meta = "".join(_header(str(tmp_path / "results.values")))
     assert "cdwU = 0.5" in meta
+    # the stream headers of BOTH fields against the files the reference's CPU program wrote for this configuration file
+    # (tests/golden/detqmc_run_o2_L4_cdw/expected, from oracle/_ref/detqmcsdwo2_ref; src/detsdwopdim.cpp:5040-5108)
+    exp = os.path.join(ROOT, "tests", "golden", "detqmc_run_o2_L4_cdw", "expected")
+    assert (tmp_path / "simulation.conf").read_text() == open(os.path.join(os.path.dirname(exp), "simulation.conf")).read()
+    for fn in ("configs-l.infoheader", "configs-phi.infoheader"):
+        assert _header(str(tmp_path / fn)) == _header(os.path.join(exp, fn)), fn
+    for fn in ("configs-l.textstream", "configs-phi.textstream"):
+        assert _header(str(tmp_path / fn)) == _header(os.path.join(exp, fn + ".header")), fn
     # the same parameters through the Python view: the first configuration is written behind the first measured sweep -- 4 thermalisation
     # sweeps, sweep(false), sweep(true) with measureInterval = 2 (DetQMC::run, src/detqmc.h:435-505)
     rep = DetSDW(SDWParams(opdim=2, L=4, beta=2.0, dtau=0.1, s=10, r=-0.5, c=1.0, u=1.0, lambda_=1.0, mu=-0.5, weakZflux=True, delaySteps=8, cdwU=0.5,   # c, u: the defaults of the reference option parser
