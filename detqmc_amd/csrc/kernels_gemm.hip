@@ -410,10 +410,16 @@ __global__ __launch_bounds__(256, (FULL && STAGE == 1) ? 3 : 2) void k_flush(con
 // behind the first barrier -- the fragment reads of the MFMA loop are LDS reads (lgkmcnt), so the tile's loads (vmcnt) stay in flight
 // until the epilogue -- and K > 32 runs in phases of 32 through the same 64 KB (two workgroups per CU).  Same MFMAs in the same order as
 // k_flush: bit-identical G.  scripts/micro/flush_r4.hip, profiles/r04_flush_micro.log: 128 chains, n = 512, K ~ 2 Binomial(32, 0.47):
-// 214 -> 198 us per launch (5.0 -> 5.4 TB/s of read-modify-write traffic); K = 32: 216 -> 187 us; K = 56 / 64: 272 / 297 us, unchanged
-// (there the MFMA pipe binds).  Measured and dropped in the same harness: the tile requested behind the loop (no gain over k_flush: what
-// pays is the overlap, not the halved L2 traffic), two LDS buffers of 16 or 8 k with the next phase's DMA in flight (216 / 232 us: the
-// extra barriers cost more than the exposed DMA of a phase), all of K in LDS at one workgroup per CU (227 us).
+// 214 -> 198 us per launch (5.0 -> 5.4 TB/s of read-modify-write traffic); K = 32: 216 -> 187 us; K = 56 / 64: 272 / 297 us, unchanged.
+// Used for K <= 32 (launch_flush).  What the same harness measured and dropped on the way to "MFMA time and HBM time overlap" (DESIGN.md
+// section 15 has the account): the tile requested behind the loop (no gain over k_flush: what pays is the overlap, not the halved L2
+// traffic); two LDS buffers of 16 or 8 k with the next phase's DMA in flight (216 / 232 us: the extra barriers cost more than the exposed
+// DMA of a phase); all of K in LDS at one workgroup per CU (227 us); PERSISTENT workgroups (one wave per SIMD, the next chunk's DMA in
+// flight behind the MFMAs; 308 us at K = 56 against 272) -- their phase timers show the waves stalled 3500 cycles per chunk ISSUING
+// memory instructions (a wave issues in order: while the memory pipe is backed up it cannot issue MFMAs either), pacing those
+// instructions through the MFMA loop made it worse (379 us), so on this chip the overlap has to come from OTHER waves of the same SIMD,
+// i.e. from occupancy, which is what k_flush's three workgroups per CU already buy; a start skew between the two workgroups of a CU
+// (-4 %).
 // ---------------------------------------------------------------------------------------------
 #define FLUSH_KH 32
 template<int TAG>
@@ -541,7 +547,11 @@ void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx
                                            else hipLaunchKernelGGL((k_flush<M3_, FULL_, ST_, 0>), grid, dim3(256), 0, lc.st, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, lc.cs, lc.nb); } while (0)
     static const bool flush_4m = dev_knob("DQMC_FLUSH_4M") && atoi(dev_knob("DQMC_FLUSH_4M")) != 0;               // developer knob (A/B): 4 MFMAs, 122 registers, 4 workgroups per CU
     static const bool flush_reg = dev_knob("DQMC_FLUSH_LDS") && atoi(dev_knob("DQMC_FLUSH_LDS")) == 0;            // developer knob (A/B): the register-fragment kernel of round 3
-    if (full && !use_4m() && !flush_4m && stage != 2 && !flush_reg) {
+    // K <= 32 (delay depth <= 16 for O(1) / O(2), <= 8 for O(3); the LU's trailing updates): one LDS phase, 187 against 216 us per launch of
+    // 128 chains at K = 32.  Deeper blocks (the bench runs K ~ 60 of at most 64): both kernels tie within 3 % (profiles/r04_flush_micro.log,
+    // modes 2 and 4), the register kernel with its three workgroups per CU stays
+    static const bool flush_lds_all = dev_knob("DQMC_FLUSH_LDS") && atoi(dev_knob("DQMC_FLUSH_LDS")) == 2;      // developer knob (A/B): LDS panels for every K
+    if (full && !use_4m() && !flush_4m && stage != 2 && !flush_reg && (Kmax <= FLUSH_KH || flush_lds_all)) {
         // LDS-shared operand panels; 64 KB of dynamic LDS: the attribute belongs to (function, device)
         const size_t lds = (size_t)2 * FLUSH_KH * 64 * sizeof(cplx);
         static std::mutex mu;

@@ -314,6 +314,578 @@ __global__ __launch_bounds__(256, MINB) void k_flush_lds2(const cplx* __restrict
             }
 }
 
+// LDS-DMA the compiler does not see (cdna_hip_programming.md, inline-asm recipe): lane's 16 bytes at gsrc -> LDS at (wave-uniform) dst + 16 lane
+__device__ __forceinline__ void glds16_asm(const cplx* gsrc, const cplx* lds_dst) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// var 5 = var 4 with the LDS-DMA hidden from the compiler (inline asm, waited for by hand): hipcc otherwise drains every outstanding
+// LDS-DMA (s_waitcnt vmcnt(0)) in front of the MFMA loop's first LDS read, i.e. nothing overlaps.
+// var 4 (below, kept for the record): PERSISTENT workgroups (one or two per CU) walk a list of tiles; the LDS-DMA of the NEXT 32-k chunk (the next phase of this tile or
+// the first phase of the next tile) is in flight while the MFMAs of the current chunk run -- memory and matrix cores overlap inside ONE
+// workgroup instead of relying on a second workgroup that tends to run in phase with the first.
+template<int KH, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_flush_pipe_asm(const cplx* __restrict__ X0, const cplx* __restrict__ GrT0, int ld,
+                                                           cplx* __restrict__ G0, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb) {
+    extern __shared__ cplx sm[];                  // [2][ Xs[KH][64], Gs[KH][64] ]
+    __shared__ int sK[128];
+    const int tn = n / 64, tiles = tn * tn;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int per = nb >> 3;                      // chains per XCD: chain = 8 q + xcd
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    for (int q = tid; q < per; q += 256) sK[q] = Kdev[q * 8 + xcd];
+    __syncthreads();
+    const int T = per * tiles;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    // next work item with K > 0 at or after u
+    auto skip = [&](int u) { while (u < T && sK[u / tiles] <= 0) u += W; return u; };
+    auto dma = [&](int buf, int u, int kb) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const size_t off = (size_t)(q * 8 + xcd) * cs;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        const int ti = (tile % tn) * 64, tj = (tile / tn) * 64;
+        cplx* Xs = sm + buf * 2 * KH * 64;
+        cplx* Gs = Xs + KH * 64;
+        const cplx* X = X0 + off; const cplx* GrT = GrT0 + off;
+        for (int kl = wave; kl < kc; kl += 4) {
+            const size_t k = (size_t)(kb + kl);
+            glds16_asm(X + k * ld + ti + lane, Xs + kl * 64);
+            glds16_asm(GrT + k * ld + tj + lane, Gs + kl * 64);
+        }
+    };
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+    };
+    auto mac = [&](const cplx (&f)[4]) {
+        double asum[2], bsum[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+            }
+    };
+    zero();
+    cplx c[2][2][4];
+    int u = skip(w), kb = 0, buf = 0;
+    if (u >= T) return;
+    dma(0, u, 0);
+    cplx* pbase = nullptr;                        // tile whose epilogue (add + store) is still due: it runs BEHIND the next barrier, so that
+                                                  // the barrier's vmcnt(0) never waits for stores that were issued a moment ago
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+                acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cplx* p = pbase + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                    __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                    __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y);
+                }
+        zero();
+    };
+    while (u < T) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        const bool last = kb + KH >= K8;
+        // the chunk after this one
+        int un = u, kbn = kb + KH;
+        if (last) { un = skip(u + W); kbn = 0; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this chunk's panels have landed; everybody is done with the other buffer
+        // the deferred epilogue comes BEFORE the next DMA is issued: hipcc drains every outstanding LDS-DMA (vmcnt(0)) at the next use
+        // of an ordinary load's result, and the epilogue uses the tile loaded one chunk ago
+        if (kb == 0 && pbase) epilogue();
+        if (un < T) dma(buf ^ 1, un, kbn);
+        if (kb == 0) {
+            cplx* base = G0 + (size_t)(q * 8 + xcd) * cs + (size_t)((tile / tn) * 64 + wj + l4) * ldc + (tile % tn) * 64 + wi + l15;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                        c[a][b][r].x = __builtin_nontemporal_load(&p->x); c[a][b][r].y = __builtin_nontemporal_load(&p->y);
+                    }
+            pbase = base;
+        }
+        {
+            const cplx* Xs = sm + buf * 2 * KH * 64;
+            const cplx* Gs = Xs + KH * 64;
+            auto loadf = [&](int kl, cplx (&f)[4]) {
+                const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+                const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+                f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+            };
+            cplx s[4], t[4];
+            loadf(0, s);
+            for (int k0 = 0; k0 < kc; k0 += 8) {
+                loadf(k0 + 4, t);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(s);
+                __builtin_amdgcn_sched_barrier(0);
+                loadf(min(k0 + 8, kc - 4), s);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        u = un; kb = kbn; buf ^= 1;
+    }
+    epilogue();
+}
+
+template<int KH, int MINB, int NOG, int NOMFMA>
+__global__ __launch_bounds__(256, MINB) void k_flush_pipe_abl(const cplx* __restrict__ X0, const cplx* __restrict__ GrT0, int ld,
+                                                           cplx* __restrict__ G0, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb) {
+    extern __shared__ cplx sm[];                  // [2][ Xs[KH][64], Gs[KH][64] ]
+    __shared__ int sK[128];
+    const int tn = n / 64, tiles = tn * tn;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int per = nb >> 3;                      // chains per XCD: chain = 8 q + xcd
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    for (int q = tid; q < per; q += 256) sK[q] = Kdev[q * 8 + xcd];
+    __syncthreads();
+    const int T = per * tiles;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    // next work item with K > 0 at or after u
+    auto skip = [&](int u) { while (u < T && sK[u / tiles] <= 0) u += W; return u; };
+    auto dma = [&](int buf, int u, int kb) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const size_t off = (size_t)(q * 8 + xcd) * cs;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        const int ti = (tile % tn) * 64, tj = (tile / tn) * 64;
+        cplx* Xs = sm + buf * 2 * KH * 64;
+        cplx* Gs = Xs + KH * 64;
+        const cplx* X = X0 + off; const cplx* GrT = GrT0 + off;
+        for (int kl = wave; kl < kc; kl += 4) {
+            const size_t k = (size_t)(kb + kl);
+            glds16_asm(X + k * ld + ti + lane, Xs + kl * 64);
+            glds16_asm(GrT + k * ld + tj + lane, Gs + kl * 64);
+        }
+    };
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+    };
+    auto mac = [&](const cplx (&f)[4]) {
+        double asum[2], bsum[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+            }
+    };
+    zero();
+    cplx c[2][2][4];
+    int u = skip(w), kb = 0, buf = 0;
+    if (u >= T) return;
+    dma(0, u, 0);
+    cplx* pbase = nullptr;                        // tile whose epilogue (add + store) is still due: it runs BEHIND the next barrier, so that
+                                                  // the barrier's vmcnt(0) never waits for stores that were issued a moment ago
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+                acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cplx* p = pbase + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                    if (NOG) { if (acc_re[a][b][r] == 1.2345e301) p->x = acc_im[a][b][r]; }
+                    else {
+                    __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                    __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y); }
+                }
+        zero();
+    };
+    while (u < T) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        const bool last = kb + KH >= K8;
+        // the chunk after this one
+        int un = u, kbn = kb + KH;
+        if (last) { un = skip(u + W); kbn = 0; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this chunk's panels have landed; everybody is done with the other buffer
+        // the deferred epilogue comes BEFORE the next DMA is issued: hipcc drains every outstanding LDS-DMA (vmcnt(0)) at the next use
+        // of an ordinary load's result, and the epilogue uses the tile loaded one chunk ago
+        if (kb == 0 && pbase) epilogue();
+        if (un < T) dma(buf ^ 1, un, kbn);
+        if (kb == 0) {
+            cplx* base = G0 + (size_t)(q * 8 + xcd) * cs + (size_t)((tile / tn) * 64 + wj + l4) * ldc + (tile % tn) * 64 + wi + l15;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                        if (NOG) c[a][b][r] = make_double2(0.0, 0.0); else { c[a][b][r].x = __builtin_nontemporal_load(&p->x); c[a][b][r].y = __builtin_nontemporal_load(&p->y); }
+                    }
+            pbase = base;
+        }
+        {
+            const cplx* Xs = sm + buf * 2 * KH * 64;
+            const cplx* Gs = Xs + KH * 64;
+            auto loadf = [&](int kl, cplx (&f)[4]) {
+                const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+                const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+                f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+            };
+            cplx s[4], t[4];
+            loadf(0, s);
+            for (int k0 = 0; k0 < (NOMFMA ? 8 : kc); k0 += 8) {
+                loadf(k0 + 4, t);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(s);
+                __builtin_amdgcn_sched_barrier(0);
+                loadf(min(k0 + 8, kc - 4), s);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        u = un; kb = kbn; buf ^= 1;
+    }
+    epilogue();
+}
+
+template<int KH, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_flush_pipe_tim(const cplx* __restrict__ X0, const cplx* __restrict__ GrT0, int ld,
+                                                           cplx* __restrict__ G0, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb, unsigned long long* __restrict__ dbg) {
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define TICK(i) do { unsigned long long t_ = __builtin_readcyclecounter(); tk[i] += t_ - tlast; tlast = t_; } while (0)
+    extern __shared__ cplx sm[];                  // [2][ Xs[KH][64], Gs[KH][64] ]
+    __shared__ int sK[128];
+    const int tn = n / 64, tiles = tn * tn;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int per = nb >> 3;                      // chains per XCD: chain = 8 q + xcd
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    for (int q = tid; q < per; q += 256) sK[q] = Kdev[q * 8 + xcd];
+    __syncthreads();
+    const int T = per * tiles;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    // next work item with K > 0 at or after u
+    auto skip = [&](int u) { while (u < T && sK[u / tiles] <= 0) u += W; return u; };
+    auto dma = [&](int buf, int u, int kb) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const size_t off = (size_t)(q * 8 + xcd) * cs;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        const int ti = (tile % tn) * 64, tj = (tile / tn) * 64;
+        cplx* Xs = sm + buf * 2 * KH * 64;
+        cplx* Gs = Xs + KH * 64;
+        const cplx* X = X0 + off; const cplx* GrT = GrT0 + off;
+        for (int kl = wave; kl < kc; kl += 4) {
+            const size_t k = (size_t)(kb + kl);
+            glds16_asm(X + k * ld + ti + lane, Xs + kl * 64);
+            glds16_asm(GrT + k * ld + tj + lane, Gs + kl * 64);
+        }
+    };
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+    };
+    auto mac = [&](const cplx (&f)[4]) {
+        double asum[2], bsum[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+            }
+    };
+    zero();
+    cplx c[2][2][4];
+    int u = skip(w), kb = 0, buf = 0;
+    if (u >= T) return;
+    dma(0, u, 0);
+    cplx* pbase = nullptr;                        // tile whose epilogue (add + store) is still due: it runs BEHIND the next barrier, so that
+                                                  // the barrier's vmcnt(0) never waits for stores that were issued a moment ago
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+                acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cplx* p = pbase + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                    __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                    __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y);
+                }
+        zero();
+    };
+    while (u < T) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        const bool last = kb + KH >= K8;
+        // the chunk after this one
+        int un = u, kbn = kb + KH;
+        if (last) { un = skip(u + W); kbn = 0; }
+        TICK(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        TICK(1);                                  // own memory operations done
+        asm volatile("s_barrier" ::: "memory");
+        TICK(2);                                  // everybody's
+        // the deferred epilogue comes BEFORE the next DMA is issued: hipcc drains every outstanding LDS-DMA (vmcnt(0)) at the next use
+        // of an ordinary load's result, and the epilogue uses the tile loaded one chunk ago
+        if (kb == 0 && pbase) epilogue();
+        TICK(3);
+        if (un < T) dma(buf ^ 1, un, kbn);
+        if (kb == 0) {
+            cplx* base = G0 + (size_t)(q * 8 + xcd) * cs + (size_t)((tile / tn) * 64 + wj + l4) * ldc + (tile % tn) * 64 + wi + l15;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const cplx* p = base + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                        c[a][b][r].x = __builtin_nontemporal_load(&p->x); c[a][b][r].y = __builtin_nontemporal_load(&p->y);
+                    }
+            pbase = base;
+        }
+        TICK(4);
+        {
+            const cplx* Xs = sm + buf * 2 * KH * 64;
+            const cplx* Gs = Xs + KH * 64;
+            auto loadf = [&](int kl, cplx (&f)[4]) {
+                const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+                const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+                f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+            };
+            cplx s[4], t[4];
+            loadf(0, s);
+            for (int k0 = 0; k0 < kc; k0 += 8) {
+                loadf(k0 + 4, t);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(s);
+                __builtin_amdgcn_sched_barrier(0);
+                loadf(min(k0 + 8, kc - 4), s);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        u = un; kb = kbn; buf ^= 1;
+        tk[5] += 1;
+    }
+    epilogue();
+    TICK(0);
+    if (tid == 0 && blockIdx.x < 64) for (int i = 0; i < 6; ++i) dbg[blockIdx.x * 6 + i] = tk[i];
+#undef TICK
+}
+
+// var 6: persistent AND paced -- ONE workgroup per CU (one wave per SIMD, 128 KB of LDS: two buffers of 32 k); every vector-memory
+// instruction of a tile is issued from INSIDE the MFMA loop, a few per k-step pair: the LDS-DMA lines of the next chunk, the 16 loads of
+// this tile's G (needed only at the tile's end).  A wave issues in order: a burst of 16 + 16 + 16 memory instructions at a chunk boundary
+// keeps it -- and with one wave per SIMD the matrix pipe -- stalled while the texture-address unit works through 48 KB per wave
+// (phase timers of var 5: ~3500 cycles per chunk in "issue"); paced, each one hides behind the MFMAs already in the pipe.
+// The epilogue of tile t (add + 16 stores) runs at the start of tile t + 1, behind the barrier.
+template<int DUMMY>
+__global__ __launch_bounds__(256, 1) void k_flush_pp(const cplx* __restrict__ X0, const cplx* __restrict__ GrT0, int ld,
+                                                      cplx* __restrict__ G0, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb) {
+    constexpr int KH = 32;
+    extern __shared__ cplx sm[];                  // [2][ Xs[KH][64], Gs[KH][64] ]
+    __shared__ int sK[128];
+    const int tn = n / 64, tiles = tn * tn;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int per = nb >> 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    for (int q = tid; q < per; q += 256) sK[q] = Kdev[q * 8 + xcd];
+    __syncthreads();
+    const int T = per * tiles;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    auto skip = [&](int u) { while (u < T && sK[u / tiles] <= 0) u += W; return u; };
+    // description of the chunk whose panels are being fetched: this wave's lines are (panel, kl = wave + 4 j), j < nline
+    const cplx* nX = nullptr; const cplx* nG = nullptr;      // lane's source pointers at k = kb (row ti + lane resp. tj + lane)
+    int nline = 0, nbuf = 0, nissued = 0;
+    auto dma_setup = [&](int buf, int u, int kb) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const size_t off = (size_t)(q * 8 + xcd) * cs;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        nX = X0 + off + (size_t)(kb + wave) * ld + (tile % tn) * 64 + lane;
+        nG = GrT0 + off + (size_t)(kb + wave) * ld + (tile / tn) * 64 + lane;
+        nline = kc / 4; nbuf = buf; nissued = 0;
+    };
+    auto dma_some = [&](int count) {              // the next `count` k lines (both panels each)
+        for (int c = 0; c < count && nissued < nline; ++c, ++nissued) {
+            cplx* Xs = sm + nbuf * 2 * KH * 64 + (wave + 4 * nissued) * 64;
+            glds16_asm(nX + (size_t)(4 * nissued) * ld, Xs);
+            glds16_asm(nG + (size_t)(4 * nissued) * ld, Xs + KH * 64);
+        }
+    };
+    v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+    };
+    auto mac = [&](const cplx (&f)[4]) {
+        double asum[2], bsum[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+            }
+    };
+    zero();
+    cplx c[2][2][4];
+    int u = skip(w), kb = 0, buf = 0;
+    if (u >= T) return;
+    dma_setup(0, u, 0);
+    dma_some(8);
+    cplx* pbase = nullptr;                        // tile whose epilogue is due
+    cplx* base = nullptr;
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc_im[a][b] = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+                acc_re[a][b] = acc_re[a][b] - acc_p2[a][b];
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cplx* p = pbase + (size_t)(b * 16 + 4 * r) * ldc + a * 16;
+                    __builtin_nontemporal_store(c[a][b][r].x + acc_re[a][b][r], &p->x);
+                    __builtin_nontemporal_store(c[a][b][r].y + acc_im[a][b][r], &p->y);
+                }
+        zero();
+    };
+    // loads 4 g .. 4 g + 3 of the tile (a = g >> 1, b = g & 1: one 16 x 16 sub-tile)
+#define TILE_LOADS(g) do { \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) { \
+            const cplx* p_ = base + (size_t)(((g) & 1) * 16 + 4 * r) * ldc + ((g) >> 1) * 16; \
+            c[(g) >> 1][(g) & 1][r].x = __builtin_nontemporal_load(&p_->x); c[(g) >> 1][(g) & 1][r].y = __builtin_nontemporal_load(&p_->y); } } while (0)
+    while (u < T) {
+        const int q = u / tiles, tile = u - q * tiles;
+        const int K8 = (sK[q] + 7) & ~7;
+        const int kc = min(KH, K8 - kb);
+        const bool last = kb + KH >= K8;
+        int un = u, kbn = kb + KH;
+        if (last) { un = skip(u + W); kbn = 0; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this chunk's panels have landed; everybody is done with the other buffer
+        const bool first = (kb == 0);
+        if (first) {
+            if (pbase) epilogue();
+            base = G0 + (size_t)(q * 8 + xcd) * cs + (size_t)((tile / tn) * 64 + wj + l4) * ldc + (tile % tn) * 64 + wi + l15;
+            pbase = base;
+        }
+        const bool have_next = un < T;
+        if (have_next) dma_setup(buf ^ 1, un, kbn);
+        const int npairs = kc >> 3;
+        const int per_pair = have_next ? (nline + npairs - 1) / npairs : 0;
+        {
+            const cplx* Xs = sm + buf * 2 * KH * 64;
+            const cplx* Gs = Xs + KH * 64;
+            auto loadf = [&](int kl, cplx (&f)[4]) {
+                const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+                const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+                f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+            };
+            cplx s[4], t[4];
+            loadf(0, s);
+            for (int k0 = 0; k0 < kc; k0 += 8) {
+                loadf(k0 + 4, t);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(s);
+                __builtin_amdgcn_sched_barrier(0);
+                if (per_pair) dma_some(per_pair);
+                loadf(min(k0 + 8, kc - 4), s);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(t);
+                __builtin_amdgcn_sched_barrier(0);
+                if (first) {
+                    const int pi = k0 >> 3;
+                    if (pi == 0) TILE_LOADS(0); else if (pi == 1) TILE_LOADS(1); else if (pi == 2) TILE_LOADS(2); else TILE_LOADS(3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (first) {
+                if (npairs < 2) TILE_LOADS(1);
+                if (npairs < 3) TILE_LOADS(2);
+                if (npairs < 4) TILE_LOADS(3);
+            }
+        }
+        u = un; kb = kbn; buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    epilogue();
+#undef TILE_LOADS
+}
+
 // var 4: PERSISTENT workgroups (one or two per CU) walk a list of tiles; the LDS-DMA of the NEXT 32-k chunk (the next phase of this tile or
 // the first phase of the next tile) is in flight while the MFMAs of the current chunk run -- memory and matrix cores overlap inside ONE
 // workgroup instead of relying on a second workgroup that tends to run in phase with the first.
@@ -506,6 +1078,8 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&B.a)); CK(hipEventCreate(&B.b));
     CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_lds<0, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds<0, 16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_lds<0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 32, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 32, 2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_lds<1, 32, 2, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -515,8 +1089,18 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k_flush_lds2<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024));
     CK(hipFuncSetAttribute((const void*)k_rmw, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_pipe<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe_asm<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe_asm<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe_asm<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_pipe<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_pipe<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe_tim<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pp<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe_abl<32, 1, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe_abl<32, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe_abl<16, 2, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_pipe_abl<16, 2, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    unsigned long long* dbg; CK(hipMalloc(&dbg, 64 * 6 * 8));
     const dim3 grid(64 * nb), blk(256);
     for (int mode = 0; mode < 5; ++mode) {
         std::vector<int> hk(nb);
@@ -566,6 +1150,9 @@ int main(int argc, char** argv) {
             restore(); hipLaunchKernelGGL((k_flush_lds<1, 64, 1>), grid, blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("lds early KH64");
             restore(); hipLaunchKernelGGL((k_flush_lds2<16, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("lds2 KH16");
             restore(); hipLaunchKernelGGL((k_flush_pipe<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe KH32 256 WG");
+            restore(); hipLaunchKernelGGL((k_flush_pipe_asm<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe asm KH32 256 WG");
+            restore(); hipLaunchKernelGGL((k_flush_pp<0>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("persistent paced");
+            restore(); hipLaunchKernelGGL((k_flush_pipe_asm<16, 2>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe asm KH16 512 WG");
             restore(); hipLaunchKernelGGL((k_flush_pipe<16, 2>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe KH16 512 WG");
             restore(); hipLaunchKernelGGL((k_flush_lds2<8, 2>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("lds2 KH8");
             CK(hipDeviceSynchronize());
@@ -580,10 +1167,28 @@ int main(int argc, char** argv) {
         rep("LDS panels KH 32, early, skew 3 (~2.5 us)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 32, 2, 3>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("LDS panels KH 32, early, skew 6 (~5 us)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 32, 2, 6>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("LDS panels KH 32, early, skew 10 (~8 us)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 32, 2, 10>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS panels KH 16, tile late, 3 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<0, 16, 3>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("LDS panels KH 8, tile late, 3 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<0, 8, 3>), grid, blk, 16 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("LDS panels KH 32, tile late, 2 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<0, 32, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("LDS panels KH 16, tile early, 2 WG/CU hint", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 16, 2>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("LDS 2 buffers KH 16, tile early, 2 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds2<16, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("LDS 2 buffers KH 8, tile early, 2 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds2<8, 2>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("persistent PACED KH 32, 256 WG (1/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pp<0>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("persistent asm-DMA KH 32, 256 WG (1/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe_asm<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("persistent asm-DMA KH 16, 512 WG (2/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe_asm<16, 2>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("persistent asm-DMA KH 16, 256 WG (1/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe_asm<16, 1>), dim3(256), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        {
+            hipLaunchKernelGGL((k_flush_pipe_tim<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb, dbg);
+            unsigned long long h[64 * 6]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            double sum[6] = {0, 0, 0, 0, 0, 0};
+            for (int wgi = 0; wgi < 64; ++wgi) for (int i = 0; i < 6; ++i) sum[i] += (double)h[wgi * 6 + i] / 64;
+            printf("  persistent asm-DMA KH 32, cycles (100 MHz counter) per workgroup, mean of 64: mfma+tail %.0f, own vm wait %.0f, barrier %.0f, epilogue %.0f, dma issue + tile loads %.0f; chunks %.1f\n",
+                   sum[0], sum[1], sum[2], sum[3], sum[4], sum[5]);
+        }
+        rep("  ablation KH 32 1/CU: no G traffic", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe_abl<32, 1, 1, 0>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("  ablation KH 32 1/CU: 1/4.. MFMA (8 k per chunk max)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe_abl<32, 1, 0, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("  ablation KH 16 2/CU: no G traffic", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe_abl<16, 2, 1, 0>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("  ablation KH 16 2/CU: MFMA 8 k per chunk max", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe_abl<16, 2, 0, 1>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("persistent pipeline KH 32, 256 WG (1/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("persistent pipeline KH 16, 512 WG (2/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe<16, 2>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("persistent pipeline KH 16, 256 WG (1/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe<16, 1>), dim3(256), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
