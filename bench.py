@@ -301,20 +301,54 @@ def worker(a, readline=None, emit=None):
         out = {"dt": dt, "n_g": info.n_g, "m": info.m,
                "acceptance": [batch.chain(i).info.lastAccRatioLocal_phi for i in range(min(B, 4))]}
     emit("RESULT " + json.dumps(out))
-    # then, if asked: the same steps again with per-kernel HIP-event timing (the profile worker: ONE context alone on the GPU)
-    if readline().strip() == "SOLO":
-        if FAKE:
-            emit("SOLO " + json.dumps({"dt_profiled": dt, "prof": None}))
-            return
-        ctx.profile_enable(True)
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            batch.sweepThermalization()
-        ctx.synchronize()
-        dts = time.perf_counter() - t0
-        prof = ctx.profile_read()
-        ctx.profile_enable(False)
-        emit("SOLO " + json.dumps({"dt_profiled": dts, "prof": {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}}))
+    # then, if asked: the same steps again with per-kernel HIP-event timing
+    #   SOLO  -- this worker's (first) context, for the profile worker that runs ONE context alone on the GPU
+    #   PROF4 -- ALL contexts of this worker at once, each with events on its own stream: the per-family device times in the regime
+    #            `value` is measured in (the contexts overlap, so a family's time includes waiting for the other contexts' kernels)
+    while True:
+        cmd = readline().strip()
+        if cmd == "SOLO":
+            if FAKE:
+                emit("SOLO " + json.dumps({"dt_profiled": dt, "prof": None}))
+                break
+            ctx.profile_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                batch.sweepThermalization()
+            ctx.synchronize()
+            dts = time.perf_counter() - t0
+            prof = ctx.profile_read()
+            ctx.profile_enable(False)
+            emit("SOLO " + json.dumps({"dt_profiled": dts, "prof": {k: list(v) if isinstance(v, tuple) else v for k, v in prof.items()}}))
+        elif cmd == "PROF4":
+            if FAKE:
+                emit("PROF4 " + json.dumps({"dt_profiled": dt, "contexts": 0, "families": None}))
+                continue
+            ctxs = batch.kernel_contexts()
+            for c in ctxs:
+                c.profile_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                batch.sweepThermalization()
+            for c in ctxs:
+                c.synchronize()
+            dts = time.perf_counter() - t0
+            fams = {}
+            for c in ctxs:
+                pr = c.profile_read()
+                c.profile_enable(False)
+                for k, v in pr.items():
+                    if isinstance(v, tuple) and k != "jacobi":
+                        cur = fams.setdefault(k, [0.0, 0])
+                        cur[0] += v[0]; cur[1] += v[1]
+                cur = fams.setdefault("qr_apply", [0.0, 0])
+                cur[0] += pr["decomp_round_ms"]; cur[1] += pr["decomp_rounds"]
+                for k, v in pr.get("sub", {}).items():
+                    cur = fams.setdefault(k, [0.0, 0])
+                    cur[0] += v[0]; cur[1] += v[1]
+            emit("PROF4 " + json.dumps({"dt_profiled": dts, "contexts": len(ctxs), "families": fams}))
+        else:
+            break
     if not FAKE:
         batch.close()
 
@@ -398,6 +432,8 @@ def rooflines(rawprof, n, m, B, traffic):
     """one entry per kernel family: achieved algorithmic GB/s and TFLOP/s over the family's device time, the fraction of
     each peak, and `bound` = the roof it is closer to.  `traffic` = HBM bytes per launch from the PMC passes, if taken."""
     prof = {k: (tuple(v) if isinstance(v, list) else v) for k, v in rawprof.items()}
+    if isinstance(prof.get("sub"), dict):
+        prof["sub"] = {k: list(v) for k, v in prof["sub"].items()}
     OPD = WORKLOAD["opdim"]
     MSF = 4 if OPD == 3 else 2
     N, D, s = n // MSF, WORKLOAD["delaySteps"], WORKLOAD["s"]
@@ -448,8 +484,18 @@ def rooflines(rawprof, n, m, B, traffic):
         roofs.append(entry("qr_apply", "k_qr_apply_reg", prof["decomp_round_ms"], max(prof["decomp_rounds"], 1), qb * calls * B, qf * calls * B,
                            "block reflectors of up to 4 panels applied to the trailing matrix / to Q with the columns in registers: "
                            "one read + one write per launch, 2 x 8 rows 16 ncols flop per reflector"))
-        rest_ms = max(prof["decomp"][0] - prof["decomp_round_ms"], 0.0)
-        roofs.append(entry("qr_rest", "k_qr_panel, " + ("LU of the Green's function (k_lu_panel, k_lu_rowswap_trsm, K = 32 updates), " if n <= 512 else "") + "triangular solves, glue", rest_ms, max(prof["decomp"][1] - prof["decomp_rounds"], 1),
+        sub = prof.get("sub") or {}
+        sub_ms = 0.0
+        for key, kern, note in (("lu_update", "k_flush<..., TAG = 1> / k_flush_lds<1>", "trailing updates of the LU factorisation inside greenFromUdV (K = 32): a read-modify-write "
+                                 "stream over the trailing matrix with a thin product, on the flush kernel"),
+                                ("fact_gemm", "k_zgemm<..., TAG = 1>", "products inside factorisations: the levels of the recursive triangular solves (N = K = 32 ... 256), "
+                                 "the block Gram-Schmidt QR for n_g > 1024")):
+            v = sub.get(key)
+            if v and v[1] > 0:
+                roofs.append(entry(key, kern, v[0], v[1], v[3], v[2], note))
+                sub_ms += v[0]
+        rest_ms = max(prof["decomp"][0] - prof["decomp_round_ms"] - sub_ms, 0.0)
+        roofs.append(entry("qr_rest", "k_qr_panel, " + ("LU of the Green's function (k_lu_panel, k_lu_rowswap_trsm, K = 32 updates), " if n <= 512 else "") + "triangular solves, glue", rest_ms, max(prof["decomp"][1] - prof["decomp_rounds"] - sum(int(v[1]) for v in sub.values()), 1),
                            0.0, 0.0, "panel factorisations (a chain of dependent reductions: latency bound) and the small kernels "
                            "around the QR; no roofline claimed", latency_bound=True))
     bl = prof["bmult"][1]
@@ -484,7 +530,7 @@ def rooflines(rawprof, n, m, B, traffic):
 def load_traffic(B, D):
     """HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, WRITE_SIZE),
     taken with scripts/pmc_collect.sh + scripts/pmc_traffic_summary.py for this batch size and delay depth"""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_b%d_d%d.json" % (rnd, B, D))
         if os.path.exists(path):
             try:
@@ -616,10 +662,16 @@ def main():
     #   ONE context with ONE chain: the latency of a single Markov chain
     lead = rank == 0
     inproc_solo = None
+    prof4 = None
+    if lead and not a.inprocess and R == 1 and n_gpus == 1:
+        # the timed regime once more with per-family event timing in every context (only when ONE worker drives the whole GPU)
+        send(procs[0][1], "PROF4")
+        prof4 = json.loads(read_tag(procs[0][1], "PROF4"))
     for i, (_, p) in enumerate(procs):
         send(p, "SOLO" if (a.inprocess and lead and i == 0) else "QUIT")
     if a.inprocess and lead:
         inproc_solo = json.loads(read_tag(procs[0][1], "SOLO"))
+        send(procs[0][1], "QUIT")
     for _, p in procs:
         p.wait()
     cpu = CpuBaseline() if (lead and n_gpus == 1 and not a.no_cpu_baseline) else None     # 1-core run overlaps the post-phases
@@ -632,6 +684,7 @@ def main():
         one_ctx = Bc * a.steps / json.loads(read_tag(pw, "RESULT"))["dt"]
         send(pw, "SOLO")
         solo = json.loads(read_tag(pw, "SOLO"))
+        send(pw, "QUIT")
         pw.wait()
         nst = max(2, min(a.steps, 4))
         # one context x ONE chain.  The delay depth is a performance knob (same chain for every depth): a batch amortises the flush of
@@ -709,6 +762,14 @@ def main():
                                           if isinstance(v, tuple) and k != "jacobi"}
             res["decompositions"] = {"svd_calls": prof["svd_calls"], "jacobi_sweeps": prof["svd_sweeps_total"],
                                      "max_sweeps": prof["svd_sweeps_max"], "qr_calls": prof["qr_calls"], "lu_calls": prof.get("lu_calls", 0)}
+        if prof4 and prof4.get("families"):
+            res["device_ms_by_family_timed_regime"] = {
+                "families": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(prof4["families"].items())},
+                "contexts": prof4["contexts"], "sweeps_per_s_with_event_records": R * B * a.steps / prof4["dt_profiled"],
+                "note": "the %d contexts of the timed region profiled TOGETHER (HIP events on each context's own stream, the same %d steps once more): "
+                        "device time summed over the contexts; a family's time includes what its launches waited for kernels of the other "
+                        "contexts, so the sum exceeds contexts x wall time of one context alone; qr_apply, lu_update and fact_gemm are parts of decomp"
+                        % (prof4["contexts"], a.steps)}
         if cpu is not None:
             res.update(cpu.finish(r0["m"], (r0["m"] + WORKLOAD["s"] - 1) // WORKLOAD["s"]))
         print(json.dumps(res), flush=True)

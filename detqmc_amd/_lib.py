@@ -42,6 +42,7 @@ class dqmc_params(C.Structure):
                 ("lambda_", C.c_double),
                 ("txhor", C.c_double), ("txver", C.c_double), ("tyhor", C.c_double), ("tyver", C.c_double),
                 ("mux", C.c_double), ("muy", C.c_double), ("accRatio", C.c_double), ("cdwU", C.c_double),
+                ("rng_window_per_site", C.c_int32), ("reserved_model", C.c_int32),
                 ("tuning", dqmc_tuning)]
 
 
@@ -50,7 +51,13 @@ class dqmc_update_state(C.Structure):
                 ("ra_runningAverage", C.c_double), ("ra_values", C.c_double * 100),
                 ("ra_samplesAdded", C.c_int32), ("ra_head", C.c_int32),
                 ("rng_consumed", C.c_uint64), ("rng_avail", C.c_uint64),
-                ("error", C.c_int32), ("reserved", C.c_int32)]
+                ("error", C.c_int32), ("reserved", C.c_int32),
+                ("angleDelta", C.c_double), ("scaleDelta", C.c_double),
+                ("curminAngleDelta", C.c_double), ("curmaxAngleDelta", C.c_double),
+                ("curminScaleDelta", C.c_double), ("curmaxScaleDelta", C.c_double),
+                ("rot_runningAverage", C.c_double), ("rot_values", C.c_double * 100),
+                ("scl_runningAverage", C.c_double), ("scl_values", C.c_double * 100),
+                ("rot_samplesAdded", C.c_int32), ("rot_head", C.c_int32), ("scl_samplesAdded", C.c_int32), ("scl_head", C.c_int32)]
 
 
 class dqmc_profile(C.Structure):
@@ -58,7 +65,8 @@ class dqmc_profile(C.Structure):
                 ("svd_calls", C.c_uint64), ("svd_sweeps_total", C.c_uint64), ("svd_sweeps_max", C.c_uint64),
                 ("qr_calls", C.c_uint64), ("gemm_flops", C.c_double), ("decomp_round_ms", C.c_double),
                 ("decomp_rounds", C.c_uint64), ("blocks_nonempty", C.c_uint64), ("chains", C.c_uint64),
-                ("updates_accepted", C.c_uint64), ("lu_calls", C.c_uint64)]
+                ("updates_accepted", C.c_uint64), ("lu_calls", C.c_uint64),
+                ("sub_ms", C.c_double * 4), ("sub_launches", C.c_uint64 * 4), ("sub_flops", C.c_double * 4), ("sub_bytes", C.c_double * 4)]
 
 
 class detsdw_params(C.Structure):
@@ -75,6 +83,8 @@ class detsdw_params(C.Structure):
                 ("stabilisation", C.c_int32), ("cb_none", C.c_int32),
                 ("wolffClusterUpdate", C.c_int32), ("wolffClusterShiftUpdate", C.c_int32),
                 ("repeatWolffPerSweep", C.c_int32), ("fermionMeasurements", C.c_int32),
+                ("spinProposalMethod", C.c_int32), ("adaptScaleVariance", C.c_int32), ("repeatUpdateInSlice", C.c_int32),
+                ("reserved_model", C.c_int32),
                 ("tuning", dqmc_tuning)]
 
 
@@ -89,6 +99,7 @@ class detsdw_info(C.Structure):
                 ("addedWolffClusterSize", C.c_double),
                 ("beta", C.c_double), ("dtau", C.c_double),
                 ("phiDelta", C.c_double), ("lastAccRatioLocal_phi", C.c_double), ("r", C.c_double),
+                ("angleDelta", C.c_double), ("scaleDelta", C.c_double),
                 ("rngDrawn", C.c_uint64)]
 
 
@@ -155,6 +166,7 @@ SYMBOLS = [
     ("dqmc_push_uniforms_host", C.c_int, [_P, _DP, C.c_size_t]),
     ("dqmc_push_uniforms_all_host", C.c_int, [_P, _DP, C.c_size_t]),
     ("dqmc_update_slice", C.c_int, [_P, C.c_int, C.c_int]),
+    ("dqmc_update_slice_ex", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("dqmc_get_schedule_info", C.c_int, [_P, C.POINTER(dqmc_schedule_info)]),
     ("dqmc_get_update_states_all_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),
     ("dqmc_get_update_state_host", C.c_int, [_P, C.POINTER(dqmc_update_state)]),

@@ -108,6 +108,10 @@ struct dqmc_ctx {
     double fam_ms[FAM_COUNT] = {0};
     uint64_t fam_launches[FAM_COUNT] = {0};
     double gemm_flops = 0.0;
+    SubProf subprof{};                  // hooks handed to the launchers through Launch::sub while profiling is on
+    std::vector<std::pair<int, int>> sub_open;      // (sub-family, begin event)
+    double sub_ms[SUBFAM_COUNT] = {0}, sub_flops[SUBFAM_COUNT] = {0}, sub_bytes[SUBFAM_COUNT] = {0};
+    uint64_t sub_launches[SUBFAM_COUNT] = {0};
     std::string fault;                  // DQMC_SYNC_CHECK: first kernel family whose work came back with an error
 };
 static const char* const kFamName[FAM_COUNT] = {"k_bmult_chain / site-local V", "k_zgemm (n_g^3 products)", "decomposition (QR / LU / Jacobi, triangular solves)",
@@ -665,7 +669,8 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
             A_(dalloc(c, &c->Gwin, (size_t)MSF * hm.pbudget * (MSF * hm.pbudget + 1)));
         }
     }
-    c->uni_cap = (size_t)(p->opdim + 1 + (p->cdwU != 0.0 ? 2 : 0)) * N * p->m + 64;     // one sweep's worst case (+ the cdwl pass)
+    if (p->rng_window_per_site < 0 || p->rng_window_per_site > 4096) return fail(DQMC_EINVAL, "rng_window_per_site");
+    c->uni_cap = (size_t)(p->rng_window_per_site > 0 ? p->rng_window_per_site : (p->opdim + 1 + (p->cdwU != 0.0 ? 2 : 0))) * N * p->m + 64;     // one sweep's worst case (+ the cdwl pass)
     A_(dalloc(c, &c->uniforms, c->uni_cap));
     A_(dalloc(c, &c->us, 1));
     A_(dalloc(c, &c->scalar_out, 8));
@@ -689,6 +694,9 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     DevUpdateState hus;
     memset(&hus, 0, sizeof(hus));
     hus.pub.phiDelta = 0.5;                 // AdjustmentData::InitialPhiDelta (detsdwopdim.h:489)
+    hus.pub.angleDelta = 0.0; hus.pub.scaleDelta = 0.1;                      // InitialAngleDelta, InitialScaleDelta (:490-491)
+    hus.pub.curminAngleDelta = -1.0; hus.pub.curmaxAngleDelta = 1.0;         // Min / MaxAngleDelta (:494-495)
+    hus.pub.curminScaleDelta = 0.0; hus.pub.curmaxScaleDelta = 1.0;          // Min / MaxScaleDelta (:492-493)
     hus.pub.targetAccRatio = p->accRatio;
     hus.slice_done = 1;
     hus.r = p->r;
@@ -1209,7 +1217,7 @@ extern "C" int dqmc_push_uniforms_host(dqmc_ctx* c, const double* u, size_t nval
     if (!c || (!u && nvals)) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     if (nvals > c->uni_cap)
-        return fail(DQMC_EINVAL, "more uniforms than one sweep can consume ((opdim+1 [+2 with cdwU])*N*m + 64)");
+        return fail(DQMC_EINVAL, "more uniforms than the window holds (rng_window_per_site * N * m + 64; default per site: opdim + 1 [+ 2 with cdwU])");
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(copy_sync(c, selp(c, c->uniforms), u, nvals * sizeof(double), hipMemcpyHostToDevice));
     uint64_t vals[2] = {0, (uint64_t)nvals};
@@ -1223,7 +1231,7 @@ extern "C" int dqmc_push_uniforms_all_host(dqmc_ctx* c, const double* u, size_t 
     if (!c || (!u && nvals)) return fail(DQMC_EINVAL, "null argument");
     (void)hipSetDevice(c->p.device);
     if (nvals > c->uni_cap)
-        return fail(DQMC_EINVAL, "more uniforms than one sweep can consume ((opdim+1 [+2 with cdwU])*N*m + 64)");
+        return fail(DQMC_EINVAL, "more uniforms than the window holds (rng_window_per_site * N * m + 64; default per site: opdim + 1 [+ 2 with cdwU])");
     HIPCHK(hipMemcpy2DAsync(c->uniforms, c->lc.cs, u, nvals * sizeof(double), nvals * sizeof(double), (size_t)c->nb, hipMemcpyHostToDevice, c->st));
     std::vector<uint64_t> vals((size_t)2 * c->nb);
     for (int b = 0; b < c->nb; ++b) { vals[2 * b] = 0; vals[2 * b + 1] = (uint64_t)nvals; }
@@ -1244,10 +1252,21 @@ extern "C" int dqmc_get_update_states_all_host(dqmc_ctx* c, dqmc_update_state* o
 }
 
 extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
+    return dqmc_update_slice_ex(c, k, thermalization, DQMC_PROPOSE_BOX, DQMC_ADAPT_BOX, 0, 1);
+}
+
+extern "C" int dqmc_update_slice_ex(dqmc_ctx* c, int k, int thermalization, int proposal, int adapt, int adapt_scale_variance, int repeat) {
     if (!c) return fail(DQMC_EINVAL, "null ctx");
     (void)hipSetDevice(c->p.device);
     if (k < 1 || k > c->m) return fail(DQMC_EINVAL, "updateInSlice: k out of range");
     if (c->currentTimeslice != k) return fail(DQMC_EINVAL, "updateInSlice: currentTimeslice != k");
+    if (proposal < DQMC_PROPOSE_BOX || proposal > DQMC_PROPOSE_ROTATE_AND_SCALE) return fail(DQMC_EINVAL, "updateInSlice: unknown proposal kind");
+    if (proposal != DQMC_PROPOSE_BOX && (c->p.opdim != 3 || c->hm.hubbard))
+        return fail(DQMC_EINVAL, "rotate / scale proposals are only supported for the O(3) model");      // detsdwopdim.cpp:3938, 4012, 4085
+    if (adapt < DQMC_ADAPT_BOX || adapt > DQMC_ADAPT_SCALE) return fail(DQMC_EINVAL, "updateInSlice: unknown adaptation");
+    if (repeat < 1) return fail(DQMC_EINVAL, "repeatUpdateInSlice must be >= 1");
+    if (c->hm.hubbard && repeat != 1) return fail(DQMC_EINVAL, "Hubbard replica: repeat must be 1");
+    const int adapt_what = adapt | (adapt_scale_variance ? 4 : 0);
     if (c->hm.hubbard) {            // DetHubbard::updateInSlice (dethubbard.cpp:141-172): the whole slice in one launch
         ProfScope ps(c, FAM_UPDATE, 1);
         launch_hubbard_slice(c->lc, c->hm, c->us, c->uniforms, c->G, k, c->hub_e_m2a, c->hub_e_p2a);
@@ -1261,12 +1280,12 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
     // schedule: the flush is timed / checked on the stream it runs on.
     const bool pipe = c->pipelined;
     Launch lc2 = c->lc; lc2.st = c->st2;
-    auto pass = [&](int cdw_pass) -> int {
+    auto pass = [&](int cdw_pass, int thermal, int reset_nd) -> int {
         for (int r = 0; r < rounds; ++r) {
             {
                 ProfScope ps(c, FAM_UPDATE, 1);
-                launch_update_decide(c->lc, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, cdw_pass ? 0 : thermalization, cdw_pass,
-                                     c->Gwin, (pipe && r > 0) ? c->pipe_P : 0);
+                launch_update_decide(c->lc, nullptr, c->hm, c->us, c->uniforms, c->G, c->W, k, r == 0, cdw_pass ? 0 : thermal, cdw_pass,
+                                     c->Gwin, (pipe && r > 0) ? c->pipe_P : 0, proposal, adapt_what, reset_nd && r == 0);
             }
             if (pipe && r > 0) HIPCHK(hipStreamWaitEvent(c->st, c->ev_flush, 0));      // gather reads whole rows / columns of the flushed G
             {
@@ -1292,10 +1311,12 @@ extern "C" int dqmc_update_slice(dqmc_ctx* c, int k, int thermalization) {
         if (pipe) HIPCHK(hipStreamWaitEvent(c->st, c->ev_flush, 0));                     // whatever comes next on the main stream sees the flushed G
         return DQMC_OK;
     };
-    { int rc = pass(0); if (rc) return rc; }
+    // repeatUpdateInSlice passes over the slice (detsdwopdim.cpp:2438); the step-size adaptation sees the last one's acceptance ratio
+    // (updateInSliceThermalization, :3294-3331); the Box-Muller stack of the scale proposals is reset once per updateInSlice (:2433)
+    for (int rep = 0; rep < repeat; ++rep) { int rc = pass(0, (thermalization && rep == repeat - 1) ? 1 : 0, rep == 0); if (rc) return rc; }
     // cdwU != 0: the second pass over the slice updates the discrete field (detsdwopdim.cpp:2474-2485); its acceptance ratio is
     // discarded there and here (no step-width adaptation)
-    if (c->hm.cdw_on) { int rc = pass(1); if (rc) return rc; }
+    if (c->hm.cdw_on) { int rc = pass(1, 0, 0); if (rc) return rc; }
     return finish(c, "dqmc_update_slice");
 }
 
@@ -1562,6 +1583,19 @@ extern "C" int dqmc_set_exchange_parameter(dqmc_ctx* c, double r) {
 // ---------------------------------------------------------------------------------------------
 // profiling
 // ---------------------------------------------------------------------------------------------
+static void sub_prof_begin(void* u, int sub) {
+    dqmc_ctx* c = (dqmc_ctx*)u;
+    if (c->ev_used + 2 > c->ev_pool.size())
+        for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
+    (void)hipEventRecord(c->ev_pool[c->ev_used], c->st);
+    c->sub_open.push_back({sub, (int)c->ev_used});
+    c->ev_used += 2;
+}
+static void sub_prof_end(void* u, int sub, double flops, double bytes) {
+    dqmc_ctx* c = (dqmc_ctx*)u;
+    (void)hipEventRecord(c->ev_pool[c->sub_open.back().second + 1], c->st);
+    c->sub_launches[sub] += 1; c->sub_flops[sub] += flops; c->sub_bytes[sub] += bytes;
+}
 static void prof_collect(dqmc_ctx* c) {
     (void)hipStreamSynchronize(c->st);
     if (c->st2) (void)hipStreamSynchronize(c->st2);
@@ -1570,6 +1604,12 @@ static void prof_collect(dqmc_ctx* c) {
         if (hipEventElapsedTime(&ms, c->ev_pool[o.second], c->ev_pool[o.second + 1]) == hipSuccess)
             c->fam_ms[o.first] += ms;
     }
+    for (auto& o : c->sub_open) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[o.second], c->ev_pool[o.second + 1]) == hipSuccess)
+            c->sub_ms[o.first] += ms;
+    }
+    c->sub_open.clear();
     c->ev_open.clear();
     c->ev_used = 0;
 }
@@ -1578,7 +1618,10 @@ extern "C" int dqmc_profile_enable(dqmc_ctx* c, int on) {
     (void)hipSetDevice(c->p.device);
     prof_collect(c);
     c->prof = on != 0;
+    c->subprof = SubProf{sub_prof_begin, sub_prof_end, c};
+    c->lc.sub = c->prof ? &c->subprof : nullptr;
     for (int i = 0; i < FAM_COUNT; ++i) { c->fam_ms[i] = 0; c->fam_launches[i] = 0; }
+    for (int i = 0; i < SUBFAM_COUNT; ++i) { c->sub_ms[i] = 0; c->sub_flops[i] = 0; c->sub_bytes[i] = 0; c->sub_launches[i] = 0; }
     c->svd_calls = 0; c->svd_sweeps_total = 0; c->svd_sweeps_max = 0; c->qr_calls = 0; c->lu_calls = 0; c->gemm_flops = 0.0;
     const unsigned long long zero[2] = {0, 0};
     for (int b = 0; b < c->nb; ++b)
@@ -1606,5 +1649,8 @@ extern "C" int dqmc_profile_read(dqmc_ctx* c, dqmc_profile* out) {
         out->updates_accepted += v[1];
     }
     out->chains = (uint64_t)c->nb;
+    for (int i = 0; i < SUBFAM_COUNT; ++i) {
+        out->sub_ms[i] = c->sub_ms[i]; out->sub_launches[i] = c->sub_launches[i]; out->sub_flops[i] = c->sub_flops[i]; out->sub_bytes[i] = c->sub_bytes[i];
+    }
     return DQMC_OK;
 }

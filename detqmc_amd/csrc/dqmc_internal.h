@@ -29,7 +29,12 @@ typedef double2 cplx;   // .x = re, .y = im; same bytes as dqmc_cplx / std::comp
 // chain b lives at (address of chain 0's buffer) + b * cs: all chains share one arena layout.  Kernels are
 // launched with gridDim.z = nb and shift their per-chain pointer arguments by blockIdx.z * cs; read-only
 // tables (plaquette tables, neighbours, tournament schedule) are shared and never shifted.
-struct Launch { hipStream_t st; int nb; size_t cs; };
+// sub: optional timing hooks for launches that belong to a kernel family of their own INSIDE a larger scope (profiling only): the
+// trailing updates of the LU factorisation on the flush kernel (sub-family 0) and the products inside factorisations / triangular
+// solves on k_zgemm (sub-family 1) -- both fill the GPU and are priced against a roof, unlike the panel kernels around them
+enum { SUBFAM_LU_UPDATE = 0, SUBFAM_FACT_GEMM = 1, SUBFAM_COUNT = 4 };
+struct SubProf { void (*begin)(void* user, int sub); void (*end)(void* user, int sub, double flops, double bytes); void* user; };
+struct Launch { hipStream_t st; int nb; size_t cs; const SubProf* sub = nullptr; };
 template<class T> __device__ __forceinline__ T* chain_ptr(T* p, size_t cs) {
     return p ? (T*)((char*)p + (size_t)blockIdx.z * cs) : p;
 }
@@ -118,6 +123,8 @@ struct DevUpdateState {
     int block_j;             // accepted updates in the block the last decision launch produced
     int slice_done;
     int flush_k;             // K = MSF j of the block whose flush is in flight (pipelined update: block_j already belongs to the next block)
+    int nd_has;              // rotate / scale proposals: the Box-Muller stack of NormalDistribution holds a value (normaldistribution.h), ...
+    double nd_cached;        // ... this one; reset at the top of every updateInSlice
     int chol_fail;           // set by k_chol64 when a Cholesky-QR panel fails its pivot test; read and cleared by the host after the factorisation
     double r;                // this chain's exchange parameter (differs between the chains of a batch)
     int block_sites[DQMC_MAX_WDIM];
@@ -191,7 +198,8 @@ void launch_cdw_terms(const Launch& lc, const DevModel& hm);      // cdwC / cdwS
 // cdw_mode 0: phi proposals (with the cdw terms in e^{dtau V} when cdw_on); 1: the cdwl pass (proposeNewCDWl, :4173-4182)
 void launch_update_decide(const Launch& lc, const DevModel* dm, const DevModel& hm, DevUpdateState* us,
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal, int cdw_pass = 0,
-                          const cplx* Gwin = nullptr, int winP = 0);      // winP > 0: G entries from the window copy (k_update_window)
+                          const cplx* Gwin = nullptr, int winP = 0,       // winP > 0: G entries from the window copy (k_update_window)
+                          int proposal = 0, int adapt_what = 0, int reset_nd = 0);   // proposal: DQMC_PROPOSE_*; adapt_what: 0 box, 1 rotate, 2 scale (+ 4: adaptScaleVariance)
 void launch_update_window(const Launch& lc, const DevModel& hm, DevUpdateState* us, const cplx* G, const cplx* X, const cplx* GrT,
                           cplx* Gw, int P);
 void launch_update_gather(const Launch& lc, const DevModel& hm, const DevUpdateState* us, const cplx* G,

@@ -27,7 +27,9 @@ static bool same_model(const detsdw_params& a, const detsdw_params& b, bool seed
                       a.weakZflux == b.weakZflux && a.phi2bosons == b.phi2bosons && a.has_mux_muy == b.has_mux_muy &&
                       a.updateMethod == b.updateMethod && a.stabilisation == b.stabilisation && a.cb_none == b.cb_none &&
                       a.wolffClusterUpdate == b.wolffClusterUpdate && a.wolffClusterShiftUpdate == b.wolffClusterShiftUpdate &&
-                      a.repeatWolffPerSweep == b.repeatWolffPerSweep && a.fermionMeasurements == b.fermionMeasurements;
+                      a.repeatWolffPerSweep == b.repeatWolffPerSweep && a.fermionMeasurements == b.fermionMeasurements &&
+                      a.spinProposalMethod == b.spinProposalMethod && a.adaptScaleVariance == b.adaptScaleVariance &&
+                      a.repeatUpdateInSlice == b.repeatUpdateInSlice;
     const bool reals = a.beta == b.beta && a.dtau == b.dtau && a.c == b.c && a.u == b.u && a.lambda == b.lambda &&
                        a.txhor == b.txhor && a.txver == b.txver && a.tyhor == b.tyhor && a.tyver == b.tyver &&
                        a.mu == b.mu && a.mux == b.mux && a.muy == b.muy && a.accRatio == b.accRatio && a.cdwU == b.cdwU;
@@ -88,6 +90,11 @@ void DetSDW::normalise(detsdw_params& p, int& bcv) {
     if (p.updateMethod == 2 && (p.delaySteps <= 0 || p.delaySteps > N))
         throw ParameterWrong("Parameter delaySteps has incorrect value");
     if (p.repeatWolffPerSweep == 0) p.repeatWolffPerSweep = 1;
+    if (p.repeatUpdateInSlice == 0) p.repeatUpdateInSlice = 1;
+    if (p.repeatUpdateInSlice < 1) throw ParameterWrong("Parameter repeatUpdateInSlice has incorrect value");
+    if (p.spinProposalMethod < 0 || p.spinProposalMethod > 2) throw ParameterWrong("Parameter spinProposalMethod has incorrect value");     // detsdwparams.cpp:81-87
+    if (p.spinProposalMethod != 0 && p.opdim != 3)      // the reference throws from the first proposal (detsdwopdim.cpp:3938, 4012, 4085)
+        throw ParameterWrong("spinProposalMethod rotate_then_scale / rotate_and_scale is only supported for the O(3) model");
     if ((p.globalShift || p.wolffClusterUpdate || p.wolffClusterShiftUpdate) && p.globalUpdateInterval == 0)
         throw ParameterWrong("Parameter globalUpdateInterval has incorrect value");                      // detsdwparams.cpp:89-93
     if (p.wolffClusterShiftUpdate && (p.globalShift || p.wolffClusterUpdate))
@@ -136,6 +143,7 @@ DetSDW::DetSDW(const detsdw_params* in, int nchains, int sub_batches) {
     kp.mux = p.mux; kp.muy = p.muy; kp.accRatio = p.accRatio; kp.cdwU = p.cdwU;
     kp.stabilisation = p.stabilisation;
     kp.cb_none = p.cb_none ? 1 : 0;          // reference option checkerboard=false (DetSDW<CB_NONE, OPDIM>)
+    kp.rng_window_per_site = uniformsPerSite();
     // result-neutral execution choices.  The pipelined update pays only while few contexts share the GPU (with more of them the
     // contexts overlap each other instead): automatic here means at most two sub-batches.
     kp.tuning = p.tuning;
@@ -183,8 +191,7 @@ void DetSDW::setupUdVStorage_and_calculateGreen(Group& g) {
 
 // Ship the worst-case number of upcoming uniforms of this sweep; the device consumes a prefix.
 void DetSDW::beginLocalUpdates(Group& g) {
-    // per slice and site: opdim box draws + at most one acceptance draw; with cdwU one proposal + one acceptance draw more
-    const size_t need = (size_t)(opdim_ + 1 + (ch_[0].pars.cdwU != 0.0 ? 2 : 0)) * N_ * m_;
+    const size_t need = (size_t)uniformsPerSite() * N_ * m_;
     g.window.resize(need * g.count);               // all chains' windows back to back: one host -> device transfer
     for (int b = 0; b < g.count; ++b) std::memcpy(&g.window[b * need], ch_[g.first + b].rng.peek(need), need * sizeof(double));
     check(dqmc_push_uniforms_all_host(g.ctx, g.window.data(), need), "dqmc_push_uniforms_all_host");
@@ -197,11 +204,32 @@ void DetSDW::endLocalUpdates(Group& g) {
         c.rng.consume((size_t)st[b].rng_consumed);
         c.phiDelta = st[b].phiDelta;
         c.lastAccRatio = st[b].lastAccRatio;
+        c.angleDelta = st[b].angleDelta;
+        c.scaleDelta = st[b].scaleDelta;
     }
 }
 
+// per site and slice of a sweep: what the local updates can consume from the RNG stream -- box: opdim proposal draws + at most one
+// acceptance draw; rotate / scale: a Gaussian draw costs a variable number (polar Box-Muller), 8 is far above the mean of ~ 3.6 and an
+// overrun is reported (DQMC_ERNG), never silent; times repeatUpdateInSlice; the cdwl pass: one proposal + one acceptance draw
+int DetSDW::uniformsPerSite() const {
+    const detsdw_params& p = ch_[0].pars;
+    const int per_pass = p.spinProposalMethod == 0 ? p.opdim + 1 : 8;
+    return per_pass * p.repeatUpdateInSlice + (p.cdwU != 0.0 ? 2 : 0);
+}
+
+// which proposal / adaptation this sweep uses (updateInSlice, updateInSliceThermalization: detsdwopdim.cpp:2438-2470, 3299-3321)
 void DetSDW::updateInSlice(Group& g, int k, bool thermalization) {
-    check(dqmc_update_slice(g.ctx, k, thermalization ? 1 : 0), "updateInSlice");
+    const detsdw_params& p = ch_[0].pars;
+    int proposal = DQMC_PROPOSE_BOX, adapt = DQMC_ADAPT_BOX;
+    if (p.spinProposalMethod == 1) {                       // rotate_then_scale: each sweep alternates between rotating and scaling
+        proposal = (performedSweeps_ % 2 == 0) ? DQMC_PROPOSE_ROTATE : DQMC_PROPOSE_SCALE;
+        adapt = (performedSweeps_ % 2 == 0) ? DQMC_ADAPT_ROTATE : DQMC_ADAPT_SCALE;
+    } else if (p.spinProposalMethod == 2) {                // rotate_and_scale: the adapted quantity alternates every 100 sweeps
+        proposal = DQMC_PROPOSE_ROTATE_AND_SCALE;
+        adapt = (performedSweeps_ % 200 < 100) ? DQMC_ADAPT_ROTATE : DQMC_ADAPT_SCALE;
+    }
+    check(dqmc_update_slice_ex(g.ctx, k, thermalization ? 1 : 0, proposal, adapt, p.adaptScaleVariance, p.repeatUpdateInSlice), "updateInSlice");
     if (measuring_) check(dqmc_measure_slice(g.ctx), "measure");     // updateInSliceAndMaybeMeasure (detmodel.h:1279-1285)
 }
 
@@ -635,6 +663,8 @@ void DetSDW::set_control_data(const detsdw_control_data& in, int b) {
     check(dqmc_set_update_state_host(ctx_, &st), "set_control_data");
     ch_[b].phiDelta = st.phiDelta;
     ch_[b].lastAccRatio = st.lastAccRatio;
+    ch_[b].angleDelta = st.angleDelta;
+    ch_[b].scaleDelta = st.scaleDelta;
 }
 
 void DetSDW::getInfo(detsdw_info& o, int b) {
@@ -651,6 +681,7 @@ void DetSDW::getInfo(detsdw_info& o, int b) {
     o.currentTimeslice = dqmc_current_timeslice(ctx_);
     o.beta = c.pars.beta; o.dtau = c.pars.dtau; o.phiDelta = c.phiDelta; o.lastAccRatioLocal_phi = c.lastAccRatio;
     o.r = c.pars.r; o.rngDrawn = c.rng.drawn();
+    o.angleDelta = c.angleDelta; o.scaleDelta = c.scaleDelta;
 }
 void DetSDW::getPhi(double* out, int b) {
     syncPhiFromDevice(b);

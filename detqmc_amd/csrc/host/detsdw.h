@@ -81,6 +81,7 @@ private:
         int acceptedWolffClusterShiftUpdates = 0, attemptedWolffClusterShiftUpdates = 0;
         double addedWolffClusterSize = 0.0;
         double phiDelta = 0.5, lastAccRatio = 0.0;
+        double angleDelta = 0.0, scaleDelta = 0.1;          // AdjustmentData::InitialAngleDelta / InitialScaleDelta (detsdwopdim.h:490-491)
         detsdw_observables obs{};
         std::vector<double> kOccX, kOccY, pairPlus, pairMinus;
         Chain(const detsdw_params& p) : pars(p), rng(p.rngSeed, (uint32_t)p.simindex + 1u) {}   // detqmc.h:181
@@ -111,6 +112,7 @@ private:
     void sweepDown(Group& g, bool thermalization);
     void sweepUp(Group& g, bool thermalization);
     void updateInSlice(Group& g, int k, bool thermalization);
+    int uniformsPerSite() const;
     void beginLocalUpdates(Group& g);
     void endLocalUpdates(Group& g);
     void globalMove(Group& g);

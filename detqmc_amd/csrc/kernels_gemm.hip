@@ -536,8 +536,17 @@ static bool use_4m() {
     return v;
 }
 
+static void launch_flush_impl(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx* G, int ldc, int n, int Kmax,
+                              const int* Kdev, int Kmul, int tag);
 void launch_flush(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx* G, int ldc, int n, int Kmax,
                   const int* Kdev, int Kmul, int tag) {
+    const bool sub = tag && lc.sub;
+    if (sub) lc.sub->begin(lc.sub->user, SUBFAM_LU_UPDATE);
+    launch_flush_impl(lc, X, GrT, ld, G, ldc, n, Kmax, Kdev, Kmul, tag);
+    if (sub) lc.sub->end(lc.sub->user, SUBFAM_LU_UPDATE, 8.0 * n * n * Kmax * lc.nb, 16.0 * (2.0 * n * n + 2.0 * n * Kmax) * lc.nb);
+}
+static void launch_flush_impl(const Launch& lc, const cplx* X, const cplx* GrT, int ld, cplx* G, int ldc, int n, int Kmax,
+                              const int* Kdev, int Kmul, int tag) {
     const int tn = (n + 63) / 64;
     const dim3 grid = (lc.nb % 8 == 0) ? dim3(tn * tn * lc.nb, 1, 1) : dim3(tn * tn, 1, lc.nb);
     static const bool force_ragged = dev_knob("DQMC_FLUSH_RAGGED") && atoi(dev_knob("DQMC_FLUSH_RAGGED")) != 0;   // developer knob (A/B)
@@ -635,6 +644,10 @@ static void launch_gemm_tagged(const Launch& lc, const GemmArgs& a) {
     }
 }
 void launch_gemm(const Launch& lc, const GemmArgs& a) {
-    if (a.tag) launch_gemm_tagged<1>(lc, a);
-    else       launch_gemm_tagged<0>(lc, a);
+    if (a.tag) {
+        if (lc.sub) lc.sub->begin(lc.sub->user, SUBFAM_FACT_GEMM);
+        launch_gemm_tagged<1>(lc, a);
+        if (lc.sub) lc.sub->end(lc.sub->user, SUBFAM_FACT_GEMM, 8.0 * a.M * a.N * a.K * lc.nb,
+                                16.0 * ((double)a.M * a.K + (double)a.K * a.N + (a.accumulate ? 2.0 : 1.0) * a.M * a.N) * lc.nb);
+    } else launch_gemm_tagged<0>(lc, a);
 }

@@ -165,6 +165,27 @@ __device__ __forceinline__ double u_wave_total(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// ---- rotate / scale proposals of the O(3) model (detsdwopdim.cpp:3934-4170), arithmetic in the reference's order, no fma contraction.
+// The transcendental functions (sincos, pow, log) are the device library's: they agree with glibc's to an ulp or two, so a proposed
+// field agrees with the reference's to ~1e-16 relative rather than bit for bit (tests: same decisions, fields to 1e-13).
+// unit vector of the new direction: cone around the old direction v, cos(theta) = ct, azimuth ph (proposeRandomRotatedVector<3>, :3945-3992)
+__device__ __forceinline__ void rot3_unit(const double (&v)[3], double ct, double ph, double& r_out, double (&out)[3]) {
+#pragma clang fp contract(off)
+    const double x = v[0], y = v[1], z = v[2];
+    const double x2 = x * x, y2 = y * y, z2 = z * z;
+    const double r2 = x2 + y2 + z2;
+    const double r = sqrt(r2);
+    const double st = sqrt(1.0 - ct * ct);
+    double sp, cp;
+    sincos(ph, &sp, &cp);
+    const double x2n = x2 / r2, y2n = y2 / r2;
+    const double xn = x / r, yn = y / r, zn = z / r;
+    out[0] = (st / (x2n + y2n)) * ((x2n * zn + y2n) * cp + (zn - 1) * xn * yn * sp) + xn * ct;
+    out[1] = (st / (x2n + y2n)) * ((zn - 1) * xn * yn * cp + (x2n + y2n * zn) * sp) + yn * ct;
+    out[2] = -st * (xn * cp + yn * sp) + zn * ct;
+    r_out = r;
+}
+
 // Everything the decision for ONE candidate site needs from global memory is loaded one candidate ahead
 // (while the previous decision is being computed), so the L2 round trip of the scattered G entries and of
 // the field values never sits on the critical path of the sequential chain.  The ~44 scalars (uniforms, field
@@ -174,14 +195,23 @@ __device__ __forceinline__ double u_wave_total(double v) {
 // CDW 0: cdwU == 0.  CDW 1: phi proposals with the cdw terms of the site in e^{+-dtau V}.  CDW 2: the second pass over the slice
 // (detsdwopdim.cpp:2474-2485) -- proposeNewCDWl (:4173-4182): ONE uniform picks the new l, phi stays, probSPhi = 1 and the ratio
 // cdwl_gamma(new) / cdwl_gamma(old) joins the acceptance probability (:3110); its acceptance ratio is discarded.
-template<int OPDIM, int CDW>
+// PROP (round 4; O(3) only, spinProposalMethod != box, detsdwopdim.cpp:3934-4170): 0 box, 1 proposeRotatedPhi (two uniforms: cos(theta) in
+// [angleDelta, 1] and the azimuth), 2 proposeScaledPhi (|phi|^3 Gaussian around its old value: polar Box-Muller on the replica's stream,
+// normaldistribution.h -- a VARIABLE number of uniforms, the second value of a pair kept for the next proposal; not positive => the
+// proposal is dropped without an acceptance draw), 3 proposeRotatedScaledPhi (the Gaussian draw, then the two uniforms of the rotation).
+// The uniforms of such a proposal come from a window of UNIW values that starts at the cursor the candidate's prefetch was issued
+// with (exact: the decision before it is still open, but a window is long enough for both outcomes); beyond it: direct loads.
+// adapt_what (thermalisation, end of the slice): 0 ADAPT_BOX, 1 ADAPT_ROTATE, 2 ADAPT_SCALE (+ 4: adaptScaleVariance), :3299-3375.
+template<int OPDIM, int CDW, int PROP>
 __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
                                                        const cplx* __restrict__ Gfull, cplx* __restrict__ Wout,
                                                        int k, int first, int thermal, size_t cs,
-                                                       const cplx* __restrict__ Gwin, int winP) {
+                                                       const cplx* __restrict__ Gwin, int winP, int adapt_what, int reset_nd) {
+    static_assert(PROP == 0 || (OPDIM == 3 && CDW != 2), "rotate / scale proposals belong to the phi pass of the O(3) model");
     constexpr int MSF = (OPDIM == 3) ? 4 : 2;
     constexpr int SLOTS = MSF * DQMC_MAX_WDIM / 64;
-    constexpr int NPROP = (CDW == 2) ? 1 : OPDIM;      // uniforms a proposal draws
+    constexpr int NPROP = (CDW == 2) ? 1 : OPDIM;      // uniforms a BOX proposal draws
+    constexpr int UNIW = 16;                           // PROP != 0: prefetched window of uniforms
     dm = chain_model(dm, cs); CHAIN(us); CHAIN(uni); CHAIN(Gfull); CHAIN(Wout); CHAIN(Gwin);
     dm.r = us->r;                         // the exchange parameter differs between the chains of a batch
     const int N = dm.N, D = dm.D, m = dm.m;
@@ -227,7 +257,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
 
     // ---- scalar items of one candidate, as doubles (lane l of wave 0 loads item l, l + 64, ...) ----
     constexpr int O_UNI = 0;                       // OPDIM + 2 uniforms: the decision before may or may not have
-    constexpr int O_TL = O_UNI + OPDIM + 2;        //   consumed one more than the guess the loads were issued with
+    constexpr int O_TL = O_UNI + (PROP == 0 ? OPDIM + 2 : UNIW);   //   consumed one more than the guess the loads were issued with
     constexpr int O_TE = O_TL + OPDIM;             // phi(later slice), phi(earlier slice)
     constexpr int O_CH = O_TE + OPDIM;
     constexpr int O_SH = O_CH + 1;
@@ -330,12 +360,18 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     // for the store's round trip (s_waitcnt vmcnt(0)) before every prefetch.  The slice's field lives in LDS.
     for (int t = tid; t < OPDIM * N; t += 256) sphi[t] = phik[t];
     int cnd_nI = 0;                                // nI the u/v registers were loaded for
+    [[maybe_unused]] unsigned long long win_cur = cur;      // PROP != 0: cursor the current candidate's window of uniforms starts at
+    // PROP 2 / 3: the Box-Muller stack of NormalDistribution (normaldistribution.h:44-78) -- after a pair has been generated its first
+    // value waits for the next get(); reset at the top of updateInSlice (:2433-2435), kept across the launches and repeats of a slice
+    [[maybe_unused]] bool nd_has = (PROP >= 2 && !reset_nd) ? (us->nd_has != 0) : false;
+    [[maybe_unused]] double nd_cached = (PROP >= 2 && !reset_nd) ? us->nd_cached : 0.0;
+    [[maybe_unused]] const double angleDelta = us->pub.angleDelta, scaleDelta = us->pub.scaleDelta;
     int prev_site = -1;                            // site decided in the previous iteration
     bool prev_acc = false, prev_used_uniform = true;
 
     int it = 0;                                    // proposal counter of this launch: selects the u/v buffer
     while (j < dnow && site < N && it < budget) {
-        if (cur + NPROP + 1 > avail) { err = DQMC_ERNG; break; }
+        if (cur + (PROP == 0 ? NPROP + 1 : 2 * UNIW) > avail) { err = DQMC_ERNG; break; }
         const int nI = MSF * j;
         cplx* su = su2 + (it & 1) * MSF * WD;
         cplx* sv = sv2 + (it & 1) * WD * MSF;
@@ -374,7 +410,8 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         // not behind the last proposal of the budget: that candidate belongs to the next launch, and with a window copy (winP > 0)
         // its entries lie outside the (MSF P)^2 window this launch may read
         const bool have_next = (site + 1 < N) && (it + 1 < budget);
-        if (have_next) fetch(pre, pu, pv, site + 1, site, cur + NPROP, nI);
+        if (have_next) fetch(pre, pu, pv, site + 1, site, PROP == 0 ? cur + NPROP : cur, nI);
+        [[maybe_unused]] const unsigned long long fetch_cur_next = cur;     // PROP != 0: where the NEXT candidate's window starts
         // ---- the waves split the work between the two barriers: wave 0 does the scalar Metropolis arithmetic of this
         //      proposal (D) and hands delta, exp(-dS), the acceptance uniform and G[c,c] to the others through LDS; waves
         //      1-3 meanwhile form p and q (E).  Neither waits for the other before barrier 2. ----
@@ -383,7 +420,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         double newphi[OPDIM], coshN = 0.0, sinhN = 0.0;
 #pragma unroll
         for (int d = 0; d < OPDIM; ++d) newphi[d] = 0.0;
-        cur += NPROP;
+        if constexpr (PROP == 0) cur += NPROP;             // (PROP != 0: the count comes back from wave 0 behind barrier 2)
         double lnew = 0.0, cCn = 1.0, sCn = 0.0;          // CDW 2: the proposed l and its cosh / sinh terms
         TICK(2);
         if (tid >= 64) {
@@ -433,11 +470,91 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             int nbr[4];
             neighbours(site, nbr);
             double oldphi[OPDIM], snb[OPDIM], tnb[OPDIM];
+            [[maybe_unused]] int consumed = 0;           // PROP != 0: uniforms this proposal drew
+            [[maybe_unused]] bool valid = true;          //            changed != NONE
+            [[maybe_unused]] double uacc_peek = 0.5;
+            if constexpr (PROP != 0) {
+                int wpos = (int)(cur - win_cur);
+                auto next_uniform = [&]() -> double {
+                    const int wp = wpos + consumed;
+                    double v;
+                    if (wp < UNIW) v = scand[O_UNI + wp];
+                    else { const unsigned long long idx = cur + consumed; v = idx < avail ? uni[idx] : 0.25; }
+                    consumed += 1;
+                    return v;
+                };
+                double ov[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) ov[d] = sphi[d * N + site];
+                [[maybe_unused]] auto nd_get = [&](double sigma, double mean) -> double {     // NormalDistribution::get
+#pragma clang fp contract(off)
+                    double var;
+                    if (!nd_has) {
+                        double v1, v2, rsq;
+                        int guard = 0;
+                        do {
+                            const double u1 = next_uniform(), u2 = next_uniform();
+                            v1 = 2.0 * u1 - 1.0; v2 = 2.0 * u2 - 1.0;
+                            rsq = v1 * v1 + v2 * v2;
+                        } while ((rsq >= 1.0 || rsq == 0.0) && ++guard < 64);
+                        const double fac = sqrt(-2.0 * log(rsq) / rsq);
+                        nd_cached = v1 * fac;            // pushed first, handed out second
+                        var = v2 * fac;
+                        nd_has = true;
+                    } else { var = nd_cached; nd_has = false; }
+                    const double t = sigma * var;
+                    return mean + t;
+                };
+                double nv[3] = {ov[0], ov[1], ov[2]};
+                if constexpr (PROP == 1) {
+#pragma clang fp contract(off)
+                    const double a0 = next_uniform(), a1 = next_uniform();
+                    const double span = 1.0 - angleDelta;
+                    const double ct = a0 * span + angleDelta;
+                    const double ph = a1 * 2.0 * M_PI;
+                    double r, un[3];
+                    rot3_unit(ov, ct, ph, r, un);
+                    nv[0] = un[0] * r; nv[1] = un[1] * r; nv[2] = un[2] * r;
+                } else if constexpr (PROP == 2) {
+#pragma clang fp contract(off)
+                    const double r3 = pow(ov[0] * ov[0] + ov[1] * ov[1] + ov[2] * ov[2], 1.5);
+                    const double new_r3 = nd_get(scaleDelta, r3);
+                    if (new_r3 <= 0) valid = false;
+                    else {
+                        const double q = new_r3 / r3;
+                        const double scale = pow(q, 1.0 / 3.0);
+                        nv[0] = ov[0] * scale; nv[1] = ov[1] * scale; nv[2] = ov[2] * scale;
+                    }
+                } else {
+#pragma clang fp contract(off)
+                    const double rr = sqrt(ov[0] * ov[0] + ov[1] * ov[1] + ov[2] * ov[2]);
+                    const double r3 = pow(rr, 3.0);
+                    const double new_r3 = nd_get(scaleDelta, r3);
+                    if (new_r3 <= 0) valid = false;
+                    else {
+                        const double a0 = next_uniform(), a1 = next_uniform();
+                        const double span = 1.0 - angleDelta;
+                        const double ct = a0 * span + angleDelta;
+                        const double ph = a1 * 2.0 * M_PI;
+                        double r, un[3];
+                        rot3_unit(ov, ct, ph, r, un);
+                        const double new_r = pow(new_r3, 1.0 / 3.0);
+                        nv[0] = un[0] * new_r; nv[1] = un[1] * new_r; nv[2] = un[2] * new_r;
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < OPDIM; ++d) newphi[d] = nv[d < 3 ? d : 0];
+                {   // the uniform an acceptance test would draw next (not consumed here)
+                    const int wp = wpos + consumed;
+                    if (wp < UNIW) uacc_peek = scand[O_UNI + wp];
+                    else { const unsigned long long idx = cur + consumed; uacc_peek = idx < avail ? uni[idx] : 0.5; }
+                }
+            }
 #pragma unroll
             for (int d = 0; d < OPDIM; ++d) {
                 oldphi[d] = sphi[d * N + site];
                 double low = -phiDelta, high = phiDelta;
-                newphi[d] = (CDW == 2) ? oldphi[d] : propose_component(oldphi[d], low, high, scand[O_UNI + uoff + d]);
+                if constexpr (PROP == 0) newphi[d] = (CDW == 2) ? oldphi[d] : propose_component(oldphi[d], low, high, scand[O_UNI + uoff + d]);
                 // XPLUS, XMINUS, YPLUS, YMINUS in the order of the reference's neighbour loop (:4208-4214)
                 snb[d] = ((0.0 + sphi[d * N + nbr[0]]) + sphi[d * N + nbr[1]]) + sphi[d * N + nbr[2]] + sphi[d * N + nbr[3]];
                 tnb[d] = scand[O_TL + d] + scand[O_TE + d];
@@ -526,7 +643,8 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             }
             if (tid == 0) {
                 sdec[4 * MSF * MSF] = probSPhi;
-                sdec[4 * MSF * MSF + 1] = scand[O_UNI + uoff + NPROP];
+                if constexpr (PROP == 0) sdec[4 * MSF * MSF + 1] = scand[O_UNI + uoff + NPROP];
+                else { sdec[4 * MSF * MSF + 1] = uacc_peek; sdec[4 * MSF * MSF + 2] = valid ? 0.0 : 2.0; sdec[4 * MSF * MSF + 3] = (double)consumed; }
                 if constexpr (CDW == 2) { sdec[4 * MSF * MSF + 2] = nullp ? 1.0 : 0.0; sdec[4 * MSF * MSF + 3] = lnew; }
             }
         }
@@ -639,7 +757,13 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         if constexpr (CDW == 2) {
             if (sdec[4 * MSF * MSF + 2] != 0.0) { prob = 1.0; accept = false; }      // null proposal: the uniform is drawn, the state stays
         }
-        if (!accept) { accept = uacc < prob; cur += 1; used_uniform = true; }   // rand01 drawn only if prob <= 1 (:3113)
+        [[maybe_unused]] bool dropped = false;
+        if constexpr (PROP != 0) {
+            cur += (unsigned long long)sdec[4 * MSF * MSF + 3];                        // what the proposal drew
+            dropped = sdec[4 * MSF * MSF + 2] != 0.0;                                  // changed == NONE (:3063): no acceptance draw at all
+            if (dropped) accept = false;
+        }
+        if (!accept && !dropped) { accept = uacc < prob; cur += 1; used_uniform = true; }   // rand01 drawn only if prob <= 1 (:3113)
         if constexpr (CDW == 2) {
             if (sdec[4 * MSF * MSF + 2] != 0.0) accept = false;
         }
@@ -748,6 +872,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         prev_acc = accept;
         prev_used_uniform = used_uniform;
         cnd_nI = nI;                               // what the u/v registers were fetched for; the accepted site is patched in
+        if constexpr (PROP != 0) win_cur = fetch_cur_next;
         site += 1;
         it += 1;
         TICK(9);
@@ -782,34 +907,53 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         for (int l = 0; l < j; ++l) us->block_sites[l] = isite[l];
         us->pub.rng_consumed = cur;
         us->pub.error = err;
+        if constexpr (PROP >= 2) { us->nd_has = nd_has ? 1 : 0; us->nd_cached = nd_cached; }
         int sdone = 0;
         if (site >= N && err == 0) {
             sdone = 1;
             double accratio = (double)acc_count / (double)N;            // :3173
             if (CDW != 2) us->pub.lastAccRatio = accratio;              // the cdwl pass's ratio is discarded (:2476-2477)
             if (thermal && CDW != 2) {
-                // RunningAverage::addValue (RunningAverage.h:57-68), sampleSize = 100
+                // RunningAverage::addValue (RunningAverage.h:57-68), sampleSize = 100, of the average that belongs to the kind of move
+                // this pass made (accRatioLocal_box_RA / _rotate_RA / _scale_RA, :3322-3329)
                 const int sampleSize = 100;
-                double ra = us->pub.ra_runningAverage;
-                int added = us->pub.ra_samplesAdded, head = us->pub.ra_head;
+                const int what = adapt_what & 3;
+                double* rap = what == 0 ? &us->pub.ra_runningAverage : what == 1 ? &us->pub.rot_runningAverage : &us->pub.scl_runningAverage;
+                double* vals = what == 0 ? us->pub.ra_values : what == 1 ? us->pub.rot_values : us->pub.scl_values;
+                int32_t* addp = what == 0 ? &us->pub.ra_samplesAdded : what == 1 ? &us->pub.rot_samplesAdded : &us->pub.scl_samplesAdded;
+                int32_t* headp = what == 0 ? &us->pub.ra_head : what == 1 ? &us->pub.rot_head : &us->pub.scl_head;
+                double ra = *rap;
+                int added = *addp, head = *headp;
                 if (added < sampleSize) {
-                    us->pub.ra_values[added] = accratio;
+                    vals[added] = accratio;
                     ra += accratio / sampleSize;
                 } else {
-                    ra -= us->pub.ra_values[head] / sampleSize;
-                    us->pub.ra_values[head] = accratio;
+                    ra -= vals[head] / sampleSize;
+                    vals[head] = accratio;
                     head = (head + 1) % sampleSize;
                     ra += accratio / sampleSize;
                 }
                 added += 1;
-                us->pub.ra_runningAverage = ra;
-                us->pub.ra_samplesAdded = added;
-                us->pub.ra_head = head;
-                if (added % sampleSize == 0) {                          // :3331-3341
-                    double pd = us->pub.phiDelta;
-                    if (ra < us->pub.targetAccRatio) pd *= 0.95;
-                    else if (ra > us->pub.targetAccRatio) pd *= 1.05;
-                    us->pub.phiDelta = pd;
+                *rap = ra; *addp = added; *headp = head;
+                if (added % sampleSize == 0) {                          // :3331-3375
+                    const double tgt = us->pub.targetAccRatio;
+                    if (what == 0) {
+                        double pd = us->pub.phiDelta;
+                        if (ra < tgt) pd *= 0.95;
+                        else if (ra > tgt) pd *= 1.05;
+                        us->pub.phiDelta = pd;
+                    } else if (what == 1) {
+                        // angleDelta = minimal cos(theta): bisection between the current bounds, MinAngleDelta = -1, MaxAngleDelta = 1
+                        double ad = us->pub.angleDelta;
+                        if (ra < tgt && ad < 1.0) { us->pub.curminAngleDelta = ad; ad += (us->pub.curmaxAngleDelta - ad) / 2; }
+                        else if (ra > tgt && ad > -1.0) { us->pub.curmaxAngleDelta = ad; ad -= (ad - us->pub.curminAngleDelta) / 2; }
+                        us->pub.angleDelta = ad;
+                    } else if (adapt_what & 4) {                        // adaptScaleVariance; both branches test ra > target, as the reference does
+                        double sd = us->pub.scaleDelta;
+                        if (ra > tgt && sd < 1.0) { us->pub.curminScaleDelta = sd; sd += (us->pub.curmaxScaleDelta - sd) / 2; }
+                        else if (ra > tgt && sd > 0.0) { us->pub.curmaxScaleDelta = sd; sd -= (sd - us->pub.curminScaleDelta) / 2; }
+                        us->pub.scaleDelta = sd;
+                    }
                 }
             }
         }
@@ -826,30 +970,34 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
 
 void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, DevUpdateState* us,
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal, int cdw_pass,
-                          const cplx* Gwin, int winP) {
+                          const cplx* Gwin, int winP, int proposal, int adapt_what, int reset_nd) {
     const int WD = hm.MSF * hm.D;
     size_t lds = ((size_t)WD * (WD + 1) + 6 * (size_t)hm.MSF * WD) * sizeof(cplx) + (size_t)hm.opdim * hm.N * sizeof(double);
     const int cdw = hm.cdw_on ? (cdw_pass ? 2 : 1) : 0;
+    const int prop = (cdw == 2) ? 0 : proposal;                  // the cdwl pass has its own one-uniform proposal
     const void* f = nullptr;
-#define DECIDE_CASE(O, C) if (hm.opdim == O && cdw == C) f = (const void*)k_update_decide<O, C>;
-    DECIDE_CASE(1, 0) DECIDE_CASE(1, 1) DECIDE_CASE(1, 2) DECIDE_CASE(2, 0) DECIDE_CASE(2, 1) DECIDE_CASE(2, 2)
-    DECIDE_CASE(3, 0) DECIDE_CASE(3, 1) DECIDE_CASE(3, 2)
+    int slot = -1;
+#define DECIDE_CASE(O, C, P) if (hm.opdim == O && cdw == C && prop == P) { f = (const void*)k_update_decide<O, C, P>; slot = ((O - 1) * 3 + C) * 4 + P; }
+    DECIDE_CASE(1, 0, 0) DECIDE_CASE(1, 1, 0) DECIDE_CASE(1, 2, 0) DECIDE_CASE(2, 0, 0) DECIDE_CASE(2, 1, 0) DECIDE_CASE(2, 2, 0)
+    DECIDE_CASE(3, 0, 0) DECIDE_CASE(3, 1, 0) DECIDE_CASE(3, 2, 0)
+    DECIDE_CASE(3, 0, 1) DECIDE_CASE(3, 0, 2) DECIDE_CASE(3, 0, 3) DECIDE_CASE(3, 1, 1) DECIDE_CASE(3, 1, 2) DECIDE_CASE(3, 1, 3)
 #undef DECIDE_CASE
+    if (!f) return;            // dqmc_update_slice_ex rejects the combination before it gets here
     if (lds > 48 * 1024) {     // deep delay blocks: raise the dynamic LDS limit of the instantiation to what is needed
         // the attribute belongs to (function, device); several contexts / host threads may get here at once
         static std::mutex mu;
-        static size_t raised_tab[64][12] = {};
+        static size_t raised_tab[64][36] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> lk(mu);
-        size_t& raised = raised_tab[dev & 63][(hm.opdim - 1) * 3 + cdw];
+        size_t& raised = raised_tab[dev & 63][slot];
         if (lds > raised) {
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised = lds;
             else (void)hipGetLastError();      // the launch below then reports the problem
         }
     }
     void* args[] = {(void*)&hm, (void*)&us, (void*)&uniforms, (void*)&G, (void*)&W, (void*)&k, (void*)&first, (void*)&thermal, (void*)&lc.cs,
-                    (void*)&Gwin, (void*)&winP};
+                    (void*)&Gwin, (void*)&winP, (void*)&adapt_what, (void*)&reset_nd};
     (void)hipLaunchKernel(f, dim3(1, 1, lc.nb), dim3(256), args, lds, lc.st);
 }
 

@@ -62,12 +62,20 @@ class SDWParams:
     device: int = 0
     stabilisation: str = "svd"   # "svd": UdV = SVD like the reference; "qr": pre-pivoted Householder UDT
     checkerboard: bool = True    # False = CB_NONE: dense B_k = e^{-dtau V_k} e^{-dtau K} (reference option checkerboard=false)
+    spinProposalMethod: str = "box"      # "box", "rotate_then_scale", "rotate_and_scale" (the latter two: opdim = 3 only)
+    adaptScaleVariance: bool = False
+    repeatUpdateInSlice: int = 1
     # result-neutral execution choices (dqmc_tuning, include/dqmc_hip.h); 0 = automatic
     pipeline: int = 0            # 1 / -1: pipelined delayed updates on / off
     qrVariant: int = 0           # 1: Householder panels, 2: block Gram-Schmidt + Cholesky-QR2
     greenVariant: int = 0        # 1: QR instead of LU inside greenFromUdV
     maxJacobiSweeps: int = 0     # SVD mode: sweep budget of the Jacobi SVD (0 = 80)
     proposalBudget: int = 0      # proposals per delayed-update block (-1: no limit)
+
+
+SPIN_PROPOSAL = {"box": 0, "rotate_then_scale": 1, "rotate_and_scale": 2}
+PROPOSE = {"box": 0, "rotate": 1, "scale": 2, "rotate_and_scale": 3}
+ADAPT = {"box": 0, "rotate": 1, "scale": 2}
 
 
 def _tuning(pipeline=0, qrVariant=0, greenVariant=0, maxJacobiSweeps=0, proposalBudget=0):
@@ -86,12 +94,12 @@ class KernelContext:
     def __init__(self, opdim, L, m, s, dtau, delaySteps=16, bc="pbc", weakZflux=False, r=-1.0, c=3.0, u=1.0,
                  lambda_=1.0, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, mux=-0.5, muy=-0.5,
                  accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd", checkerboard=True, nchains=1, cdwU=0.0,
-                 pipeline=0, qrVariant=0, greenVariant=0, maxJacobiSweeps=0, proposalBudget=0):
+                 pipeline=0, qrVariant=0, greenVariant=0, maxJacobiSweeps=0, proposalBudget=0, rngWindowPerSite=0):
         self.lib = load()
         p = _lib.dqmc_params(opdim=opdim, L=L, m=m, s=s, delaySteps=delaySteps, bc=BC[bc],
                              weakZflux=int(weakZflux), phi2bosons=int(phi2bosons), device=device,
                              stabilisation=STABILISATION[stabilisation], cb_none=int(not checkerboard), dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
-                             tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio, cdwU=cdwU,
+                             tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio, cdwU=cdwU, rng_window_per_site=int(rngWindowPerSite),
                              tuning=_tuning(pipeline, qrVariant, greenVariant, maxJacobiSweeps, proposalBudget))
         h = C.c_void_p()
         check(self.lib.dqmc_create_batch(C.byref(p), nchains, C.byref(h)))
@@ -202,8 +210,9 @@ class KernelContext:
         u = np.ascontiguousarray(u, dtype=np.float64)
         check(self.lib.dqmc_push_uniforms_host(self.h, u.ctypes.data_as(_lib._DP), u.size))
 
-    def updateInSlice(self, k, thermalization=False):
-        check(self.lib.dqmc_update_slice(self.h, k, int(thermalization)))
+    def updateInSlice(self, k, thermalization=False, proposal="box", adapt="box", adaptScaleVariance=False, repeat=1):
+        """updateInSlice / updateInSliceThermalization; proposal: box | rotate | scale | rotate_and_scale (the latter three: O(3))"""
+        check(self.lib.dqmc_update_slice_ex(self.h, k, int(thermalization), PROPOSE[proposal], ADAPT[adapt], int(adaptScaleVariance), int(repeat)))
 
     def update_state(self):
         st = _lib.dqmc_update_state()
@@ -301,7 +310,9 @@ class KernelContext:
                    svd_sweeps_max=int(pr.svd_sweeps_max), qr_calls=int(pr.qr_calls), gemm_flops=pr.gemm_flops,
                    decomp_round_ms=pr.decomp_round_ms, decomp_rounds=int(pr.decomp_rounds),
                    blocks_nonempty=int(pr.blocks_nonempty), chains=int(pr.chains),
-                   updates_accepted=int(pr.updates_accepted), lu_calls=int(pr.lu_calls))
+                   updates_accepted=int(pr.updates_accepted), lu_calls=int(pr.lu_calls),
+                   sub={"lu_update": [pr.sub_ms[0], int(pr.sub_launches[0]), pr.sub_flops[0], pr.sub_bytes[0]],
+                        "fact_gemm": [pr.sub_ms[1], int(pr.sub_launches[1]), pr.sub_flops[1], pr.sub_bytes[1]]})
         return out
 
 
@@ -331,6 +342,8 @@ def _host_params(pars: SDWParams):
         stabilisation=STABILISATION[pars.stabilisation], cb_none=int(not pars.checkerboard),
         wolffClusterUpdate=int(pars.wolffClusterUpdate), wolffClusterShiftUpdate=int(pars.wolffClusterShiftUpdate),
         repeatWolffPerSweep=int(pars.repeatWolffPerSweep), fermionMeasurements=int(pars.fermionMeasurements),
+        spinProposalMethod=SPIN_PROPOSAL[pars.spinProposalMethod], adaptScaleVariance=int(pars.adaptScaleVariance),
+        repeatUpdateInSlice=int(pars.repeatUpdateInSlice),
         tuning=_tuning(pars.pipeline, pars.qrVariant, pars.greenVariant, pars.maxJacobiSweeps, pars.proposalBudget))
 
 

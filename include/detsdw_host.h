@@ -25,8 +25,8 @@ typedef struct detsdw_replica detsdw_replica;
 
 /* ModelParamsDetSDW (src/detsdwparams.h:24-120) + rngSeed/simindex of DetQMCParams
  * (src/detqmcparams.h) as far as the sweep path uses them.  Unsupported reference options
- * (turnoffFermions, rotate/scale proposals) are rejected by
- * detsdw_create with DQMC_EINVAL and a message naming the option. */
+ * (turnoffFermions, overRelaxation, phiFixed) are rejected by detsdw_create with DQMC_EINVAL and a
+ * message naming the option. */
 typedef struct detsdw_params {
     int32_t opdim;
     int32_t L;
@@ -56,6 +56,11 @@ typedef struct detsdw_params {
     int32_t repeatWolffPerSweep;      /* cluster flips per attempt, 0 is read as 1 */
     int32_t fermionMeasurements;      /* 1: sweep(takeMeasurements) also takes the G-dependent observables (the reference's
                                          default, i.e. turnoffFermionMeasurements = false); 0: bosonic observables only */
+    int32_t spinProposalMethod;       /* 0 box (default), 1 rotate_then_scale, 2 rotate_and_scale -- the latter two for opdim == 3 only
+                                         (src/detsdwparams.h:40-42, src/detsdwopdim.cpp:2447-2470) */
+    int32_t adaptScaleVariance;       /* adapt scaleDelta during thermalization (src/detsdwparams.h:43) */
+    int32_t repeatUpdateInSlice;      /* passes of local updates per time slice and sweep, 0 is read as 1 (src/detsdwparams.h:90) */
+    int32_t reserved_model;
     dqmc_tuning tuning;               /* result-neutral execution choices handed to every kernel context (dqmc_hip.h); all zero =
                                          automatic.  With pipeline = 0 the host layer switches the pipelined update on only for
                                          handles of at most two kernel contexts (more contexts overlap each other instead) */
@@ -74,6 +79,7 @@ typedef struct detsdw_info {
     double beta, dtau;
     double phiDelta, lastAccRatioLocal_phi;
     double r;                    /* exchange parameter */
+    double angleDelta, scaleDelta;   /* rotate / scale proposals (AdjustmentData, src/detsdwopdim.h:510-512) */
     uint64_t rngDrawn;           /* uniforms consumed from the stream so far */
 } detsdw_info;
 

@@ -94,6 +94,11 @@ typedef struct dqmc_params {
     double accRatio;      /* target acceptance for the box step adaptation */
     double cdwU;          /* != 0: the discrete field l_i(tau) in {+-1, +-2} next to phi (detsdwparams.h:61; evMatrix,
                              detsdwopdim.cpp:3187-3229); dqmc_update_slice then runs the cdwl pass behind the phi pass (:2474-2485) */
+    int32_t rng_window_per_site;   /* capacity of the window of pre-drawn uniforms, per site and time slice of a sweep; 0 = what box proposals
+                                      with repeatUpdateInSlice = 1 can consume at most (opdim + 1, + 2 with cdwU).  Callers that use
+                                      dqmc_update_slice_ex with more passes or the rotate / scale proposals (whose Gaussian draws consume
+                                      a variable number) size it: repeat x (opdim + 1) resp. repeat x 8 (+ 2 with cdwU) */
+    int32_t reserved_model;
     dqmc_tuning tuning;   /* all zero = automatic */
 } dqmc_params;
 
@@ -111,6 +116,16 @@ typedef struct dqmc_update_state {
     uint64_t rng_avail;      /* size of the pushed window */
     int32_t error;           /* DQMC_ERNG if the window ran dry */
     int32_t reserved;
+    /* rotate / scale proposals of the O(3) model (spinProposalMethod != box): AdjustmentData::angleDelta (the minimal cos(theta) of a
+     * rotation), scaleDelta (width of the Gaussian |phi|^3 update), the bisection bounds of their adaptation and the running
+     * averages accRatioLocal_rotate_RA / _scale_RA (src/detsdwopdim.h:489-530, src/detsdwopdim.cpp:3299-3375) */
+    double angleDelta, scaleDelta;
+    double curminAngleDelta, curmaxAngleDelta, curminScaleDelta, curmaxScaleDelta;
+    double rot_runningAverage;
+    double rot_values[100];
+    double scl_runningAverage;
+    double scl_values[100];
+    int32_t rot_samplesAdded, rot_head, scl_samplesAdded, scl_head;
 } dqmc_update_state;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -182,6 +197,16 @@ int dqmc_push_uniforms_all_host(dqmc_ctx* ctx, const double* u, size_t n);
  * deltaSPhi :4186-4239, get_delta_forsite :3179-3289); thermalization != 0 adds the step-size
  * adaptation of updateInSliceThermalization (:3294-3375) */
 int dqmc_update_slice(dqmc_ctx* ctx, int k, int thermalization);
+/* The same with the other proposal kinds and repeatUpdateInSlice (src/detsdwopdim.cpp:2438-2470): `proposal` = DQMC_PROPOSE_BOX
+ * (proposeNewPhiBox), _ROTATE (proposeRotatedPhi, :3945-4002), _SCALE (proposeScaledPhi, :4016-4077), _ROTATE_AND_SCALE
+ * (proposeRotatedScaledPhi, :4092-4170) -- the last three for opdim == 3 only, as in the reference; `repeat` passes over the slice
+ * (each a full updateInSlice_delayed; lastAccRatio is the last pass's); with thermalization != 0 the running average and step
+ * parameter named by `adapt` are updated once, from the last pass (updateInSliceThermalization, :3294-3375): DQMC_ADAPT_BOX (phiDelta),
+ * _ROTATE (angleDelta), _SCALE (scaleDelta, only moved with adapt_scale_variance != 0).  Which kind a sweep uses (rotate_then_scale
+ * alternates with performedSweeps, rotate_and_scale alternates the ADAPTED quantity every 100 sweeps) is the host layer's business. */
+enum { DQMC_PROPOSE_BOX = 0, DQMC_PROPOSE_ROTATE = 1, DQMC_PROPOSE_SCALE = 2, DQMC_PROPOSE_ROTATE_AND_SCALE = 3 };
+enum { DQMC_ADAPT_BOX = 0, DQMC_ADAPT_ROTATE = 1, DQMC_ADAPT_SCALE = 2 };
+int dqmc_update_slice_ex(dqmc_ctx* ctx, int k, int thermalization, int proposal, int adapt, int adapt_scale_variance, int repeat);
 /* Which schedule dqmc_update_slice runs for this context (latched at dqmc_create from dqmc_tuning::pipeline and the shape of the
  * context) and how many delayed-update blocks have gone through each since dqmc_create. */
 typedef struct dqmc_schedule_info {
@@ -254,6 +279,14 @@ typedef struct dqmc_profile {
     uint64_t updates_accepted;  /* accepted local updates, summed over all chains, since dqmc_profile_enable (flush flops = 8 n_g^2 MSF each) */
     uint64_t lu_calls;          /* QR mode: Green's functions whose inner inverse came from the LU factorisation (n_g <= 512); qr_calls then
                                    counts the chain factorisations (UDT) only */
+    /* GPU-filling launches INSIDE the decomposition family, timed on their own (their time is also part of ms[DQMC_FAM_DECOMP]):
+       [0] trailing updates of the LU factorisation (K = 32, on the flush kernel), [1] products inside factorisations and triangular
+       solves (k_zgemm: the levels of the recursive solves, the block Gram-Schmidt QR); flops counted as 8 M N K, bytes as the
+       operands read once and the result written (read-modify-written) once */
+    double sub_ms[4];
+    uint64_t sub_launches[4];
+    double sub_flops[4];
+    double sub_bytes[4];
 } dqmc_profile;
 int dqmc_profile_enable(dqmc_ctx* ctx, int on);
 int dqmc_profile_read(dqmc_ctx* ctx, dqmc_profile* out);

@@ -58,6 +58,9 @@ class SDWParams:
     phi2bosons: bool = False
     turnoffFermionMeasurements: bool = True   # False: measure() also takes the G-dependent observables
     checkerboard: bool = True     # False = CB_NONE: dense B = e^{-dtau V} e^{-dtau K} (detsdwopdim.h:1305-1375)
+    spinProposalMethod: str = "box"           # "box", "rotate_then_scale", "rotate_and_scale" (the latter two: opdim 3 only; detsdwparams.h:40)
+    adaptScaleVariance: bool = False          # detsdwparams.h:43
+    repeatUpdateInSlice: int = 1              # detsdwparams.h:90
     rngSeed: int = 1020304050
     simindex: int = 0
     # derived
@@ -124,6 +127,56 @@ class RunningAverage:
         return self.runningAverage
 
 
+def _libm_sincos():
+    """The reference, built with g++ -O2, evaluates cos(phi) and sin(phi) of proposeRandomRotatedVector through ONE glibc sincos()
+    call, whose results differ from sin() / cos() in the last bit for ~0.1 % of the arguments (measured in this image, glibc 2.35):
+    the oracle calls the same function so that rotated fields stay bit-identical to the reference fixtures."""
+    import ctypes
+    try:
+        libm = ctypes.CDLL("libm.so.6")
+        libm.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        libm.sincos.restype = None
+    except (OSError, AttributeError):
+        return lambda x: (math.sin(x), math.cos(x))
+    sv, cv = ctypes.c_double(), ctypes.c_double()
+
+    def f(x):
+        libm.sincos(x, ctypes.byref(sv), ctypes.byref(cv))
+        return sv.value, cv.value
+    return f
+
+
+_sincos = _libm_sincos()
+
+
+class NormalDistribution:
+    """normaldistribution.h:25-80: polar Box-Muller on the replica's RngWrapper, the two values of a pair on a stack (the
+    second one generated is handed out first); reset() at the top of every updateInSlice (detsdwopdim.cpp:2433-2435)."""
+
+    def __init__(self, rng):
+        self.rng = rng
+        self.stack = []
+
+    def reset(self):
+        self.stack = []
+
+    def get(self, sigma, mean):
+        if not self.stack:
+            while True:
+                u1 = self.rng.rand01()
+                u2 = self.rng.rand01()
+                v1 = 2.0 * u1 - 1.0
+                v2 = 2.0 * u2 - 1.0
+                rsq = v1 * v1 + v2 * v2
+                if not (rsq >= 1.0 or rsq == 0.0):
+                    break
+            fac = math.sqrt(-2.0 * math.log(rsq) / rsq)
+            self.stack.append(v1 * fac)
+            self.stack.append(v2 * fac)
+        var = self.stack.pop()
+        return mean + sigma * var
+
+
 class UdV:
     """udv.h:40-65.  M = U diag(d) V_t^dagger."""
 
@@ -160,6 +213,10 @@ def replica_exchange_probability(par1, action1, par2, action2):
 class DetSDWOracle:
     # AdjustmentData constants, detsdwopdim.h:489-498
     InitialPhiDelta = 0.5
+    InitialAngleDelta = 0.0
+    InitialScaleDelta = 0.1
+    MinScaleDelta, MaxScaleDelta = 0.0, 1.0
+    MinAngleDelta, MaxAngleDelta = -1.0, 1.0
     AccRatioAdjustmentSamples = 100
     phiDeltaGrowFactor = 1.05
     phiDeltaShrinkFactor = 0.95
@@ -187,6 +244,16 @@ class DetSDWOracle:
         self.targetAccRatioLocal_phi = p.accRatio
         self.lastAccRatioLocal_phi = 0.0
         self.accRatioLocal_box_RA = RunningAverage(self.AccRatioAdjustmentSamples)
+        # rotate / scale proposals (detsdwopdim.h:489-530)
+        self.angleDelta = self.InitialAngleDelta
+        self.scaleDelta = self.InitialScaleDelta
+        self.accRatioLocal_rotate_RA = RunningAverage(self.AccRatioAdjustmentSamples)
+        self.accRatioLocal_scale_RA = RunningAverage(self.AccRatioAdjustmentSamples)
+        self.curminAngleDelta, self.curmaxAngleDelta = self.MinAngleDelta, self.MaxAngleDelta
+        self.curminScaleDelta, self.curmaxScaleDelta = self.MinScaleDelta, self.MaxScaleDelta
+        self.normal_distribution = NormalDistribution(self.rng)
+        if p.spinProposalMethod != "box" and p.opdim != 3:
+            raise ValueError("rotate / scale proposals are only supported for the O(3) model (detsdwopdim.cpp:3934-3939)")
         self.acceptedGlobalShifts = 0
         self.attemptedGlobalShifts = 0
         self.acceptedWolffClusterUpdates = 0
@@ -660,6 +727,57 @@ class DetSDWOracle:
             newphi[d] += self.rng.randRange(-self.phiDelta, +self.phiDelta)
         return newphi
 
+    def _rotated(self, vec, r_new_over_r=None, new_r=None):
+        """the rotation shared by proposeRandomRotatedVector<3> and proposeRandomRotatedScaledVector<3> (detsdwopdim.cpp:3945-3992,
+        4112-4146): new direction in a cone around the old one, cos(theta) in [angleDelta, 1]; length r (rotate) or new_r"""
+        x, y, z = float(vec[0]), float(vec[1]), float(vec[2])
+        # pow(x, 2.0): g++ -O2 expands it to x * x (exact, allowed without -ffast-math), while libm's pow is only guaranteed to ~0.52 ulp
+        # -- the two differ in the last bit once in ~1e4 arguments, which the 12-sweep fixture is long enough to see
+        x2, y2, z2 = x * x, y * y, z * z
+        r2 = x2 + y2 + z2
+        r = math.sqrt(r2)
+        cosTheta = self.rng.rand01() * (1.0 - self.angleDelta) + self.angleDelta
+        phi = self.rng.rand01() * 2.0 * math.pi
+        sinTheta = math.sqrt(1.0 - cosTheta * cosTheta)
+        sinPhi, cosPhi = _sincos(phi)
+        x2n, y2n = x2 / r2, y2 / r2
+        xn, yn, zn = x / r, y / r, z / r
+        newx = (sinTheta / (x2n + y2n)) * ((x2n * zn + y2n) * cosPhi + (zn - 1) * xn * yn * sinPhi) + xn * cosTheta
+        newy = (sinTheta / (x2n + y2n)) * ((zn - 1) * xn * yn * cosPhi + (x2n + y2n * zn) * sinPhi) + yn * cosTheta
+        newz = -sinTheta * (xn * cosPhi + yn * sinPhi) + zn * cosTheta
+        length = r if new_r is None else new_r
+        return np.array([newx * length, newy * length, newz * length])
+
+    def proposeRotatedPhi(self, site, k):
+        """detsdwopdim.cpp:3945-4002: two uniforms; always a valid proposal"""
+        return self._rotated(self.phi[k, site]), True
+
+    def proposeScaledPhi(self, site, k):
+        """detsdwopdim.cpp:4016-4077: new |phi|^3 Gaussian around the old one (width scaleDelta); not positive -> changed = NONE"""
+        x, y, z = (float(v) for v in self.phi[k, site])
+        x2, y2, z2 = x * x, y * y, z * z
+        r3 = math.pow(x2 + y2 + z2, 3.0 / 2.0)
+        new_r3 = self.normal_distribution.get(self.scaleDelta, r3)
+        if new_r3 <= 0:
+            return self.phi[k, site].copy(), False
+        scale = math.pow(new_r3 / r3, 1.0 / 3.0)
+        return np.array([x * scale, y * scale, z * scale]), True
+
+    def proposeRotatedScaledPhi(self, site, k):
+        """detsdwopdim.cpp:4092-4160: Gaussian draw for |phi|^3 first; only if it is positive the two uniforms of the rotation"""
+        x, y, z = (float(v) for v in self.phi[k, site])
+        x2, y2, z2 = x * x, y * y, z * z
+        r = math.sqrt(x2 + y2 + z2)
+        r3 = math.pow(r, 3)
+        new_r3 = self.normal_distribution.get(self.scaleDelta, r3)
+        if new_r3 <= 0:
+            return self.phi[k, site].copy(), False
+        # (the rotation draws its uniforms before new_r = new_r3^(1/3) is formed, as in the reference)
+        vec = self.phi[k, site]
+        cos_draws = self._rotated(vec, new_r=1.0)               # unit vector
+        new_r = math.pow(new_r3, 1.0 / 3.0)
+        return cos_draws * new_r, True
+
     def proposeNewCDWl(self, site, k):
         """detsdwopdim.cpp:4173-4182: one uniform, the field phi stays."""
         return self.cdwl_from_uniform(self.rng.rand01())
@@ -679,6 +797,14 @@ class DetSDWOracle:
             while j < delayStepsNow and site < N:
                 if what == "phi":
                     newphi = self.proposeNewPhiBox(site, k)
+                    new_cdwl = int(self.cdwl[k, site])
+                    probSPhi = math.exp(-self.deltaSPhi(site, k, newphi))
+                elif what in ("rotate", "scale", "rotate_and_scale"):
+                    newphi, valid = (self.proposeRotatedPhi if what == "rotate" else self.proposeScaledPhi if what == "scale"
+                                     else self.proposeRotatedScaledPhi)(site, k)
+                    if not valid:                       # changed == NONE (:3063): rejected at once, no acceptance draw
+                        site += 1
+                        continue
                     new_cdwl = int(self.cdwl[k, site])
                     probSPhi = math.exp(-self.deltaSPhi(site, k, newphi))
                 else:
@@ -727,22 +853,57 @@ class DetSDWOracle:
         return accratio / N
 
     def updateInSlice(self, k):
-        """detsdwopdim.cpp:2428-2489 (box proposals, delayed method, repeatUpdateInSlice=1)."""
-        self.lastAccRatioLocal_phi = self.updateInSlice_delayed(k)
+        """detsdwopdim.cpp:2428-2489 (delayed method)."""
+        self.normal_distribution.reset()
+        for _ in range(self.pars.repeatUpdateInSlice):
+            spm = self.pars.spinProposalMethod
+            if spm == "box":
+                what = "phi"
+            elif spm == "rotate_then_scale":            # each sweep alternates between rotating and scaling (:2447-2462)
+                what = "rotate" if self.performedSweeps % 2 == 0 else "scale"
+            else:
+                what = "rotate_and_scale"
+            self.lastAccRatioLocal_phi = self.updateInSlice_delayed(k, what)
         if self.pars.cdwU:                              # :2474-2485: second pass over the slice, its acceptance ratio is discarded
             self.updateInSlice_delayed(k, "cdwl")
 
     def updateInSliceThermalization(self, k):
-        """detsdwopdim.cpp:3294-3375 (ADAPT_BOX branch)."""
+        """detsdwopdim.cpp:3294-3375."""
         self.updateInSlice(k)
-        ra = self.accRatioLocal_box_RA
+        spm = self.pars.spinProposalMethod
+        if spm == "box":
+            what, ra = "box", self.accRatioLocal_box_RA
+        elif spm == "rotate_then_scale":                # must match the order of moves in updateInSlice (:3303-3311)
+            what = "rotate" if self.performedSweeps % 2 == 0 else "scale"
+        else:                                           # alternate every AccRatioAdjustmentSamples sweeps (:3312-3320)
+            what = "rotate" if self.performedSweeps % (2 * self.AccRatioAdjustmentSamples) < self.AccRatioAdjustmentSamples else "scale"
+        if what == "rotate":
+            ra = self.accRatioLocal_rotate_RA
+        elif what == "scale":
+            ra = self.accRatioLocal_scale_RA
         ra.addValue(self.lastAccRatioLocal_phi)
         if ra.samplesAdded % self.AccRatioAdjustmentSamples == 0:
             avg = ra.get()
-            if avg < self.targetAccRatioLocal_phi:
-                self.phiDelta *= self.phiDeltaShrinkFactor
-            elif avg > self.targetAccRatioLocal_phi:
-                self.phiDelta *= self.phiDeltaGrowFactor
+            tgt = self.targetAccRatioLocal_phi
+            if what == "box":
+                if avg < tgt:
+                    self.phiDelta *= self.phiDeltaShrinkFactor
+                elif avg > tgt:
+                    self.phiDelta *= self.phiDeltaGrowFactor
+            elif what == "rotate":                      # :3344-3353 -- angleDelta = minimal cos(theta); bisection between cur min / max
+                if avg < tgt and self.angleDelta < self.MaxAngleDelta:
+                    self.curminAngleDelta = self.angleDelta
+                    self.angleDelta += (self.curmaxAngleDelta - self.angleDelta) / 2
+                elif avg > tgt and self.angleDelta > self.MinAngleDelta:
+                    self.curmaxAngleDelta = self.angleDelta
+                    self.angleDelta -= (self.angleDelta - self.curminAngleDelta) / 2
+            elif self.pars.adaptScaleVariance:          # :3356-3372 (both branches test avg > target, as in the reference)
+                if avg > tgt and self.scaleDelta < self.MaxScaleDelta:
+                    self.curminScaleDelta = self.scaleDelta
+                    self.scaleDelta += (self.curmaxScaleDelta - self.scaleDelta) / 2
+                elif avg > tgt and self.scaleDelta > self.MinScaleDelta:
+                    self.curmaxScaleDelta = self.scaleDelta
+                    self.scaleDelta -= (self.scaleDelta - self.curminScaleDelta) / 2
 
     # ------------------------------------------------------------------ sweeps (a9)
     def sweepDown(self, upd):

@@ -87,6 +87,21 @@ CASES = {
     "o2_L8_fmeas_apbc_flux": dict(args=dict(opdim=2, L=8, beta=2, s=10, delaySteps=16, sweeps=1, measureSweeps=1, fermionMeas=1,
                                             sliceTrace=0, bc="apbc-y", weakZflux=1),
                                   drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi", "init_udv")),
+    # round 4: rotate / scale proposals of the O(3) model and their adaptation (proposeRotatedPhi / proposeScaledPhi /
+    # proposeRotatedScaledPhi, detsdwopdim.cpp:3934-4170; ADAPT_ROTATE / ADAPT_SCALE :3299-3375; Box-Muller stack normaldistribution.h)
+    # and repeatUpdateInSlice > 1 (:2438).  12 sweeps: the rotate and the scale running averages each reach 100 samples (m = 20 slices
+    # per sweep, alternating sweeps), so angleDelta and scaleDelta move.
+    "o3_L4_rotscale": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=12, spinProposalMethod="rotate_then_scale",
+                                     adaptScaleVariance=1, sliceTrace=0),
+                           drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi", "init_udv")),
+    "o3_L4_rotandscale": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=6, spinProposalMethod="rotate_and_scale",
+                                        adaptScaleVariance=1, sliceTrace=0),
+                              drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi", "init_udv")),
+    "o3_L6_rotscale_rep2": dict(args=dict(opdim=3, L=6, beta=1.5, s=10, delaySteps=12, sweeps=2, spinProposalMethod="rotate_then_scale",
+                                          repeatUpdateInSlice=2, sliceTrace=0),
+                                drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi", "init_udv"), subsample=4),
+    "o2_L4_rep3": dict(args=dict(opdim=2, L=4, beta=2, s=10, delaySteps=6, sweeps=2, repeatUpdateInSlice=3, sliceTrace=0),
+                       drop=("bchain_", "bdense", "bmult_", "init_coshTermPhi", "init_sinhTermPhi", "init_udv")),
     "o1_L4": dict(args=dict(opdim=1, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
     "o3_L4": dict(args=dict(opdim=3, L=4, beta=2, s=10, delaySteps=6, sweeps=3)),
     # BASELINE config 2 (bring-up size): full G only at a few points

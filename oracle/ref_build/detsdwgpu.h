@@ -311,11 +311,9 @@ private:
         if (probe.u[1] == 0) throw_GeneralError("DetSDWGpu: processIndex must be simindex + 1 >= 1");
 
         if (pars.turnoffFermions) throw_ParameterWrong_message("DetSDWGpu: turnoffFermions is not supported");
-        if (pars.spinProposalMethod != ModelParamsDetSDW::BOX) throw_ParameterWrong_message("DetSDWGpu: only spinProposalMethod=box is supported");
         if (pars.overRelaxation) throw_ParameterWrong_message("DetSDWGpu: overRelaxation is not supported");
         if (pars.phiFixed) throw_ParameterWrong_message("DetSDWGpu: phiFixed is not supported");
         if (pars.dumpGreensFunction) throw_ParameterWrong_message("DetSDWGpu: dumpGreensFunction is not supported");
-        if (pars.repeatUpdateInSlice != 1) throw_ParameterWrong_message("DetSDWGpu: repeatUpdateInSlice must be 1");
 
         detsdw_params p;
         std::memset(&p, 0, sizeof(p));
@@ -340,6 +338,9 @@ private:
         p.wolffClusterUpdate = pars.wolffClusterUpdate; p.wolffClusterShiftUpdate = pars.wolffClusterShiftUpdate;
         p.repeatWolffPerSweep = (int32_t)pars.repeatWolffPerSweep;
         p.fermionMeasurements = pars.turnoffFermionMeasurements ? 0 : 1;
+        p.spinProposalMethod = pars.spinProposalMethod == ModelParamsDetSDW::BOX ? 0 : pars.spinProposalMethod == ModelParamsDetSDW::ROTATE_THEN_SCALE ? 1 : 2;
+        p.adaptScaleVariance = pars.adaptScaleVariance ? 1 : 0;
+        p.repeatUpdateInSlice = (int32_t)pars.repeatUpdateInSlice;
         if (detsdw_create(&p, &h_) != DQMC_OK) throw_GeneralError(std::string("detsdw_create: ") + detsdw_last_error());
         // the constructor consumed the draws of setupRandomField: bring the driver's wrapper to the same position
         shadow_ = rng;

@@ -150,7 +150,8 @@ static ModelParamsDetSDW make_params(const std::map<std::string, std::string>& k
     if (kv.count("muy")) { p.muy = get<double>(kv, "muy", 0.0); p.specified.insert("muy"); }
     p.checkerboard = get<int>(kv, "checkerboard", 1) != 0; p.specified.insert("checkerboard");
     p.updateMethod_string = gets(kv, "updateMethod", "delayed"); p.specified.insert("updateMethod");
-    p.spinProposalMethod_string = "box"; p.specified.insert("spinProposalMethod");
+    p.spinProposalMethod_string = gets(kv, "spinProposalMethod", "box"); p.specified.insert("spinProposalMethod");
+    p.adaptScaleVariance = get<int>(kv, "adaptScaleVariance", 0) != 0; p.specified.insert("adaptScaleVariance");
     p.bc_string = gets(kv, "bc", "pbc"); p.specified.insert("bc");
     p.weakZflux = get<int>(kv, "weakZflux", 0) != 0; p.specified.insert("weakZflux");
     p.globalShift = get<int>(kv, "globalShift", 0) != 0; p.specified.insert("globalShift");
@@ -179,6 +180,10 @@ static void dump_state(SDW& rep, const std::string& tag) {
     dump(tag + "_g_inv_sv", rep.g_inv_sv);
     dump_scalar(tag + "_phiDelta", rep.ad.phiDelta);
     dump_scalar(tag + "_lastAccRatio", rep.ad.lastAccRatioLocal_phi);
+    if (rep.pars.spinProposalMethod_string != "box") {        // rotate / scale proposals (detsdwopdim.cpp:3934-4170, adaptation :3299-3375)
+        dump_scalar(tag + "_angleDelta", rep.ad.angleDelta);
+        dump_scalar(tag + "_scaleDelta", rep.ad.scaleDelta);
+    }
     dump_scalar(tag + "_accGlobalShifts", rep.us.acceptedGlobalShifts);
     dump_scalar(tag + "_attGlobalShifts", rep.us.attemptedGlobalShifts);
     dump_scalar(tag + "_accWolff", rep.us.acceptedWolffClusterUpdates);

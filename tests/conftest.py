@@ -44,6 +44,9 @@ def oracle_params(args):
     kw["wolffClusterShiftUpdate"] = bool(int(a.get("wolffClusterShiftUpdate", 0)))
     kw["repeatWolffPerSweep"] = int(a.get("repeatWolffPerSweep", 1))
     kw["turnoffFermionMeasurements"] = not bool(int(a.get("fermionMeas", 0)))
+    kw["spinProposalMethod"] = a.get("spinProposalMethod", "box")
+    kw["adaptScaleVariance"] = bool(int(a.get("adaptScaleVariance", 0)))
+    kw["repeatUpdateInSlice"] = int(a.get("repeatUpdateInSlice", 1))
     kw["rngSeed"] = int(a.get("rngSeed", 1020304050))
     kw["simindex"] = int(a.get("simindex", 0))
     return SDWParams(**kw)

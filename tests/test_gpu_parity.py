@@ -42,7 +42,8 @@ def _sdw_params(a, **over):
               weakZflux=op.weakZflux, globalShift=op.globalShift, globalUpdateInterval=op.globalUpdateInterval,
               wolffClusterUpdate=op.wolffClusterUpdate, wolffClusterShiftUpdate=op.wolffClusterShiftUpdate,
               repeatWolffPerSweep=op.repeatWolffPerSweep, fermionMeasurements=not op.turnoffFermionMeasurements,
-              rngSeed=op.rngSeed, simindex=op.simindex, checkerboard=op.checkerboard, cdwU=op.cdwU)
+              rngSeed=op.rngSeed, simindex=op.simindex, checkerboard=op.checkerboard, cdwU=op.cdwU,
+              spinProposalMethod=op.spinProposalMethod, adaptScaleVariance=op.adaptScaleVariance, repeatUpdateInSlice=op.repeatUpdateInSlice)
     kw.update(over)
     return SDWParams(**kw)
 
@@ -1553,6 +1554,63 @@ def test_cholesky_qr_failure_falls_back_to_householder_panels():
         assert relerr((U2 * d2[None, :]) @ Vt2.conj().T, M2) < 1e-12 and relerr(U2.conj().T @ U2, np.eye(n)) < 1e-12
         ctx.close()
     assert relerr(out[2], out[1]) < 1e-12
+
+
+@pytest.mark.parametrize("stab", ["svd", "qr"])
+@pytest.mark.parametrize("name", ["o3_L4_rotscale", "o3_L4_rotandscale", "o3_L6_rotscale_rep2", "o2_L4_rep3"])
+def test_rotate_scale_proposals_and_repeated_updates_vs_reference(name, stab):
+    """spinProposalMethod = rotate_then_scale / rotate_and_scale (O(3)) with the ADAPT_ROTATE / ADAPT_SCALE bisections, and
+    repeatUpdateInSlice > 1, against the reference (/root/reference/src/detsdwopdim.cpp:2438-2470, 3934-4170, 3299-3375; the Box-Muller
+    stack of src/normaldistribution.h).  Every accept / reject decision, the number of uniforms consumed (a Gaussian draw takes a
+    variable number), angleDelta and scaleDelta after 12 sweeps are the reference's exactly.  The proposed vectors go through the
+    device library's sincos / pow / log, which agree with glibc's to an ulp or two: rotated and scaled field values agree to 1e-13
+    relative, not bit for bit (box proposals -- o2_L4_rep3 -- stay bit-identical)."""
+    from detqmc_amd import DetSDW
+    g = load_golden(name)
+    rep = DetSDW(_sdw_params(g["params"], stabilisation=stab))
+    assert np.array_equal(rep.phi[1:], _golden_phi(g, "init_phi")[1:])
+    exact = g["params"].get("spinProposalMethod", "box") == "box"
+    i = 1
+    moved = set()
+    while f"sweep{i}_phi" in g:
+        rep.sweepThermalization()
+        ref = _golden_phi(g, f"sweep{i}_phi")[1:]
+        if exact:
+            assert np.array_equal(rep.phi[1:], ref), f"sweep {i}: trajectory diverged"
+        else:
+            assert np.allclose(rep.phi[1:], ref, rtol=1e-13, atol=1e-15), f"sweep {i}: trajectory diverged"
+        if f"sweep{i}_g" in g:
+            assert relerr(rep.g, g[f"sweep{i}_g"]) < TOL, f"sweep {i}"
+        else:
+            assert relerr(np.diag(rep.g), g[f"sweep{i}_g_diag"]) < TOL, f"sweep {i}"
+        inf = rep.info
+        assert inf.phiDelta == g[f"sweep{i}_phiDelta"][0]
+        assert abs(inf.lastAccRatioLocal_phi - g[f"sweep{i}_lastAccRatio"][0]) < 1e-15
+        if f"sweep{i}_angleDelta" in g:
+            assert inf.angleDelta == g[f"sweep{i}_angleDelta"][0] and inf.scaleDelta == g[f"sweep{i}_scaleDelta"][0], f"sweep {i}"
+            moved.add((inf.angleDelta, inf.scaleDelta))
+        i += 1
+    if name == "o3_L4_rotscale":
+        assert len(moved) >= 3
+    nxt = np.array([rep.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"]), "RNG stream position differs from the reference"
+    rep.close()
+
+
+def test_rotate_scale_parameter_rules():
+    """rotate / scale proposals exist for the O(3) model only (the reference throws from proposeRandomRotatedVector<OPDIM != 3>,
+    /root/reference/src/detsdwopdim.cpp:3934-3942): rejected at create; dqmc_update_slice_ex rejects them for an O(2) context"""
+    from detqmc_amd import DetSDW, DqmcError, SDWParams
+    with pytest.raises(DqmcError) as e:
+        DetSDW(SDWParams(opdim=2, L=4, beta=2.0, spinProposalMethod="rotate_then_scale"))
+    assert "O(3)" in str(e.value)
+    with pytest.raises(DqmcError):
+        DetSDW(SDWParams(opdim=3, L=4, beta=2.0, repeatUpdateInSlice=-1))
+    rep = DetSDW(SDWParams(opdim=2, L=4, beta=2.0))
+    with pytest.raises(DqmcError) as e2:
+        rep.kernel_context.updateInSlice(rep.info.m, proposal="rotate")
+    assert "O(3)" in str(e2.value)
+    rep.close()
 
 
 def test_environment_cannot_change_the_markov_chain():

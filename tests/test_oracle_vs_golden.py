@@ -299,3 +299,32 @@ def test_hubbard_oracle_vs_reference(name):
     assert np.array_equal([o.rng.rand01() for _ in range(4)], g["rng_next"])
     if name == "hub_L4":        # known answer: half filling at mu = 0
         assert abs(o.obs["occTotal"] - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["o3_L4_rotscale", "o3_L4_rotandscale", "o3_L6_rotscale_rep2", "o2_L4_rep3"])
+def test_rotate_scale_proposals_and_repeated_updates(name):
+    """spinProposalMethod = rotate_then_scale / rotate_and_scale with ADAPT_ROTATE / ADAPT_SCALE (O(3); detsdwopdim.cpp:2438-2470,
+    3934-4170, 3299-3375; Box-Muller stack of normaldistribution.h) and repeatUpdateInSlice > 1: same libm as the reference in this
+    container, so the field is bit-identical and angleDelta / scaleDelta move exactly as the reference's do."""
+    g = load_golden(name)
+    o = DetSDWOracle(oracle_params(g["params"]))
+    assert np.array_equal(o.phi[1:], np.transpose(g["init_phi"], (2, 0, 1))[1:])
+    i = 1
+    moved = set()
+    while f"sweep{i}_phi" in g:
+        o.sweepThermalization()
+        assert np.array_equal(o.phi[1:], np.transpose(g[f"sweep{i}_phi"], (2, 0, 1))[1:]), f"sweep {i}: field trajectory diverged"
+        if f"sweep{i}_g" in g:
+            assert relerr(o.g, g[f"sweep{i}_g"]) < TOL
+        else:
+            assert relerr(np.diag(o.g), g[f"sweep{i}_g_diag"]) < TOL
+        assert o.phiDelta == g[f"sweep{i}_phiDelta"][0]
+        assert abs(o.lastAccRatioLocal_phi - g[f"sweep{i}_lastAccRatio"][0]) < 1e-15
+        if f"sweep{i}_angleDelta" in g:
+            assert o.angleDelta == g[f"sweep{i}_angleDelta"][0] and o.scaleDelta == g[f"sweep{i}_scaleDelta"][0]
+            moved.add((o.angleDelta, o.scaleDelta))
+        i += 1
+    if name == "o3_L4_rotscale":
+        assert len(moved) >= 3, "the fixture must exercise both adaptations"
+    nxt = np.array([o.rng.rand01() for _ in range(4)])
+    assert np.array_equal(nxt, g["rng_next"]), "number of RNG draws consumed differs from the reference"
