@@ -180,6 +180,7 @@ SYMBOLS = [
     ("dqmc_backup", C.c_int, [_P]),
     ("dqmc_restore", C.c_int, [_P]),
     ("dqmc_exchange_action_host", C.c_int, [_P, _DP]),
+    ("dqmc_exchange_actions_device", C.c_int, [_P, _P]),
     ("dqmc_phi_action_all_host", C.c_int, [_P, _DP]),
     ("dqmc_shift_fields_all_host", C.c_int, [_P, _DP]),
     ("dqmc_set_exchange_parameter", C.c_int, [_P, C.c_double]),
@@ -219,6 +220,7 @@ SYMBOLS = [
     ("detsdw_set_exchange_parameter_value", C.c_int, [_P, C.c_double]),
     ("detsdw_get_exchange_parameter_name", C.c_char_p, [_P]),
     ("detsdw_get_exchange_action_contribution", C.c_int, [_P, _DP]),
+    ("detsdw_exchange_actions_device", C.c_int, [_P, _P]),
     ("detsdw_get_control_data", C.c_int, [_P, C.POINTER(detsdw_control_data)]),
     ("detsdw_set_control_data", C.c_int, [_P, C.POINTER(detsdw_control_data)]),
     ("detsdw_replica_exchange_probability", C.c_double, [C.c_double] * 4),

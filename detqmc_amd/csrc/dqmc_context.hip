@@ -1553,6 +1553,25 @@ extern "C" int dqmc_exchange_action_host(dqmc_ctx* c, double* out) {
     return DQMC_OK;
 }
 
+// The same for ALL chains, left ON THE DEVICE: out_dev[b] = 1/2 dtau sum phi^2 of chain b, out_dev a caller-owned device array of
+// nchains doubles (e.g. the send buffer of the replica-exchange all_gather over RCCL: no host hop).  Returns when the values are there.
+extern "C" int dqmc_exchange_actions_device(dqmc_ctx* c, double* out_dev) {
+    if (!c || !out_dev) return fail(DQMC_EINVAL, "null argument");
+    (void)hipSetDevice(c->p.device);
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, out_dev) != hipSuccess || at.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(DQMC_EINVAL, "dqmc_exchange_actions_device: out_dev must be device memory");
+    }
+    {
+        ProfScope ps(c, FAM_OTHER, 2);
+        launch_phi_sq_sum(c->lc, c->hm, c->scalar_out);
+        launch_gather_scalars(c->lc, c->scalar_out, 0.5 * c->p.dtau, out_dev);
+    }
+    HIPCHK(hipStreamSynchronize(c->st));
+    return finish(c, "dqmc_exchange_actions_device");
+}
+
 // phiAction of every chain (detsdwopdim.cpp:4242-4300), computed on the device from the resident field: out[nchains]
 extern "C" int dqmc_phi_action_all_host(dqmc_ctx* c, double* out) {
     if (!c || !out) return fail(DQMC_EINVAL, "null argument");

@@ -219,6 +219,7 @@ void launch_add_diag(const Launch& lc, cplx* A, const double* d, int n);
 void launch_copy(const Launch& lc, const cplx* A, cplx* B, size_t count);
 void launch_copy_bytes(const Launch& lc, const void* src, void* dst, size_t bytes);   // same buffer of every chain
 void launch_phi_sq_sum(const Launch& lc, const DevModel& hm, double* out);
+void launch_gather_scalars(const Launch& lc, const double* src, double factor, double* dst);      // dst[b] = factor * src of chain b (dst: plain device array)
 void launch_phi_action(const Launch& lc, const DevModel& hm, const DevUpdateState* us, double* out);
 void launch_phi_shift(const Launch& lc, const DevModel& hm, const double* shifts /* shared buffer [nchains][opdim] */);
 // fermionic observables of one time slice accumulated from the shifted Green's function gs (kernels_measure.hip)

@@ -638,6 +638,9 @@ double DetSDW::get_exchange_action_contribution(int b) {
     check(dqmc_exchange_action_host(ctx_, &v), "get_exchange_action_contribution");
     return v;
 }
+void DetSDW::exchangeActionsDevice(double* out_dev) {
+    for (auto& g : groups_) check(dqmc_exchange_actions_device(g.ctx, out_dev + g.first), "get_exchange_action_contribution (device)");
+}
 void DetSDW::get_control_data(detsdw_control_data& out, int b) {
     dqmc_ctx* ctx_ = select(b);
     out.acceptedGlobalShifts = ch_[b].acceptedGlobalShifts;
@@ -885,6 +888,10 @@ extern "C" int detsdw_set_exchange_parameter_value(detsdw_replica* r, double v) 
 extern "C" const char* detsdw_get_exchange_parameter_name(detsdw_replica* r) { return r ? r->impl->get_exchange_parameter_name() : ""; }
 extern "C" int detsdw_get_exchange_action_contribution(detsdw_replica* r, double* out) {
     RGUARD(*out = r->impl->get_exchange_action_contribution(r->sel))
+}
+extern "C" int detsdw_exchange_actions_device(detsdw_replica* r, double* out_dev) {
+    if (!out_dev) { g_host_err = "null argument"; return DQMC_EINVAL; }
+    RGUARD(r->impl->exchangeActionsDevice(out_dev))
 }
 extern "C" int detsdw_get_control_data(detsdw_replica* r, detsdw_control_data* out) { RGUARD(r->impl->get_control_data(*out, r->sel)) }
 extern "C" int detsdw_set_control_data(detsdw_replica* r, const detsdw_control_data* in) { RGUARD(r->impl->set_control_data(*in, r->sel)) }

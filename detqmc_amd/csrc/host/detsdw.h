@@ -113,6 +113,9 @@ private:
     void sweepUp(Group& g, bool thermalization);
     void updateInSlice(Group& g, int k, bool thermalization);
     int uniformsPerSite() const;
+public:
+    void exchangeActionsDevice(double* out_dev);        // out_dev[chain], device memory
+private:
     void beginLocalUpdates(Group& g);
     void endLocalUpdates(Group& g);
     void globalMove(Group& g);

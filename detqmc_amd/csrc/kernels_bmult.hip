@@ -599,3 +599,12 @@ void launch_phi_shift(const Launch& lc, const DevModel& hm, const double* shifts
 void launch_phi_sq_sum(const Launch& lc, const DevModel& hm, double* out) {
     hipLaunchKernelGGL(k_phi_sq_sum, dim3(1, 1, lc.nb), dim3(256), 0, lc.st, hm, out, lc.cs);
 }
+// dst[b] = factor * (first double of chain b's buffer `src`): the per-chain scalars of a batch gathered into ONE contiguous device
+// array (the send buffer of a collective)
+__global__ void k_gather_scalars(const double* __restrict__ src, size_t cs, int nb, double factor, double* __restrict__ dst) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb) dst[b] = factor * *(const double*)((const char*)src + (size_t)b * cs);
+}
+void launch_gather_scalars(const Launch& lc, const double* src, double factor, double* dst) {
+    hipLaunchKernelGGL(k_gather_scalars, dim3((lc.nb + 63) / 64), dim3(64), 0, lc.st, src, lc.cs, lc.nb, factor, dst);
+}

@@ -550,6 +550,11 @@ class DetSDWBatch:
     def load_state(self, path):
         check(self.lib.detsdw_load_state(self.h, str(path).encode()), host=True)
 
+    def exchange_actions_device(self, device_ptr):
+        """get_exchange_action_contribution of EVERY chain written to device memory (len(self) doubles at device_ptr, e.g.
+        torch_tensor.data_ptr()): the send buffer of the replica-exchange all_gather, no host hop"""
+        check(self.lib.detsdw_exchange_actions_device(self.h, C.c_void_p(int(device_ptr))), host=True)
+
     @property
     def kernel_context(self):
         """the kernel context of chain 0 (the only one unless the batch has several sub-batches)"""

@@ -114,20 +114,44 @@ def replica_exchange_step(replica, state: ExchangeState, dist, device="cpu"):
     blobs_local = [r.get_control_data() for r in reps]
     nblob = len(blobs_local[0])
     rec = 8 + nblob
-    # ---- all ranks -> everyone: per local replica [action as 8 bytes | control blob]
-    payload = b"".join(np.float64(r.get_exchange_action_contribution()).tobytes() + bl for r, bl in zip(reps, blobs_local))
-    send = torch.from_numpy(np.frombuffer(payload, dtype=np.uint8).copy()).to(device)
-    if dist is not None:
-        recv = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(recv, send)
+    # ---- all ranks -> everyone: per local replica the exchange action (8 bytes) and the control blob.
+    # Device collectives (backend nccl = RCCL): when the local replicas are the chains of ONE DetSDWBatch, their actions are reduced on
+    # the GPU straight into the send tensor of the all_gather (detsdw_exchange_actions_device) -- no device -> host -> device hop;
+    # the control blobs (host-side statistics + the step-size state) travel in a second all_gather.
+    batch = getattr(getattr(reps[0], "rep", None), "_batch", None)
+    on_device = (str(device) != "cpu" and batch is not None and len(batch) == nl
+                 and all(getattr(getattr(r, "rep", None), "_batch", None) is batch and r.rep._chain == b for b, r in enumerate(reps)))
+    state.exchange_payload = "device" if on_device else "host"       # which path the last step took (drivers report it)
+    if on_device:
+        send_act = torch.empty(nl, dtype=torch.float64, device=device)
+        batch.exchange_actions_device(send_act.data_ptr())
+        send_blob = torch.from_numpy(np.frombuffer(b"".join(blobs_local), dtype=np.uint8).copy()).to(device)
+        if dist is not None:
+            recv_act = [torch.empty_like(send_act) for _ in range(world)]
+            recv_blob = [torch.empty_like(send_blob) for _ in range(world)]
+            dist.all_gather(recv_act, send_act)
+            dist.all_gather(recv_blob, send_blob)
+        else:
+            recv_act, recv_blob = [send_act], [send_blob]
     else:
-        recv = [send]
+        payload = b"".join(np.float64(r.get_exchange_action_contribution()).tobytes() + bl for r, bl in zip(reps, blobs_local))
+        send = torch.from_numpy(np.frombuffer(payload, dtype=np.uint8).copy()).to(device)
+        if dist is not None:
+            recv = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(recv, send)
+        else:
+            recv = [send]
     # ---- rank 0 decides, serially over adjacent control parameters, with ITS first replica's RNG stream
     out = torch.zeros(nproc * rec, dtype=torch.uint8)
     if rank == 0:
-        gathered = b"".join(r.cpu().numpy().tobytes() for r in recv)
-        actions = [float(np.frombuffer(gathered[p * rec:p * rec + 8], dtype=np.float64)[0]) for p in range(nproc)]
-        blobs = [gathered[p * rec + 8:(p + 1) * rec] for p in range(nproc)]
+        if on_device:
+            actions = [float(v) for t in recv_act for v in t.cpu().tolist()]
+            allblob = b"".join(t.cpu().numpy().tobytes() for t in recv_blob)
+            blobs = [allblob[p * nblob:(p + 1) * nblob] for p in range(nproc)]
+        else:
+            gathered = b"".join(r.cpu().numpy().tobytes() for r in recv)
+            actions = [float(np.frombuffer(gathered[p * rec:p * rec + 8], dtype=np.float64)[0]) for p in range(nproc)]
+            blobs = [gathered[p * rec + 8:(p + 1) * rec] for p in range(nproc)]
         # histograms of replicas moving up or down in parameter space (src/detqmcpt.h:1016-1029): a replica that visited
         # the highest parameter last is "going down", the lowest "going up"
         for pi in range(nproc):

@@ -170,6 +170,8 @@ double detsdw_get_exchange_parameter_value(detsdw_replica* r);
 int detsdw_set_exchange_parameter_value(detsdw_replica* r, double value);
 const char* detsdw_get_exchange_parameter_name(detsdw_replica* r);
 int detsdw_get_exchange_action_contribution(detsdw_replica* r, double* out);
+/* all chains of the handle at once, on the device: out_dev[chain] (device array of detsdw_num_chains doubles) */
+int detsdw_exchange_actions_device(detsdw_replica* r, double* out_dev);
 int detsdw_get_control_data(detsdw_replica* r, detsdw_control_data* out);
 int detsdw_set_control_data(detsdw_replica* r, const detsdw_control_data* in);
 /* get_replica_exchange_probability<DetSDW> (src/detsdwopdim.cpp:5251-5264) */

@@ -244,6 +244,9 @@ int dqmc_phi_action_all_host(dqmc_ctx* ctx, double* out);
 int dqmc_shift_fields_all_host(dqmc_ctx* ctx, const double* shifts);
 /* 1/2 dtau sum phi^2 (get_exchange_action_contribution, detsdwopdim.cpp:5205-5216) */
 int dqmc_exchange_action_host(dqmc_ctx* ctx, double* out);
+/* the same for every chain of the context, written to a caller-owned DEVICE array of nchains doubles (the send buffer of the
+ * replica-exchange all_gather, src/detqmcpt.h:1003-1010, without a host hop); returns when the values are there */
+int dqmc_exchange_actions_device(dqmc_ctx* ctx, double* out_dev);
 
 /* ---- fermionic measurements --------------------------------------------------
  * shiftGreenSymmetric (src/detsdwopdim.cpp:4507-4612): e^{-dtau K/2} G e^{+dtau K/2} of the selected chain */

@@ -61,7 +61,7 @@ def main():
     device = "cpu"
     if a.one_device:
         local = 0
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:         # under torch.distributed.run the collectives run for ONE rank as well
         import torch.distributed as dist
         if a.backend == "nccl":
             torch.cuda.set_device(local)
@@ -135,7 +135,7 @@ def run_conf(a):
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     dist, device = None, "cpu"
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:         # under torch.distributed.run the collectives run for ONE rank as well
         import torch.distributed as dist
         if a.backend == "nccl":
             torch.cuda.set_device(local)
@@ -229,6 +229,7 @@ def run_conf(a):
                 mm["r"] = PT.num_to_string(rvals[cpi])
                 PT.write_config_infoheader(subdir(cpi), mm, meta_mc, meta_pt, cdw=kw["cdwU"] != 0.0)
         print("Measurements finished", flush=True)
+        print("exchange payload: %s tensors, backend %s" % (getattr(st, "exchange_payload", "none"), a.backend if dist is not None else "none (single process)"), flush=True)
     batch.close()
     if dist is not None:
         dist.barrier()

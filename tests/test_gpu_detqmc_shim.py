@@ -209,6 +209,8 @@ def test_detqmcpt_driver_with_gpu_model_over_mpi_writes_the_reference_output_tre
                          timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "Measurements finished" in out.stdout
+    if launch.startswith("rccl"):
+        assert "exchange payload: device tensors, backend nccl" in out.stdout
     _compare_pt_tree(str(tmp_path))
     for p in range(4):
         assert os.path.exists(tmp_path / ("simulation.%d.state" % p))
@@ -235,20 +237,31 @@ def test_one_device_per_rank_without_enough_devices_fails_cleanly(tmp_path):
     assert not [d for d in os.listdir(tmp_path) if d.startswith("p0_") or d.startswith("p1_") or d.startswith("exchange-")]
 
 
-@pytest.mark.parametrize("launch", ["one process, 4 replicas in one batch", "2 processes x 2 replicas (gloo)"])
+@pytest.mark.parametrize("launch", ["one process, 4 replicas in one batch", "2 processes x 2 replicas (gloo)",
+                                    "rccl: torch.distributed.run, 1 rank x 4 replicas, backend nccl"])
 def test_python_replica_exchange_driver_writes_the_reference_output_tree(tmp_path, launch):
     """The repo's OWN replica-exchange driver -- scripts/run_pt.py over detqmc_amd/pt.py (replica_exchange_step, ObservableRouterPT,
     write_exchange_statistics, time series, per-parameter configuration streams) -- run on the reference's configuration file must
     write the tree the reference's `mpiexec -n 4 detqmcptsdwo2` wrote: same exchange decisions (DetQMCPT::replicaExchangeStep,
     /root/reference/src/detqmcpt.h:963-1118), same per-control-parameter accumulation and jackknife errors
     (src/mpiobservablehandlerpt.cpp:65-110, 176-215), same exchange-*.values (src/detqmcpt.h:596-660).  Once with all four replicas
-    in one batch on one rank, once spread over two ranks (torch.distributed, gloo, both on the one GPU of the box)."""
+    in one batch on one rank, once spread over two ranks (torch.distributed, gloo, both on the one GPU of the box), and once through
+    the RCCL branch the multi-GPU runs use (backend "nccl", process group initialised with the device, DEVICE tensors through
+    all_gather / broadcast, the exchange actions reduced on the GPU straight into the send tensor: detsdw_exchange_actions_device) --
+    with the one rank a one-GPU box allows."""
     import sys
     shutil.copy(os.path.join(PT_CASE, "simulation.conf"), tmp_path)
     script = os.path.join(ROOT, "scripts", "run_pt.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if launch.startswith("one"):
         cmd = [sys.executable, script, "--conf", "simulation.conf", "--stabilisation", "svd"]
+    elif launch.startswith("rccl"):
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script, "--conf", "simulation.conf", "--backend", "nccl", "--check"]
     else:
         import socket
         with socket.socket() as sk:
@@ -259,6 +272,8 @@ def test_python_replica_exchange_driver_writes_the_reference_output_tree(tmp_pat
     out = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "Measurements finished" in out.stdout
+    if launch.startswith("rccl"):
+        assert "exchange payload: device tensors, backend nccl" in out.stdout
     _compare_pt_tree(str(tmp_path))
 
 
