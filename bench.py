@@ -277,8 +277,24 @@ def worker(a, readline=None, emit=None):
     else:
         from detqmc_amd import DetSDWBatch, SDWParams
         p0 = SDWParams(device=a.device, **WORKLOAD)
-        batch = DetSDWBatch([dataclasses.replace(p0, simindex=a.simindex * B + i) for i in range(B)], sub_batches=a.sub_batches)
+        if a.exchange:
+            # the chains of this worker are the replicas of ONE parallel-tempering ensemble in r (BASELINE configs 4 / 5: 8 replicas):
+            # a ladder of control parameters, replicaExchangeStep after every sweep (detqmc_amd/pt.py; src/detqmcpt.h:963-1118)
+            rvals = [-1.4 + 0.8 * i / max(B - 1, 1) for i in range(B)]
+            batch = DetSDWBatch([dataclasses.replace(p0, simindex=a.simindex * B + i, r=rvals[i]) for i in range(B)], sub_batches=a.sub_batches)
+        else:
+            batch = DetSDWBatch([dataclasses.replace(p0, simindex=a.simindex * B + i) for i in range(B)], sub_batches=a.sub_batches)
         ctx = batch.kernel_context
+    if a.exchange and not FAKE:
+        from detqmc_amd.pt import ExchangeState, ReplicaAdapter, replica_exchange_step
+        pt_reps = [ReplicaAdapter(batch.chain(b)) for b in range(B)]
+        pt_state = ExchangeState.create(rvals, 0, 1, B)
+        sweep_only = batch.sweepThermalization
+
+        def sweep_and_exchange():
+            sweep_only()
+            replica_exchange_step(pt_reps, pt_state, None)
+        batch.sweepThermalization = sweep_and_exchange
     for _ in range(a.warmup):
         batch.sweepThermalization()
     if ctx:
@@ -556,6 +572,9 @@ def main():
                     help="independent Markov chains per worker process (default: the configuration's)")
     ap.add_argument("--sub-batches", type=int, default=int(os.environ.get("DQMC_SUB_BATCHES", "0")),
                     help="kernel contexts per worker process the chains are spread over (swept concurrently, one host thread each)")
+    ap.add_argument("--exchange", action="store_true",
+                    help="the chains of a worker are the replicas of one parallel-tempering ensemble (r ladder -1.4 ... -0.6): a replica-exchange "
+                         "step after every sweep, inside the timed region (BASELINE configs 4 / 5: --batch 8)")
     ap.add_argument("--inprocess", action="store_true",
                     help="ONE context in this process instead of worker processes (for rocprofv3)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
@@ -611,7 +630,7 @@ def main():
 
     def spawn(device, simindex, batch, steps, warmup, sub=None, extra_env=None):
         cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--config", a.config, "--device", str(0 if one_device else device), "--simindex",
-               str(simindex), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch), "--sub-batches", str(sub or S)]
+               str(simindex), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch), "--sub-batches", str(sub or S)] + (["--exchange"] if a.exchange else [])
         return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=dict(env, **(extra_env or {})))
 
     procs = []          # (gpu index, process)
@@ -729,7 +748,8 @@ def main():
             "config": {"workload": CONFIGS[a.config]["text"] + " checkerboard delayed(%d) " % WORKLOAD["delaySteps"] +
                                    "sweepThermalization, %d independent chains per GPU (%d process x %d kernel contexts x %d lockstep chains), stabilisation=%s%s"
                                    % (R * B, R, S, B // S, WORKLOAD["stabilisation"],
-                                      ", global shift move every %d sweeps" % WORKLOAD["globalUpdateInterval"] if WORKLOAD.get("globalShift") else ""),
+                                      (", global shift move every %d sweeps" % WORKLOAD["globalUpdateInterval"] if WORKLOAD.get("globalShift") else "") +
+                                      (", the chains of a process are ONE replica-exchange ensemble in r (ladder -1.4 ... -0.6), exchange step after every sweep" if a.exchange else "")),
                        "n_g": n, "m": r0["m"], "replicas_per_gpu": R * B, "processes_per_gpu": R, "contexts_per_process": S,
                        "chains_per_context": B // S,
                        "launch": "torch.distributed.run" if world > 1 else "self"},

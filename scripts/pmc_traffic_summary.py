@@ -24,7 +24,7 @@ def family(name):
     m = re.search(r"k_zgemm<(\d+), (\d+), (?:true|false), (\d+)", name)        # <TM, TN, M3, TAG, OPA, OPB>
     if m and m.group(3) == "1":
         return "gemm_in_factorisation"          # TAG = 1: LU trailing updates, triangular solves, block Gram-Schmidt products (kernels_gemm.hip)
-    if re.search(r"k_flush<(?:true|false), (?:true|false), \d+, 1>", name):
+    if re.search(r"k_flush<(?:true|false), (?:true|false), \d+, 1>", name) or "k_flush_lds<1>" in name:
         return "lu_update"                      # <M3, FULL, STAGE, TAG = 1>: trailing updates of the LU factorisation on the flush kernel (kernels_lu.hip)
     for key, fam in FAMILY:
         if key in name:
