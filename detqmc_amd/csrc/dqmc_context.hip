@@ -78,7 +78,6 @@ struct dqmc_ctx {
     int* qr_perm = nullptr;
     int* lu_swaps = nullptr;
     cplx* lu_tneg = nullptr;       // -U12^T of the current LU panel (n_g x 32), operand of the trailing update on k_flush
-    cplx* tri_dinv = nullptr;      // inverses of the 64 x 64 diagonal blocks of a triangular factor (run_trsm_right_upper_oop), LU route only
     uint64_t lu_calls = 0;         // gather lists of the LU panels (kernels_lu.hip)
     int* qr_perm_inv = nullptr;      // inverse of qr_perm and 1/d of the last lazy UDT (triangular chaining product)
     double* qr_dinv = nullptr;
@@ -645,7 +644,6 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
         A_(dalloc(c, &c->qw.W, (size_t)16 * ng)); A_(dalloc(c, &c->qw.W2, (size_t)16 * ng)); A_(dalloc(c, &c->qw.Rneg, (size_t)32 * ng));
         if (ng > 1024) { c->qw.part_count = (size_t)ng * 64 * 8; A_(dalloc(c, &c->qw.part, c->qw.part_count)); }   // split-K scratch of the block Gram-Schmidt QR
         A_(dalloc(c, &c->qr_perm, (size_t)ng)); A_(dalloc(c, &c->lu_swaps, (size_t)LU_SWAP_INTS)); A_(dalloc(c, &c->lu_tneg, (size_t)ng * 32)); A_(dalloc(c, &c->qr_perm_inv, (size_t)ng)); A_(dalloc(c, &c->qr_dinv, (size_t)ng));
-        if (ng <= 512) A_(dalloc(c, &c->tri_dinv, (size_t)((ng + 63) / 64) * 64 * 64));
         A_(dalloc(c, &c->rmax_inv, (size_t)ng)); A_(dalloc(c, &c->rmin, (size_t)ng));
         A_(dalloc(c, &c->lmax_inv, (size_t)ng)); A_(dalloc(c, &c->lmin, (size_t)ng));
     }
@@ -993,17 +991,15 @@ static int green_qr(dqmc_ctx* c, const UdVSlot* Lp, const UdVSlot* Rp) {
         {
             ProfScope ps(c, FAM_JACOBI, 0);
             int launches = run_lu(c->lc, n, c->T2, c->qr_perm, c->lu_swaps, c->lu_tneg);                  // T2 = L \ U, qr_perm = row permutation
-            // the two triangular solves out of place with the 64 x 64 diagonal blocks inverted once (kernels_qr.hip): every step of the
-            // recursion is a product on full tiles of the matrix cores
             launch_permute_scale_cols(c->lc, L.Vt, c->lmax_inv, nullptr, n, c->T3);
-            launches += run_trsm_right_upper_oop(c->lc, n, c->T2, c->T3, c->T4, c->tri_dinv);           // T4 = (V_l Dlmax^-1) U^-1
+            launches += run_trsm_right_upper(c->lc, n, c->T2, c->T3, c->qw);                  // T3 = (V_l Dlmax^-1) U^-1
             launch_logdet_vector(c->lc, c->T2, c->rmax_inv, c->lmax_inv, n, c->sv);           // |det Z| = prod |U_kk|
             launch_gather_scale_cols(c->lc, R.U, c->rmax_inv, c->qr_perm, n, c->T1);          // T1 = (U_r Drmax^-1) P^T
-            launches += run_trsm_right_upper_oop(c->lc, n, c->T2, c->T1, c->sw.A, c->tri_dinv, 1, 1);   // sw.A = T1 (L^H)^-1
+            launches += run_trsm_right_upper(c->lc, n, c->T2, c->T1, c->qw, 1, 1);            // T1 <- T1 (L^H)^-1
             c->fam_launches[FAM_JACOBI] += launches + 3;
             c->lu_calls += 1;
         }
-        gemm_dev(c, 0, 1, c->T4, c->sw.A, c->G);                                              // G = [(V_l Dlmax^-1) U^-1] [(U_r Drmax^-1 P^T) L^-H]^H
+        gemm_dev(c, 0, 1, c->T3, c->T1, c->G);                                                // G = T3 T1^H
         return DQMC_OK;
     }
     {

@@ -237,7 +237,6 @@ int run_qr_apply_q(const Launch& lc, int n, cplx* C, const QrWork& w, int trans)
 int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w);
 void qr_reset_workspace(const Launch& lc, int n, const QrWork& w);      // zero w.V / w.T before Householder panels follow a block Gram-Schmidt run
 int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w, int trans = 0, int unit = 0);   // C <- C R^-1 (trans: R = (stored lower triangle)^H; unit: unit diagonal)
-int run_trsm_right_upper_oop(const Launch& lc, int n, const cplx* R, cplx* C, cplx* Y, cplx* Dinv, int trans = 0, int unit = 0);   // Y <- C R^-1 out of place, diagonal blocks inverted once (Dinv: ceil(n / 64) * 4096 complex of scratch); C is consumed
 #define LU_SWAP_INTS 128
 int run_lu(const Launch& lc, int n, cplx* A, int* perm, int* swaps, cplx* tneg);    // tneg: scratch of n * 32 complex per chain                                 // P A = L U in place (n <= 512, else -1), kernels_lu.hip
 void launch_gather_scale_cols(const Launch& lc, const cplx* X, const double* cs, const int* perm, int n, cplx* Y);   // Y[:, j] = X[:, perm[j]] cs[perm[j]]

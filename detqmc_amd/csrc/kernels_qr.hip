@@ -16,7 +16,6 @@
 //   trailing update and formation of Q: three small GEMMs per panel on the MFMA kernel
 //                 (W = V^H C, W <- -T^(H) W, C += V W).
 #include "dqmc_internal.h"
-#include <mutex>
 #include <cstring>
 
 #define QR_NB 16
@@ -852,107 +851,6 @@ static int trsm_rec(const Launch& lc, int n, const cplx* R, cplx* C, int j0, int
 int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const QrWork& w, int trans, int unit) {
     (void)w;
     return trsm_rec(lc, n, R, C, 0, n, trans, unit);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Round 4: the same solve OUT OF PLACE with the diagonal blocks inverted once.  trsm_rec above ends in 32-wide diagonal solves by one
-// thread per row (k_trsm_block: 16 launches of ~ 25 us per solve at n = 512 -- 400 of the 1600 us a solve takes) and 32-wide updates on
-// 32 x 32 GEMM tiles.  Here: ONE launch inverts all 64 x 64 diagonal blocks (k_tri_inv64: back substitution, one thread per column of
-// the inverse), after which a leaf is the product Y_J = C_J R_JJ^-1 on the matrix cores (full 64 x 64 tiles) and the recursion stops at
-// 64: per solve 1 + 8 leaf products + 7 level updates instead of 16 diagonal kernels + 15 updates.  The solution goes to Y, C is
-// consumed (its columns are updated level by level).  Used by the LU route of the Green's function (green_qr, dqmc_context.hip).
-// ---------------------------------------------------------------------------------------------
-#define TRI_NB 64
-// Dinv block J (64 x 64, ld 64, dense: zero below the diagonal) = (the upper triangular block J of the matrix)^-1
-__global__ __launch_bounds__(64) void k_tri_inv64(const cplx* __restrict__ R, int ldr, int n, int trans, int unit, cplx* __restrict__ Dinv, size_t cs) {
-    extern __shared__ cplx tri_sm[];               // the block, [row][col], row stride 65
-    CHAIN(R); CHAIN(Dinv);
-    const int J = blockIdx.x, j0 = J * TRI_NB, nb = min(TRI_NB, n - j0);
-    const int t = threadIdx.x;
-    for (int idx = t; idx < TRI_NB * TRI_NB; idx += 64) {
-        const int r = idx % TRI_NB, c = idx / TRI_NB;
-        cplx v = make_double2(0.0, 0.0);
-        if (r < nb && c < nb && r <= c) {
-            if (unit && r == c) v = make_double2(1.0, 0.0);
-            else if (trans) { const cplx x = R[(size_t)(j0 + r) * ldr + (j0 + c)]; v = make_double2(x.x, -x.y); }
-            else v = R[(size_t)(j0 + c) * ldr + (j0 + r)];
-        } else if (r == c) v = make_double2(1.0, 0.0);          // padding of a ragged last block: identity
-        tri_sm[r * (TRI_NB + 1) + c] = v;
-    }
-    __syncthreads();
-    // column c = t of the inverse: x_c = 1 / r_cc;  x_i = -(sum_{k = i+1 .. c} r_ik x_k) / r_ii for i = c - 1 .. 0
-    const int c = t;
-    cplx x[TRI_NB];
-#pragma unroll
-    for (int i = 0; i < TRI_NB; ++i) x[i] = make_double2(0.0, 0.0);
-    {
-        const cplx d = tri_sm[c * (TRI_NB + 1) + c];
-        const double dn = d.x * d.x + d.y * d.y;
-        // (static indexing only: a run-time index into x[] would move the array to scratch memory)
-#pragma unroll
-        for (int i = TRI_NB - 1; i >= 0; --i) {
-            if (i == c) x[i] = make_double2(d.x / dn, -d.y / dn);
-            else if (i < c) {
-                cplx acc = make_double2(0.0, 0.0);
-#pragma unroll
-                for (int k = i + 1; k < TRI_NB; ++k) {
-                    if (k <= c) {
-                        const cplx r = tri_sm[i * (TRI_NB + 1) + k];
-                        acc.x += r.x * x[k].x - r.y * x[k].y;
-                        acc.y += r.x * x[k].y + r.y * x[k].x;
-                    }
-                }
-                const cplx dd = tri_sm[i * (TRI_NB + 1) + i];
-                const double dnn = dd.x * dd.x + dd.y * dd.y;
-                // -(acc) / dd
-                x[i] = make_double2(-(acc.x * dd.x + acc.y * dd.y) / dnn, -(acc.y * dd.x - acc.x * dd.y) / dnn);
-            }
-        }
-    }
-    cplx* out = Dinv + (size_t)J * TRI_NB * TRI_NB + (size_t)c * TRI_NB;
-#pragma unroll
-    for (int i = 0; i < TRI_NB; ++i) out[i] = x[i];
-}
-
-static int trsm_oop_rec(const Launch& lc, int n, const cplx* R, cplx* C, cplx* Y, const cplx* Dinv, int j0, int len, int trans) {
-    if (len <= TRI_NB) {
-        // Y[:, J] = C[:, J] Dinv_J
-        GemmArgs g = GemmArgs();
-        g.A = C + (size_t)j0 * n; g.lda = n; g.opA = 0;
-        g.B = Dinv + (size_t)(j0 / TRI_NB) * TRI_NB * TRI_NB; g.ldb = TRI_NB; g.opB = 0;
-        g.C = Y + (size_t)j0 * n; g.ldc = n;
-        g.M = n; g.N = len; g.K = len; g.Kmul = 1; g.tag = 1;
-        launch_gemm(lc, g);
-        return 1;
-    }
-    const int h = ((len / 2 + TRI_NB - 1) / TRI_NB) * TRI_NB;
-    int launches = trsm_oop_rec(lc, n, R, C, Y, Dinv, j0, h, trans);
-    // C[:, j0 + h .. j0 + len) -= Y[:, j0 .. j0 + h) R[j0 .. j0 + h, j0 + h .. j0 + len)
-    GemmArgs g = GemmArgs();
-    g.A = Y + (size_t)j0 * n; g.lda = n; g.opA = 0; g.C = C + (size_t)(j0 + h) * n; g.ldc = n;
-    if (trans) { g.B = R + (size_t)j0 * n + (j0 + h); g.ldb = n; g.opB = 1; }          // (L^H)[J1, J2] = conj(L[J2, J1])^T
-    else       { g.B = R + (size_t)(j0 + h) * n + j0; g.ldb = n; g.opB = 0; }
-    g.M = n; g.N = len - h; g.K = h; g.Kmul = 1; g.accumulate = 1; g.negate = 1; g.tag = 1;
-    launch_gemm(lc, g);
-    return launches + 1 + trsm_oop_rec(lc, n, R, C, Y, Dinv, j0 + h, len - h, trans);
-}
-// Y <- C R^-1 (R upper triangular n x n; trans: R = (stored lower triangle)^H; unit: unit diagonal); C is overwritten with
-// intermediate values, Dinv: scratch of ceil(n / 64) * 4096 complex per chain
-int run_trsm_right_upper_oop(const Launch& lc, int n, const cplx* R, cplx* C, cplx* Y, cplx* Dinv, int trans, int unit) {
-    static std::mutex mu;
-    static bool raised[64] = {};
-    const size_t lds = (size_t)TRI_NB * (TRI_NB + 1) * sizeof(cplx);
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> lk(mu);
-        if (!raised[dev & 63]) {
-            if (hipFuncSetAttribute((const void*)k_tri_inv64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) raised[dev & 63] = true;
-            else (void)hipGetLastError();
-        }
-    }
-    hipLaunchKernelGGL(k_tri_inv64, dim3((n + TRI_NB - 1) / TRI_NB, 1, lc.nb), dim3(64), lds, lc.st, R, n, n, trans, unit, Dinv, lc.cs);
-    return 1 + trsm_oop_rec(lc, n, R, C, Y, Dinv, 0, n, trans);
 }
 
 // ---------------------------------------------------------------------------------------------
