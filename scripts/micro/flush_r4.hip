@@ -735,6 +735,359 @@ __global__ __launch_bounds__(256, MINB) void k_flush_pipe_tim(const cplx* __rest
 #undef TICK
 }
 
+// var 7: WARP-SPECIALISED persistent workgroups (one per CU, 10 waves): waves 0-3 only issue LDS reads and MFMAs, waves 4-5 only the
+// LDS-DMA of the operand panels, waves 6-9 only the read-modify-write of G (they take the finished 32 x 32 blocks of the compute waves
+// from LDS).  No barriers: LDS counters (ds_add / ds_read) hand buffers back and forth, so a memory wave stalled in the issue of a
+// global_load never holds up the MFMA stream -- the one structure var 4-6's measurements do not rule out.  Every spin is capped: a
+// protocol bug ends in wrong numbers and an error word, never in a hung GPU.
+// RESULT (profiles/r04_flush_micro.log): bit-identical, no time-outs, 1.6 x SLOWER than production at every K (290 vs 180 us at the bench
+// mix).  Two loader waves are busy 78 % (LDS-DMA) / 89 % (register staged) of the kernel and still starve the MFMA waves 25-36 %.
+__device__ __forceinline__ void ws_flag_add(unsigned* flag) {
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)flag, one = 1;
+    asm volatile("ds_add_u32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(a), "v"(one) : "memory");
+}
+__device__ __forceinline__ unsigned ws_flag_read(unsigned* flag) {
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)flag;
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+// wait until *flag >= want (wave-uniform); returns false on time-out or when another wave has raised the abort word
+__device__ __forceinline__ bool ws_wait(unsigned* flag, unsigned want, unsigned* abort_word) {
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+        const unsigned v = __builtin_amdgcn_readfirstlane(ws_flag_read(flag));
+        if ((int)(v - want) >= 0) return true;
+        if ((spin & 255) == 255 && __builtin_amdgcn_readfirstlane(ws_flag_read(abort_word)) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if ((threadIdx.x & 63) == 0) ws_flag_add(abort_word);
+    return false;
+}
+template<int NBUF>
+__global__ __launch_bounds__(640) void k_flush_ws(const cplx* __restrict__ X0, const cplx* __restrict__ GrT0, int ld,
+                                                   cplx* __restrict__ G0, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb,
+                                                   unsigned* __restrict__ err) {
+    constexpr int KH = 16;
+    extern __shared__ cplx sm[];                  // panels [NBUF][ Xs[KH][64], Gs[KH][64] ], then the hand-over buffer acc[4][32][16] (one half of every 32 x 32 block)
+    __shared__ int sK[128];
+    __shared__ unsigned flags[4 + 2 * 4];         // 0 acc_ready, 1 acc_done, 2 abort; 4 + b pan_ready[b], 8 + b pan_done[b]
+    cplx* accb = sm + NBUF * 2 * KH * 64;
+    const int tn = n / 64, tiles = tn * tn;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int per = nb >> 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    for (int q = tid; q < per; q += 640) sK[q] = Kdev[q * 8 + xcd];
+    if (tid < 12) flags[tid] = 0;
+    __syncthreads();                              // the only barrier
+    const int T = per * tiles;
+    auto skip = [&](int u) { while (u < T && sK[u / tiles] <= 0) u += W; return u; };
+    unsigned* abortw = &flags[2];
+    if (wave < 4) {
+        // ------------------------------------------------ compute waves
+        const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+        v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+        auto zero = [&]() {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+        };
+        auto mac = [&](const cplx (&f)[4]) {
+            double asum[2], bsum[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                    acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+                }
+        };
+        zero();
+        unsigned chunk = 0, half_no = 0;          // chunks and hand-over halves so far
+        for (int u = skip(w); u < T; u = skip(u + W)) {
+            const int K8 = (sK[u / tiles] + 7) & ~7;
+            for (int kb = 0; kb < K8; kb += KH, ++chunk) {
+                const int kc = min(KH, K8 - kb);
+                const int buf = chunk % NBUF;
+                if (!ws_wait(&flags[4 + buf], 2 * (chunk / NBUF + 1), abortw)) return;
+                const cplx* Xs = sm + buf * 2 * KH * 64;
+                const cplx* Gs = Xs + KH * 64;
+                auto loadf = [&](int kl, cplx (&f)[4]) {
+                    const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+                    const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+                    f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+                };
+                cplx s[4], t[4];
+                loadf(0, s);
+                for (int k0 = 0; k0 < kc; k0 += 8) {
+                    loadf(k0 + 4, t);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(s);
+                    __builtin_amdgcn_sched_barrier(0);
+                    loadf(min(k0 + 8, kc - 4), s);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(t);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) ws_flag_add(&flags[8 + buf]);               // this wave is done with the buffer
+            }
+            // hand the 32 x 32 block over in two halves (rows a 16 .. a 16 + 15): accb[wave][col][row & 15]
+            cplx* ab = accb + wave * 512;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (!ws_wait(&flags[1], 4 * half_no, abortw)) return;      // the previous half has been taken by all four read-modify-write waves
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const v4d im = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+                    const v4d re = acc_re[a][b] - acc_p2[a][b];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ab[(b * 16 + 4 * r + l4) * 16 + l15] = make_double2(re[r], im[r]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) ws_flag_add(&flags[0]);
+                half_no += 1;
+            }
+            zero();
+        }
+    } else if (wave < 6) {
+        // ------------------------------------------------ panel loaders: wave 4 the X panel, wave 5 the GrT panel.  Register staged (16 plain loads of 1 KB
+        // in flight per chunk, then 16 LDS writes): a wave gets one LDS-DMA instruction out per ~ 330 cycles (phase timers of the first
+        // version: the two loader waves were busy 78 % of the time issuing 2048 of them), plain loads pipeline.  Two register sets: the
+        // loads of chunk q + 1 are in flight while chunk q waits for its LDS buffer and is written.
+        const int which = wave - 4;
+        unsigned chunk = 0;
+        int u = skip(w), kb = 0;                  // the chunk whose loads are issued next
+        auto chunk_src = [&](int uu, int kbb, int& kc) -> const cplx* {
+            const int q = uu / tiles, tile = uu - q * tiles;
+            const int K8 = (sK[q] + 7) & ~7;
+            kc = min(KH, K8 - kbb);
+            const size_t off = (size_t)(q * 8 + xcd) * cs;
+            return (which == 0 ? X0 + off + (tile % tn) * 64 : GrT0 + off + (tile / tn) * 64) + lane + (size_t)kbb * ld;
+        };
+        auto advance = [&]() { const int K8 = (sK[u / tiles] + 7) & ~7; kb += KH; if (kb >= K8) { kb = 0; u = skip(u + W); } };
+        double rAx[KH], rAy[KH], rBx[KH], rBy[KH];   // (arrays of double2 are not promoted to registers by this hipcc; arrays of double are)
+        int kcA = 0, kcB = 0;
+#define WS_ISSUE(r, kc) do { kc = 0; if (u < T) { const cplx* src_ = chunk_src(u, kb, kc); \
+            _Pragma("unroll") for (int kl = 0; kl < KH; ++kl) { const cplx t_ = src_[(size_t)min(kl, kc - 1) * ld]; r##x[kl] = t_.x; r##y[kl] = t_.y; } advance(); } } while (0)
+#define WS_COMMIT(r, kc) do { const int buf = chunk % NBUF; if (!ws_wait(&flags[8 + buf], 4 * (chunk / NBUF), abortw)) return; \
+            cplx* dst_ = sm + buf * 2 * KH * 64 + which * KH * 64 + lane; \
+            _Pragma("unroll") for (int kl = 0; kl < KH; ++kl) dst_[min(kl, kc - 1) * 64] = make_double2(r##x[kl], r##y[kl]); \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) ws_flag_add(&flags[4 + buf]); chunk += 1; } while (0)
+        WS_ISSUE(rA, kcA);
+        while (kcA > 0) {
+            WS_ISSUE(rB, kcB);
+            WS_COMMIT(rA, kcA);
+            if (kcB == 0) break;
+            WS_ISSUE(rA, kcA);
+            WS_COMMIT(rB, kcB);
+        }
+#undef WS_ISSUE
+#undef WS_COMMIT
+    } else {
+        // ------------------------------------------------ read-modify-write of G: wave 6 + m owns columns 16 m .. 16 m + 15 of the tile, lane = row
+        const int mw = wave - 6;
+        unsigned half_no = 0;
+        for (int u = skip(w); u < T; u = skip(u + W)) {
+            const int q = u / tiles, tile = u - q * tiles;
+            cplx* base = G0 + (size_t)(q * 8 + xcd) * cs + (size_t)((tile / tn) * 64 + 16 * mw) * ldc + (tile % tn) * 64 + lane;
+            cplx c[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const cplx* p = base + (size_t)j * ldc; c[j].x = __builtin_nontemporal_load(&p->x); c[j].y = __builtin_nontemporal_load(&p->y); }
+            // column 16 mw + j of the tile, row = lane: compute wave (lane >> 5, (16 mw) >> 5), half (lane >> 4) & 1, row-in-half lane & 15
+            const cplx* ab = accb + (((lane >> 5) * 2 + ((16 * mw) >> 5)) * 512) + ((16 * mw) & 31) * 16 + (lane & 15);
+            cplx d[16];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (!ws_wait(&flags[0], 4 * (half_no + 1), abortw)) return;
+                if (((lane >> 4) & 1) == a) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) d[j] = ab[j * 16];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) ws_flag_add(&flags[1]);
+                half_no += 1;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                cplx* p = base + (size_t)j * ldc;
+                __builtin_nontemporal_store(c[j].x + d[j].x, &p->x);
+                __builtin_nontemporal_store(c[j].y + d[j].y, &p->y);
+            }
+        }
+    }
+    if (tid == 0 && flags[2] != 0) atomicAdd(err, 1u);
+}
+
+template<int NBUF>
+__global__ __launch_bounds__(640) void k_flush_wst(const cplx* __restrict__ X0, const cplx* __restrict__ GrT0, int ld,
+                                                   cplx* __restrict__ G0, int ldc, int n, const int* __restrict__ Kdev, size_t cs, int nb,
+                                                   unsigned* __restrict__ err, unsigned long long* __restrict__ dbg) {
+    constexpr int KH = 16;
+    unsigned long long twait = 0, tstart = __builtin_readcyclecounter(), tw0;
+#define WSWAIT(f, v) (tw0 = __builtin_readcyclecounter(), wsok = ws_wait(f, v, abortw), twait += __builtin_readcyclecounter() - tw0, wsok)
+    bool wsok = true;
+    extern __shared__ cplx sm[];                  // panels [NBUF][ Xs[KH][64], Gs[KH][64] ], then the hand-over buffer acc[4][32][16] (one half of every 32 x 32 block)
+    __shared__ int sK[128];
+    __shared__ unsigned flags[4 + 2 * 4];         // 0 acc_ready, 1 acc_done, 2 abort; 4 + b pan_ready[b], 8 + b pan_done[b]
+    cplx* accb = sm + NBUF * 2 * KH * 64;
+    const int tn = n / 64, tiles = tn * tn;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int per = nb >> 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    for (int q = tid; q < per; q += 640) sK[q] = Kdev[q * 8 + xcd];
+    if (tid < 12) flags[tid] = 0;
+    __syncthreads();                              // the only barrier
+    const int T = per * tiles;
+    auto skip = [&](int u) { while (u < T && sK[u / tiles] <= 0) u += W; return u; };
+    unsigned* abortw = &flags[2];
+    if (wave < 4) {
+        // ------------------------------------------------ compute waves
+        const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+        v4d acc_re[2][2], acc_im[2][2], acc_p2[2][2];
+        auto zero = [&]() {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) { acc_re[a][b] = (v4d)(0.0); acc_im[a][b] = (v4d)(0.0); acc_p2[a][b] = (v4d)(0.0); }
+        };
+        auto mac = [&](const cplx (&f)[4]) {
+            double asum[2], bsum[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { asum[a] = f[a].x + f[a].y; bsum[a] = f[2 + a].x + f[2 + a].y; }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].x, f[a].x, acc_re[a][b], 0, 0, 0);
+                    acc_p2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2 + b].y, f[a].y, acc_p2[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[b], asum[a], acc_im[a][b], 0, 0, 0);
+                }
+        };
+        zero();
+        unsigned chunk = 0, half_no = 0;          // chunks and hand-over halves so far
+        for (int u = skip(w); u < T; u = skip(u + W)) {
+            const int K8 = (sK[u / tiles] + 7) & ~7;
+            for (int kb = 0; kb < K8; kb += KH, ++chunk) {
+                const int kc = min(KH, K8 - kb);
+                const int buf = chunk % NBUF;
+                if (!WSWAIT(&flags[4 + buf], 2 * (chunk / NBUF + 1))) return;
+                const cplx* Xs = sm + buf * 2 * KH * 64;
+                const cplx* Gs = Xs + KH * 64;
+                auto loadf = [&](int kl, cplx (&f)[4]) {
+                    const cplx* xr = Xs + (kl + l4) * 64 + wi + l15;
+                    const cplx* gr = Gs + (kl + l4) * 64 + wj + l15;
+                    f[0] = xr[0]; f[1] = xr[16]; f[2] = gr[0]; f[3] = gr[16];
+                };
+                cplx s[4], t[4];
+                loadf(0, s);
+                for (int k0 = 0; k0 < kc; k0 += 8) {
+                    loadf(k0 + 4, t);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(s);
+                    __builtin_amdgcn_sched_barrier(0);
+                    loadf(min(k0 + 8, kc - 4), s);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(t);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) ws_flag_add(&flags[8 + buf]);               // this wave is done with the buffer
+            }
+            // hand the 32 x 32 block over in two halves (rows a 16 .. a 16 + 15): accb[wave][col][row & 15]
+            cplx* ab = accb + wave * 512;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (!WSWAIT(&flags[1], 4 * half_no)) return;      // the previous half has been taken by all four read-modify-write waves
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const v4d im = (acc_im[a][b] - acc_re[a][b]) - acc_p2[a][b];
+                    const v4d re = acc_re[a][b] - acc_p2[a][b];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ab[(b * 16 + 4 * r + l4) * 16 + l15] = make_double2(re[r], im[r]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) ws_flag_add(&flags[0]);
+                half_no += 1;
+            }
+            zero();
+        }
+    } else if (wave < 6) {
+        // ------------------------------------------------ panel loaders: wave 4 the X panel, wave 5 the GrT panel.  Register staged (16 plain loads of 1 KB
+        // in flight per chunk, then 16 LDS writes): a wave gets one LDS-DMA instruction out per ~ 330 cycles (phase timers of the first
+        // version: the two loader waves were busy 78 % of the time issuing 2048 of them), plain loads pipeline.  Two register sets: the
+        // loads of chunk q + 1 are in flight while chunk q waits for its LDS buffer and is written.
+        const int which = wave - 4;
+        unsigned chunk = 0;
+        int u = skip(w), kb = 0;                  // the chunk whose loads are issued next
+        auto chunk_src = [&](int uu, int kbb, int& kc) -> const cplx* {
+            const int q = uu / tiles, tile = uu - q * tiles;
+            const int K8 = (sK[q] + 7) & ~7;
+            kc = min(KH, K8 - kbb);
+            const size_t off = (size_t)(q * 8 + xcd) * cs;
+            return (which == 0 ? X0 + off + (tile % tn) * 64 : GrT0 + off + (tile / tn) * 64) + lane + (size_t)kbb * ld;
+        };
+        auto advance = [&]() { const int K8 = (sK[u / tiles] + 7) & ~7; kb += KH; if (kb >= K8) { kb = 0; u = skip(u + W); } };
+        double rAx[KH], rAy[KH], rBx[KH], rBy[KH];   // (arrays of double2 are not promoted to registers by this hipcc; arrays of double are)
+        int kcA = 0, kcB = 0;
+#define WS_ISSUE(r, kc) do { kc = 0; if (u < T) { const cplx* src_ = chunk_src(u, kb, kc); \
+            _Pragma("unroll") for (int kl = 0; kl < KH; ++kl) { const cplx t_ = src_[(size_t)min(kl, kc - 1) * ld]; r##x[kl] = t_.x; r##y[kl] = t_.y; } advance(); } } while (0)
+#define WS_COMMIT(r, kc) do { const int buf = chunk % NBUF; if (!WSWAIT(&flags[8 + buf], 4 * (chunk / NBUF))) return; \
+            cplx* dst_ = sm + buf * 2 * KH * 64 + which * KH * 64 + lane; \
+            _Pragma("unroll") for (int kl = 0; kl < KH; ++kl) dst_[min(kl, kc - 1) * 64] = make_double2(r##x[kl], r##y[kl]); \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) ws_flag_add(&flags[4 + buf]); chunk += 1; } while (0)
+        WS_ISSUE(rA, kcA);
+        while (kcA > 0) {
+            WS_ISSUE(rB, kcB);
+            WS_COMMIT(rA, kcA);
+            if (kcB == 0) break;
+            WS_ISSUE(rA, kcA);
+            WS_COMMIT(rB, kcB);
+        }
+#undef WS_ISSUE
+#undef WS_COMMIT
+    } else {
+        // ------------------------------------------------ read-modify-write of G: wave 6 + m owns columns 16 m .. 16 m + 15 of the tile, lane = row
+        const int mw = wave - 6;
+        unsigned half_no = 0;
+        for (int u = skip(w); u < T; u = skip(u + W)) {
+            const int q = u / tiles, tile = u - q * tiles;
+            cplx* base = G0 + (size_t)(q * 8 + xcd) * cs + (size_t)((tile / tn) * 64 + 16 * mw) * ldc + (tile % tn) * 64 + lane;
+            cplx c[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const cplx* p = base + (size_t)j * ldc; c[j].x = __builtin_nontemporal_load(&p->x); c[j].y = __builtin_nontemporal_load(&p->y); }
+            // column 16 mw + j of the tile, row = lane: compute wave (lane >> 5, (16 mw) >> 5), half (lane >> 4) & 1, row-in-half lane & 15
+            const cplx* ab = accb + (((lane >> 5) * 2 + ((16 * mw) >> 5)) * 512) + ((16 * mw) & 31) * 16 + (lane & 15);
+            cplx d[16];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (!WSWAIT(&flags[0], 4 * (half_no + 1))) return;
+                if (((lane >> 4) & 1) == a) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) d[j] = ab[j * 16];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) ws_flag_add(&flags[1]);
+                half_no += 1;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                cplx* p = base + (size_t)j * ldc;
+                __builtin_nontemporal_store(c[j].x + d[j].x, &p->x);
+                __builtin_nontemporal_store(c[j].y + d[j].y, &p->y);
+            }
+        }
+    }
+    if (tid == 0 && flags[2] != 0) atomicAdd(err, 1u);
+    if (lane == 0 && blockIdx.x < 32) { dbg[(blockIdx.x * 10 + wave) * 2] = twait; dbg[(blockIdx.x * 10 + wave) * 2 + 1] = __builtin_readcyclecounter() - tstart; }
+#undef WSWAIT
+}
+
 // var 6: persistent AND paced -- ONE workgroup per CU (one wave per SIMD, 128 KB of LDS: two buffers of 32 k); every vector-memory
 // instruction of a tile is issued from INSIDE the MFMA loop, a few per k-step pair: the LDS-DMA lines of the next chunk, the 16 loads of
 // this tile's G (needed only at the tile's end).  A wave issues in order: a burst of 16 + 16 + 16 memory instructions at a chunk boundary
@@ -1096,6 +1449,11 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k_flush_pipe<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_pipe_tim<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_pp<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_ws<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_flush_ws<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    unsigned* wserr; CK(hipMalloc(&wserr, 4)); CK(hipMemset(wserr, 0, 4));
+    CK(hipFuncSetAttribute((const void*)k_flush_wst<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    unsigned long long* wsdbg; CK(hipMalloc(&wsdbg, 32 * 10 * 2 * 8));
     CK(hipFuncSetAttribute((const void*)k_flush_pipe_abl<32, 1, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_pipe_abl<32, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CK(hipFuncSetAttribute((const void*)k_flush_pipe_abl<16, 2, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -1152,6 +1510,8 @@ int main(int argc, char** argv) {
             restore(); hipLaunchKernelGGL((k_flush_pipe<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe KH32 256 WG");
             restore(); hipLaunchKernelGGL((k_flush_pipe_asm<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe asm KH32 256 WG");
             restore(); hipLaunchKernelGGL((k_flush_pp<0>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("persistent paced");
+            restore(); hipLaunchKernelGGL((k_flush_ws<3>), dim3(256), dim3(640), 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb, wserr); check("warp-specialised 3 buffers");
+            { unsigned e = 0; CK(hipMemcpy(&e, wserr, 4, hipMemcpyDeviceToHost)); printf("  warp-specialised: %u workgroups timed out\n", e); }
             restore(); hipLaunchKernelGGL((k_flush_pipe_asm<16, 2>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe asm KH16 512 WG");
             restore(); hipLaunchKernelGGL((k_flush_pipe<16, 2>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("pipe KH16 512 WG");
             restore(); hipLaunchKernelGGL((k_flush_lds2<8, 2>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); check("lds2 KH8");
@@ -1173,6 +1533,17 @@ int main(int argc, char** argv) {
         rep("LDS panels KH 16, tile early, 2 WG/CU hint", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds<1, 16, 2>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("LDS 2 buffers KH 16, tile early, 2 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds2<16, 2>), grid, blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("LDS 2 buffers KH 8, tile early, 2 WG/CU", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_lds2<8, 2>), grid, blk, 32 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
+        rep("WARP-SPECIALISED 3 buffers x 16 k, 256 WG x 10 waves", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_ws<3>), dim3(256), dim3(640), 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb, wserr); }));
+        {
+            hipLaunchKernelGGL((k_flush_wst<3>), dim3(256), dim3(640), 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb, wserr, wsdbg);
+            unsigned long long h[32 * 10 * 2]; CK(hipMemcpy(h, wsdbg, sizeof(h), hipMemcpyDeviceToHost));
+            double wsum[10] = {0}, tsum[10] = {0};
+            for (int g = 0; g < 32; ++g) for (int wv = 0; wv < 10; ++wv) { wsum[wv] += (double)h[(g * 10 + wv) * 2] / 32; tsum[wv] += (double)h[(g * 10 + wv) * 2 + 1] / 32; }
+            printf("  warp-specialised, cycles per wave (mean of 32 workgroups) waiting for a flag / total:");
+            for (int wv = 0; wv < 10; ++wv) printf(" [%d] %.0fk/%.0fk", wv, wsum[wv] / 1e3, tsum[wv] / 1e3);
+            printf("\n");
+        }
+        rep("WARP-SPECIALISED 2 buffers x 16 k, 256 WG x 10 waves", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_ws<2>), dim3(256), dim3(640), 96 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb, wserr); }));
         rep("persistent PACED KH 32, 256 WG (1/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pp<0>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("persistent asm-DMA KH 32, 256 WG (1/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe_asm<32, 1>), dim3(256), blk, 128 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
         rep("persistent asm-DMA KH 16, 512 WG (2/CU)", timeit(B, B.a, B.b, [&] { hipLaunchKernelGGL((k_flush_pipe_asm<16, 2>), dim3(512), blk, 64 * 1024, 0, B.X, B.GrT, n, B.G, n, n, Kd, cs, nb); }));
