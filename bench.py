@@ -67,6 +67,8 @@ def select_config(name):
     WORKLOAD = dict(_COMMON, **CONFIGS[name]["workload"])
     if os.environ.get("DQMC_DELAY_STEPS"):
         WORKLOAD["delaySteps"] = int(os.environ["DQMC_DELAY_STEPS"])
+    if os.environ.get("DQMC_BENCH_PROPOSAL_BUDGET"):
+        WORKLOAD["proposalBudget"] = int(os.environ["DQMC_BENCH_PROPOSAL_BUDGET"])
     # production variant (reference example/simulation.job:27-44): a global shift move every 10 sweeps
     if os.environ.get("DQMC_BENCH_GLOBAL_SHIFT"):
         WORKLOAD.update(globalShift=True, globalUpdateInterval=int(os.environ["DQMC_BENCH_GLOBAL_SHIFT"]))
