@@ -24,7 +24,7 @@ class dqmc_cplx(C.Structure):
 
 class dqmc_tuning(C.Structure):
     _fields_ = [("pipeline", C.c_int32), ("qr_variant", C.c_int32), ("green_variant", C.c_int32),
-                ("max_jacobi_sweeps", C.c_int32), ("proposal_budget", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("max_jacobi_sweeps", C.c_int32), ("proposal_budget", C.c_int32), ("decide_threads", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class dqmc_schedule_info(C.Structure):

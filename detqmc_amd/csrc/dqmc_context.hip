@@ -494,6 +494,8 @@ extern "C" int dqmc_create_batch(const dqmc_params* p, int nchains, dqmc_ctx** o
     if (p->delaySteps < 1 || p->delaySteps > N) return fail(DQMC_EINVAL, "delaySteps must be in 1..N");
     if (MSF * p->delaySteps > DQMC_MAX_WDIM) return fail(DQMC_EINVAL, "MSF*delaySteps must be <= 64 on this build");
     if (p->bc < 0 || p->bc > 3) return fail(DQMC_EINVAL, "bc");
+    if (p->tuning.decide_threads != 0 && p->tuning.decide_threads != 256 && p->tuning.decide_threads != 512)
+        return fail(DQMC_EINVAL, "tuning.decide_threads must be 0, 256 or 512");
     if (p->stabilisation != DQMC_STAB_SVD && p->stabilisation != DQMC_STAB_QR) return fail(DQMC_EINVAL, "stabilisation");
     if (!(p->dtau > 0)) return fail(DQMC_EINVAL, "dtau");
     if (p->model != DQMC_MODEL_SDW && p->model != DQMC_MODEL_HUBBARD) return fail(DQMC_EINVAL, "model");
@@ -541,6 +543,7 @@ static int create_fill(dqmc_ctx* c, const dqmc_params* p) {
     hm.pbudget = p->delaySteps >= 8 ? 2 * p->delaySteps : 0;
     if (p->tuning.proposal_budget != 0) hm.pbudget = p->tuning.proposal_budget < 0 ? 0 : p->tuning.proposal_budget;
     if (hm.pbudget > 0 && hm.pbudget < p->delaySteps) hm.pbudget = p->delaySteps;
+    hm.decide_nt = p->tuning.decide_threads;
 #ifdef DQMC_DECIDE_TIMING
     hm.dbg = (getenv("DQMC_DECIDE_TIMING") && atoi(getenv("DQMC_DECIDE_TIMING"))) ? 8 : 0;   // phase timers of k_update_decide; never changes a result
 #endif

@@ -23,6 +23,7 @@ typedef double2 cplx;   // .x = re, .y = im; same bytes as dqmc_cplx / std::comp
 
 #define DQMC_MAX_MSF 4
 #define DQMC_MAX_WDIM 64          // MSF * delaySteps <= 64 (W lives in LDS in the decision kernel)
+#define DQMC_DECIDE_WIDE_MAX_CHAINS 32   // contexts of at most this many chains launch k_update_decide with 512 threads (kernels_update.hip)
 
 // ---- batched chains ---------------------------------------------------------------------------
 // One context can run nb independent Markov chains (replicas) in lockstep.  Every per-chain device buffer of
@@ -71,6 +72,7 @@ __device__ __forceinline__ void xcd_chain_tile(int tiles, int nb, int& chain, in
 struct DevModel {
     int opdim, MSF, L, N, ng, m, s, n, D, P;   // P = plaquettes per subgroup = N/4
     int phi2bosons;
+    int decide_nt;     // threads per workgroup of k_update_decide: 0 automatic, 256, 512 (dqmc_tuning::decide_threads)
     int pbudget;       // proposals per delayed-update block (0: no limit); a launch-balancing knob, the chain does not depend on it
     int dbg;           // bit 3: phase timers of k_update_decide; only ever set in builds with -DDQMC_DECIDE_TIMING (always 0 otherwise)
     int dense;         // CB_NONE: the hopping part is a dense GEMM done by the host loop, the chain kernel

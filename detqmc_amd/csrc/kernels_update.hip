@@ -202,13 +202,25 @@ __device__ __forceinline__ void rot3_unit(const double (&v)[3], double ct, doubl
 // The uniforms of such a proposal come from a window of UNIW values that starts at the cursor the candidate's prefetch was issued
 // with (exact: the decision before it is still open, but a window is long enough for both outcomes); beyond it: direct loads.
 // adapt_what (thermalisation, end of the slice): 0 ADAPT_BOX, 1 ADAPT_ROTATE, 2 ADAPT_SCALE (+ 4: adaptScaleVariance), :3299-3375.
-template<int OPDIM, int CDW, int PROP>
-__global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
+// NT threads per workgroup: 256, or 512 (O(1) / O(2); O(3) needs 256 registers per thread) with the waves specialised -- a wave of its own
+// for the look-ahead loads, six for the p / q products and the rows of W.  512 is the faster kernel for a chain (single chain 6.8 -> 7.25
+// sweeps/s, the decision launches of 128 chains alone on the GPU -13 %), but its 8 waves and 380 registers per SIMD push the other contexts'
+// flush / GEMM waves off the CU: four contexts of 128 chains run 1.7 % SLOWER with it (same-box A/B, profiles/r04_decide_512.json).  The
+// launcher therefore takes 512 for small batches only.
+template<int OPDIM, int CDW, int PROP, int NT>
+__global__ __launch_bounds__(NT) void k_update_decide(DevModel dm, DevUpdateState* us, const double* __restrict__ uni,
                                                        const cplx* __restrict__ Gfull, cplx* __restrict__ Wout,
                                                        int k, int first, int thermal, size_t cs,
                                                        const cplx* __restrict__ Gwin, int winP, int adapt_what, int reset_nd) {
     static_assert(PROP == 0 || (OPDIM == 3 && CDW != 2), "rotate / scale proposals belong to the phi pass of the O(3) model");
     constexpr int MSF = (OPDIM == 3) ? 4 : 2;
+    static_assert(NT == 256 || (NT == 512 && OPDIM != 3), "launch shape");
+    constexpr int NW = NT / 64;
+    // Roles of the waves.  Wave 0: the scalar Metropolis arithmetic of a proposal (D), the border strips of W.  FETCH_WAVE: the loads of the
+    // next candidate and their hand-over through LDS (A, C) -- with eight waves a wave of its own, which does this while the others
+    // update W, with four waves wave 0.  Waves E_FIRST .. NW - 1: p = W v, q = u W (E) and the rows of W11.
+    constexpr int FETCH_WAVE = (NW >= 8) ? 1 : 0, E_FIRST = FETCH_WAVE + 1, NWE = NW - E_FIRST;
+    constexpr int U_FIRST = (NW >= 8) ? E_FIRST : 0, NWU = NW - U_FIRST;      // the waves that walk the rows of W11 (four waves: all of them)
     constexpr int SLOTS = MSF * DQMC_MAX_WDIM / 64;
     constexpr int NPROP = (CDW == 2) ? 1 : OPDIM;      // uniforms a BOX proposal draws
     constexpr int UNIW = 16;                           // PROP != 0: prefetched window of uniforms
@@ -226,8 +238,9 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     double* sphi = (double*)(sq + MSF * WD);   // phi of slice k, [OPDIM][N]: all field reads and writes of the loop
     __shared__ int isite[DQMC_MAX_WDIM];       //   go here, the accepted values reach global memory after the loop
     __shared__ double sacc[DQMC_MAX_WDIM][OPDIM + 2 > 3 ? OPDIM + 2 : 3];   // accepted: new phi, cosh, sinh (CDW 2: l, its cosh, sinh)
-    const int tid = threadIdx.x;          // 4 waves: scalar Metropolis arithmetic is done redundantly by every
-    const int lane = tid & 63;            // wave, the vector parts (p, q, W update) are split over all 256 threads
+    const int tid = threadIdx.x;          // the decision (S, det, accept) is formed redundantly by every wave,
+    const int lane = tid & 63;            // the vector parts (p, q, W update) are split over the waves
+    const int wave = tid >> 6;
     const int L = dm.L;
 
     int site = first ? 0 : us->site_cursor;
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     static_assert(O_GCC % 2 == 0, "complex items must be 16-byte aligned in LDS");
     __shared__ __attribute__((aligned(16))) double scand[NIT * 64];
     __shared__ __attribute__((aligned(16))) double sdec[4 * MSF * MSF + 4];   // wave 0 -> all: delta, G[c,c], exp(-dS), uniform, (CDW 2: null-proposal flag)
-    __shared__ cplx salg[MSF == 4 ? 4 * 80 : 1];                              // O(3): wave-private scratch of the 4 x 4 algebra (S, M', cofactors, M'^-1, F)
+    __shared__ cplx salg[MSF == 4 ? NW * 80 : 1];                              // O(3): wave-private scratch of the 4 x 4 algebra (S, M', cofactors, M'^-1, F)
 
     auto neighbours = [&](int s, int (&nbr)[4]) {
         // neighbortable.h:34-36 (XPLUS, XMINUS, YPLUS, YMINUS), computed: a table look-up would put a dependent
@@ -288,10 +301,10 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     // `curGuess` = RNG cursor if that decision consumes no acceptance uniform, nIknown = MSF * (#accepted so far)
     auto fetch = [&](double (&pre)[NIT], cplx (&pu)[SLOTS], cplx (&pv)[SLOTS], int s, int prev,
                      unsigned long long curGuess, int nIknown) {
-        if (tid >= 64) return;
+        if (wave != FETCH_WAVE) return;
 #pragma unroll
         for (int q = 0; q < NIT; ++q) {
-            const int item = tid + 64 * q;
+            const int item = lane + 64 * q;
             const double* addr = nullptr;
             double dflt = 0.0;
             if (item < O_TL) {
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         }
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
-            const int t = tid + 64 * q;                   // (i, a): entry u[a][i] = G[c_a, I_i] and v[i][a] = G[I_i, c_a]
+            const int t = lane + 64 * q;                  // (i, a): entry u[a][i] = G[c_a, I_i] and v[i][a] = G[I_i, c_a]
             if (t < MSF * nIknown) {
                 const int a = t % MSF, i = t / MSF;
                 const int Ii = isite[i / MSF] - goff + (i % MSF) * gNB, sa = s - goff + a * gNB;
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
     fetch(pre, pu, pv, site, -1, cur, 0);
     // No global store happens inside the loop: a store followed by a load that may alias makes the compiler wait
     // for the store's round trip (s_waitcnt vmcnt(0)) before every prefetch.  The slice's field lives in LDS.
-    for (int t = tid; t < OPDIM * N; t += 256) sphi[t] = phik[t];
+    for (int t = tid; t < OPDIM * N; t += NT) sphi[t] = phik[t];
     int cnd_nI = 0;                                // nI the u/v registers were loaded for
     [[maybe_unused]] unsigned long long win_cur = cur;      // PROP != 0: cursor the current candidate's window of uniforms starts at
     // PROP 2 / 3: the Box-Muller stack of NormalDistribution (normaldistribution.h:44-78) -- after a pair has been generated its first
@@ -378,12 +391,12 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         // ---- A (wave 0): land the prefetched scalars and u / v in LDS; patch in what the previous decision
         //      changed.  The u/v buffers alternate, so threads still reading the previous proposal's u are not
         //      overtaken; scand is read right after barrier 1 and rewritten only after barrier 2. ----
-        if (tid < 64) {
+        if (wave == FETCH_WAVE) {
 #pragma unroll
-            for (int q = 0; q < NIT; ++q) scand[tid + 64 * q] = pre[q];
+            for (int q = 0; q < NIT; ++q) scand[lane + 64 * q] = pre[q];
 #pragma unroll
             for (int q = 0; q < SLOTS; ++q) {
-                const int t = tid + 64 * q;
+                const int t = lane + 64 * q;
                 if (t < MSF * cnd_nI) {
                     const int a = t % MSF, i = t / MSF;
                     su[a * WD + i] = pu[q];
@@ -392,13 +405,13 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             }
             // the site accepted last time joined I after the fetch: its u / v entries are G[c, prev], G[prev, c],
             // which sit in the lanes O_GNP.. / O_GPN.. of `pre`
-            const int e = (tid < MSF * MSF) ? tid : 0;
+            const int e = (lane < MSF * MSF) ? lane : 0;
             constexpr int QN = O_GNP / 64, QP = O_GPN / 64;
             static_assert((O_GNP + 2 * MSF * MSF - 1) / 64 == QN && (O_GPN + 2 * MSF * MSF - 1) / 64 == QP, "item block straddles a lane group");
             cplx gnp = make_double2(__shfl(pre[QN], (O_GNP + 2 * e) & 63, 64), __shfl(pre[QN], (O_GNP + 2 * e + 1) & 63, 64));
             cplx gpn = make_double2(__shfl(pre[QP], (O_GPN + 2 * e) & 63, 64), __shfl(pre[QP], (O_GPN + 2 * e + 1) & 63, 64));
-            if (prev_acc && tid < MSF * MSF) {
-                const int a = tid / MSF, b = tid % MSF;
+            if (prev_acc && lane < MSF * MSF) {
+                const int a = lane / MSF, b = lane % MSF;
                 su[a * WD + (nI - MSF + b)] = gnp;          // u[a][i] = G[c_a, I_i], I_i = prev + b N
                 sv[(nI - MSF + a) * MSF + b] = gpn;         // v[i][b] = G[I_i, c_b], I_i = prev + a N
             }
@@ -423,13 +436,13 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
         if constexpr (PROP == 0) cur += NPROP;             // (PROP != 0: the count comes back from wave 0 behind barrier 2)
         double lnew = 0.0, cCn = 1.0, sCn = 0.0;          // CDW 2: the proposed l and its cosh / sinh terms
         TICK(2);
-        if (tid >= 64) {
+        if (wave >= E_FIRST) {
             // ---- E: p = W v and, speculatively (needed only on acceptance), q = u W.  Work item = one ROW of p (all MSF entries
             //      from one pass over row i of W) or one COLUMN of q, split over a quad of lanes; items [0, nI) are p(i, :), items
             //      [nI, 2 nI) are q(:, i).  Two independent accumulator sets per lane (even / odd trips) keep two rounds of LDS reads
             //      in flight: the dependent fma chain of a single accumulator left the LDS latency of every trip exposed. ----
             const int nitems = 2 * nI;
-            for (int t = tid - 64; t < 4 * nitems; t += 192) {
+            for (int t = tid - 64 * E_FIRST; t < 4 * nitems; t += 64 * NWE) {
                 const int item = t >> 2, part = t & 3;
                 cplx acc0[MSF], acc1[MSF];
 #pragma unroll
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                     if (part == 0) { if (isp) sp[i * MSF + b] = acc; else sq[b * WD + i] = acc; }
                 }
             }
-        } else {
+        } else if (wave == 0) {
             // ---- D (wave 0): the candidate's scalars (broadcast LDS reads), bosonic action (deltaSPhi, :4186-4239)
             //      and delta (get_delta_forsite, :3179-3289) ----
             int nbr[4];
@@ -808,18 +821,18 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
             }
             // block bordering of W straight from p and q in LDS (pF is formed on the fly: no staging, no barrier):
             //   W11 += (p F) q ;  W12 = p F ;  W21 = F q ;  W22 = F
-            // A lane owns column i2 of W11 (its q entries stay in registers), a wave walks the rows i = wave, wave + 4, ...: no
+            // A lane owns column i2 of W11 (its q entries stay in registers), a wave walks the rows i = w, w + NWU, ...: no
             // integer division by nI, the row's p entries are broadcast reads, four rows in flight per trip.
-            if (lane < nI) {
+            if (wave >= U_FIRST && lane < nI) {
                 cplx qc[MSF];
 #pragma unroll
                 for (int b = 0; b < MSF; ++b) qc[b] = sq[b * WD + lane];
-                const int wv = tid >> 6;
-                for (int i = wv; i < nI; i += 16) {
+                const int wv = wave - U_FIRST;
+                for (int i = wv; i < nI; i += 4 * NWU) {
                     cplx wold[4], pf[4][MSF];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int ir = min(i + 4 * r, nI - 1);
+                        const int ir = min(i + NWU * r, nI - 1);
                         wold[r] = W[ir * WS + lane];
                         cplx pi[MSF];
 #pragma unroll
@@ -837,11 +850,11 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
                         cplx acc = wold[r];
 #pragma unroll
                         for (int b = 0; b < MSF; ++b) acc = u_cfma(pf[r][b], qc[b], acc);
-                        if (i + 4 * r < nI) W[(i + 4 * r) * WS + lane] = acc;
+                        if (i + NWU * r < nI) W[(i + NWU * r) * WS + lane] = acc;
                     }
                 }
             }
-            for (int i = tid; i < nI; i += 256) {
+            for (int i = tid; i < nI; i += 64 * NW) {          // nI <= 64: wave 0
                 cplx pi[MSF];
 #pragma unroll
                 for (int q = 0; q < MSF; ++q) pi[q] = sp[i * MSF + q];
@@ -895,7 +908,7 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
 
     // ---- publish block result ----
     const int nI = MSF * j;
-    for (int t = tid; t < nI * nI; t += 256) {
+    for (int t = tid; t < nI * nI; t += NT) {
         int i = t / nI, i2 = t - i * nI;
         Wout[(size_t)i2 * WD + i] = W[i * WS + i2];        // column-major, ld = WD
     }
@@ -968,6 +981,11 @@ __global__ __launch_bounds__(256) void k_update_decide(DevModel dm, DevUpdateSta
 #undef TICK
 }
 
+template<int O, int C, int P> static const void* decide_kernel(bool wide) {
+    if constexpr (O != 3) { if (wide) return (const void*)k_update_decide<O, C, P, 512>; }
+    return (const void*)k_update_decide<O, C, P, 256>;
+}
+
 void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevModel& hm, DevUpdateState* us,
                           const double* uniforms, const cplx* G, cplx* W, int k, int first, int thermal, int cdw_pass,
                           const cplx* Gwin, int winP, int proposal, int adapt_what, int reset_nd) {
@@ -977,7 +995,10 @@ void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevMod
     const int prop = (cdw == 2) ? 0 : proposal;                  // the cdwl pass has its own one-uniform proposal
     const void* f = nullptr;
     int slot = -1;
-#define DECIDE_CASE(O, C, P) if (hm.opdim == O && cdw == C && prop == P) { f = (const void*)k_update_decide<O, C, P>; slot = ((O - 1) * 3 + C) * 4 + P; }
+    // small batches leave most of the chip idle: the 512-thread shape (see k_update_decide) is the faster one there
+    const bool wide = hm.opdim != 3 && (hm.decide_nt == 512 || (hm.decide_nt == 0 && lc.nb <= DQMC_DECIDE_WIDE_MAX_CHAINS));
+#define DECIDE_CASE(O, C, P) if (hm.opdim == O && cdw == C && prop == P) { \
+        f = decide_kernel<O, C, P>(wide); slot = wide ? 36 + (O - 1) * 3 + C : ((O - 1) * 3 + C) * 4 + P; }
     DECIDE_CASE(1, 0, 0) DECIDE_CASE(1, 1, 0) DECIDE_CASE(1, 2, 0) DECIDE_CASE(2, 0, 0) DECIDE_CASE(2, 1, 0) DECIDE_CASE(2, 2, 0)
     DECIDE_CASE(3, 0, 0) DECIDE_CASE(3, 1, 0) DECIDE_CASE(3, 2, 0)
     DECIDE_CASE(3, 0, 1) DECIDE_CASE(3, 0, 2) DECIDE_CASE(3, 0, 3) DECIDE_CASE(3, 1, 1) DECIDE_CASE(3, 1, 2) DECIDE_CASE(3, 1, 3)
@@ -986,7 +1007,7 @@ void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevMod
     if (lds > 48 * 1024) {     // deep delay blocks: raise the dynamic LDS limit of the instantiation to what is needed
         // the attribute belongs to (function, device); several contexts / host threads may get here at once
         static std::mutex mu;
-        static size_t raised_tab[64][36] = {};
+        static size_t raised_tab[64][42] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> lk(mu);
@@ -998,7 +1019,7 @@ void launch_update_decide(const Launch& lc, const DevModel* /*dm*/, const DevMod
     }
     void* args[] = {(void*)&hm, (void*)&us, (void*)&uniforms, (void*)&G, (void*)&W, (void*)&k, (void*)&first, (void*)&thermal, (void*)&lc.cs,
                     (void*)&Gwin, (void*)&winP, (void*)&adapt_what, (void*)&reset_nd};
-    (void)hipLaunchKernel(f, dim3(1, 1, lc.nb), dim3(256), args, lds, lc.st);
+    (void)hipLaunchKernel(f, dim3(1, 1, lc.nb), dim3(slot >= 36 ? 512 : 256), args, lds, lc.st);
 }
 
 // X[:, i'] = sum_i G[:, I_i] W[i, i']   (n_g x nI8, ld n_g);   GrT[:, i] = (G[I_i, :] - E)^T   (n_g x nI8, ld n_g)

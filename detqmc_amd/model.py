@@ -71,6 +71,7 @@ class SDWParams:
     greenVariant: int = 0        # 1: QR instead of LU inside greenFromUdV
     maxJacobiSweeps: int = 0     # SVD mode: sweep budget of the Jacobi SVD (0 = 80)
     proposalBudget: int = 0      # proposals per delayed-update block (-1: no limit)
+    decideThreads: int = 0       # threads per workgroup of the decision kernel (0: automatic, 256, 512); launch shape only
 
 
 SPIN_PROPOSAL = {"box": 0, "rotate_then_scale": 1, "rotate_and_scale": 2}
@@ -78,9 +79,10 @@ PROPOSE = {"box": 0, "rotate": 1, "scale": 2, "rotate_and_scale": 3}
 ADAPT = {"box": 0, "rotate": 1, "scale": 2}
 
 
-def _tuning(pipeline=0, qrVariant=0, greenVariant=0, maxJacobiSweeps=0, proposalBudget=0):
+def _tuning(pipeline=0, qrVariant=0, greenVariant=0, maxJacobiSweeps=0, proposalBudget=0, decideThreads=0):
     return _lib.dqmc_tuning(pipeline=int(pipeline), qr_variant=int(qrVariant), green_variant=int(greenVariant),
-                            max_jacobi_sweeps=int(maxJacobiSweeps), proposal_budget=int(proposalBudget))
+                            max_jacobi_sweeps=int(maxJacobiSweeps), proposal_budget=int(proposalBudget),
+                            decide_threads=int(decideThreads))
 
 
 def _fmat(a):
@@ -94,13 +96,13 @@ class KernelContext:
     def __init__(self, opdim, L, m, s, dtau, delaySteps=16, bc="pbc", weakZflux=False, r=-1.0, c=3.0, u=1.0,
                  lambda_=1.0, txhor=-1.0, txver=-0.5, tyhor=0.5, tyver=1.0, mux=-0.5, muy=-0.5,
                  accRatio=0.5, phi2bosons=False, device=0, stabilisation="svd", checkerboard=True, nchains=1, cdwU=0.0,
-                 pipeline=0, qrVariant=0, greenVariant=0, maxJacobiSweeps=0, proposalBudget=0, rngWindowPerSite=0):
+                 pipeline=0, qrVariant=0, greenVariant=0, maxJacobiSweeps=0, proposalBudget=0, rngWindowPerSite=0, decideThreads=0):
         self.lib = load()
         p = _lib.dqmc_params(opdim=opdim, L=L, m=m, s=s, delaySteps=delaySteps, bc=BC[bc],
                              weakZflux=int(weakZflux), phi2bosons=int(phi2bosons), device=device,
                              stabilisation=STABILISATION[stabilisation], cb_none=int(not checkerboard), dtau=dtau, r=r, c=c, u=u, lambda_=lambda_, txhor=txhor, txver=txver,
                              tyhor=tyhor, tyver=tyver, mux=mux, muy=muy, accRatio=accRatio, cdwU=cdwU, rng_window_per_site=int(rngWindowPerSite),
-                             tuning=_tuning(pipeline, qrVariant, greenVariant, maxJacobiSweeps, proposalBudget))
+                             tuning=_tuning(pipeline, qrVariant, greenVariant, maxJacobiSweeps, proposalBudget, decideThreads))
         h = C.c_void_p()
         check(self.lib.dqmc_create_batch(C.byref(p), nchains, C.byref(h)))
         self.h = h
@@ -344,7 +346,7 @@ def _host_params(pars: SDWParams):
         repeatWolffPerSweep=int(pars.repeatWolffPerSweep), fermionMeasurements=int(pars.fermionMeasurements),
         spinProposalMethod=SPIN_PROPOSAL[pars.spinProposalMethod], adaptScaleVariance=int(pars.adaptScaleVariance),
         repeatUpdateInSlice=int(pars.repeatUpdateInSlice),
-        tuning=_tuning(pars.pipeline, pars.qrVariant, pars.greenVariant, pars.maxJacobiSweeps, pars.proposalBudget))
+        tuning=_tuning(pars.pipeline, pars.qrVariant, pars.greenVariant, pars.maxJacobiSweeps, pars.proposalBudget, pars.decideThreads))
 
 
 class DetSDW:

@@ -66,7 +66,9 @@ typedef struct dqmc_tuning {
                                   ("SVD failed", udv.h:77-88) */
     int32_t proposal_budget;   /* proposals per delayed-update block: 0 automatic (2 delaySteps for delaySteps >= 8), -1 no
                                   limit, > 0 that many (at least delaySteps) */
-    int32_t reserved[3];
+    int32_t decide_threads;    /* threads per workgroup of the decision kernel: 0 automatic (512 for O(1) / O(2) contexts of at most 32
+                                  chains, else 256), 256, 512 (O(3): always 256).  Launch shape only: the chain does not depend on it */
+    int32_t reserved[2];
 } dqmc_tuning;
 
 /* ModelParamsDetSDW fields the kernels depend on (src/detsdwparams.h:24-120) */

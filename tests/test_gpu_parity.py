@@ -216,11 +216,15 @@ def test_wrap_advance_without_updates_vs_oracle(name):
 # ------------------------------------------------------------------------------------------------
 # local updates of one slice (a17-a20)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("threads", [256, 512])
 @pytest.mark.parametrize("name", SMALL + ["o2_L8_b5"] + L8)
-def test_update_slice_vs_reference(name):
+def test_update_slice_vs_reference(name, threads):
+    """threads: both launch shapes of the decision kernel (dqmc_tuning::decide_threads; O(3) has the 256-thread shape only)"""
     from dsfmt_oracle import RngWrapper
     g = load_golden(name)
-    ctx, op = _ctx_from_params(g["params"])
+    if threads == 512 and oracle_params(g["params"]).opdim == 3:
+        pytest.skip("O(3): one launch shape")
+    ctx, op = _ctx_from_params(g["params"], decideThreads=threads)
     phi0 = _golden_phi(g, "init_phi")
     ctx.set_fields(phi0)
     ctx.setupUdVStorage_and_calculateGreen()
@@ -608,13 +612,15 @@ def test_qr_mode_replica_trajectory_vs_reference(name):
     rep.close()
 
 
+@pytest.mark.parametrize("threads", [256, 512])
 @pytest.mark.parametrize("delaySteps", [16, 32])
-def test_qr_mode_headline_size_vs_reference_checksums(delaySteps):
+def test_qr_mode_headline_size_vs_reference_checksums(delaySteps, threads):
     """delaySteps = 32 (bench.py's setting) against the fixture the reference produced with 16: the depth of the
-    delayed-update blocks is a performance knob, the Markov chain does not depend on it."""
+    delayed-update blocks is a performance knob, the Markov chain does not depend on it -- nor on the launch shape of the
+    decision kernel (256 threads: what a context of 128 chains runs; 512: what a single chain runs)."""
     from detqmc_amd import DetSDW
     g = load_golden("o2_L16_b10")
-    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr", delaySteps=delaySteps))
+    rep = DetSDW(_sdw_params(g["params"], stabilisation="qr", delaySteps=delaySteps, decideThreads=threads))
     G = rep.g
     assert relerr(G[::16, ::16], g["init_g_sub16"]) < TOL
     assert relerr(np.diag(G), g["init_g_diag"]) < TOL
