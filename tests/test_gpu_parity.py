@@ -1636,4 +1636,4 @@ def test_environment_cannot_change_the_markov_chain():
                         "-k", "test_update_slice_vs_reference and (o2_L8_b5 or o3_L4 or o2_L4_flux)"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "3 passed" in r.stdout, r.stdout[-1000:]
+    assert "5 passed, 1 skipped" in r.stdout, r.stdout[-1000:]      # three fixtures x two launch shapes, O(3) has one shape
