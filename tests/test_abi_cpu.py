@@ -75,6 +75,10 @@ def test_fails_loudly_without_gpu_or_with_bad_parameters(lib):
         assert e.value.code == -5          # DQMC_ENODEV: no silent CPU path
         with pytest.raises(DqmcError):
             detqmc_amd.KernelContext(2, 4, 20, 10, 0.1)
+    # execution choices are validated like model parameters (dqmc_tuning, include/dqmc_hip.h)
+    with pytest.raises(DqmcError) as e:
+        detqmc_amd.KernelContext(2, 4, 20, 10, 0.1, decideThreads=384)
+    assert e.value.code == -1 and "decide_threads" in str(e.value)
 
 
 def test_product_does_not_import_the_oracle():
