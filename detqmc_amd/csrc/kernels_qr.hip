@@ -877,58 +877,106 @@ int run_trsm_right_upper(const Launch& lc, int n, const cplx* R, cplx* C, const 
 #define CHOL_PIVOT_TOL 1e-12
 // Cholesky factor of the nb x nb Hermitian block at (j0, j0) of Gm (upper triangle read), R upper with R^H R = G written back in
 // place (strict lower part zeroed).  If R1m != nullptr its block at (j0, j0) is replaced by R R1 (second CholQR pass: R_jj = R2 R1).
-// One workgroup of four waves per chain, the block in LDS: thread (j, q) owns the rows i = q (mod 4) of column j; a step reads the
-// UNSCALED pivot row (broadcast reads, scaled on the fly), updates the trailing columns and scales row K in place afterwards --
-// nobody reads row K again -- so a step costs ONE barrier.  (Versions with one wave per block: 195 us with the block in LDS and
-// dependent read-modify-write chains, 174 us with the columns in 512 registers; this one: see profiles/.)
-__global__ __launch_bounds__(256) void k_chol64(cplx* __restrict__ Gm, int ld, int j0, int nb, cplx* __restrict__ R1m, int* __restrict__ err, size_t cs) {
+// One workgroup of SIXTEEN waves per chain.  Thread (j, q) owns the rows i = q (mod 16) of column j and keeps them in REGISTERS for the
+// whole factorisation; the only thing that travels through LDS is the pivot row: the wave that owns row K + 1 publishes it (unscaled, up
+// to date) while it applies step K, into the buffer the other parity is not reading -- a step costs ONE barrier, one LDS write and six
+// independent LDS reads, and at most four element updates per thread.
+// Round 3 (four waves, the block in LDS, 84 us per launch = 12 % of a single O(3) L = 24 chain's sweep): the 64 steps were bound by the
+// ~ 450 instructions a wave issued per step; the prologue waited for every global load of R1 on its own (load, s_waitcnt vmcnt(0),
+// ds_write, sixteen times); the product R2 R1 of the second pass ran a dependent chain of LDS reads per element.  Now: all loads of
+// the prologue in flight together, the product as a loop over t with broadcast reads of R2's column t (same summation order).
+// Arithmetic per element is unchanged except 1 / sqrt(pivot): one rsqrt sequence instead of a square root followed by a division.
+#define CHOL_NQ 16
+__global__ __launch_bounds__(64 * CHOL_NQ) void k_chol64(cplx* __restrict__ Gm, int ld, int j0, int nb, cplx* __restrict__ R1m, int* __restrict__ err, size_t cs) {
     __shared__ cplx s[BGS_NB][BGS_NB + 1];
     __shared__ cplx s1[BGS_NB][BGS_NB + 1];
+    __shared__ cplx prow[2][BGS_NB];
     CHAIN(Gm); CHAIN(R1m); CHAIN(err);
-    const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (int i = q; i < BGS_NB; i += 4) {
+    const int j = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // q in a scalar register: the row tests below are scalar branches
+    constexpr int NS = BGS_NB / CHOL_NQ;           // rows per thread
+    cplx a[NS], r1[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int i = CHOL_NQ * t + q;
         const bool in = j < nb && i <= j;
-        s[i][j] = in ? Gm[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
-        if (R1m) s1[i][j] = in ? R1m[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
+        a[t] = in ? Gm[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
+        r1[t] = (in && R1m) ? R1m[(size_t)(j0 + j) * ld + (j0 + i)] : make_double2(0.0, 0.0);
     }
-    __syncthreads();
+    if (R1m) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s1[CHOL_NQ * t + q][j] = r1[t];
+    }
+    if (q == 0) prow[0][j] = a[0];                  // row 0
     // Pivot test: the K-th pivot is the squared distance of column K from the span of the columns before it; relative to the
     // column's own squared norm it is >= 1 / kappa^2 of the column-equilibrated panel.  Below CHOL_PIVOT_TOL (kappa > 10^6) the
     // re-orthogonalising second pass can no longer be trusted to restore orthogonality to rounding (CholQR2 needs kappa^2 eps << 1):
     // the panel is flagged -- also when the pivot is not positive at all -- and the host redoes the factorisation with Householder
     // panels (udt_dev / green_qr, dqmc_context.hip).  Never papered over: the flag is per chain and counted (dqmc_get_schedule_info).
-    const double g_orig = (j < nb) ? s[j][j].x : 1.0;          // the thread of column j keeps its own diagonal entry (rows q == j mod 4 ... every q holds it)
+    double g_orig = 1.0;                            // the diagonal entry of column j as it came in (held by the thread with q == j mod 16)
+#pragma unroll
+    for (int t = 0; t < NS; ++t) if (CHOL_NQ * t + q == j && j < nb) g_orig = a[t].x;
     for (int K = 0; K < nb; ++K) {
-        if (threadIdx.x == K && err && !(s[K][K].x > CHOL_PIVOT_TOL * g_orig)) *err = 1;
-        const double d = sqrt(fmax(s[K][K].x, 1e-300)), id = 1.0 / d;
-        if (j > K && j < nb) {
-            const cplx rkj = make_double2(s[K][j].x * id, s[K][j].y * id);
-            int i = K + 1 + ((q - (K + 1)) & 3);                         // first row > K that belongs to this thread
-            for (; i <= j; i += 4) {
-                const cplx rki = make_double2(s[K][i].x * id, s[K][i].y * id);
-                cplx g = s[i][j];
-                g.x -= rki.x * rkj.x + rki.y * rkj.y;                   // conj(r_Ki) r_Kj
-                g.y -= rki.x * rkj.y - rki.y * rkj.x;
-                s[i][j] = g;
+        __syncthreads();                            // pivot row K is complete in prow[K & 1]; nobody still reads prow[(K + 1) & 1]
+        const cplx* pr = prow[K & 1];
+        // all LDS reads of the step first (the rows are wave-uniform addresses: broadcasts) -- interleaved with the publish below the
+        // compiler must assume that the write aliases the reads and waits for every read on its own
+        cplx pi[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) pi[t] = pr[CHOL_NQ * t + q];
+        const cplx pj = pr[j];
+        const double dkk = pr[K].x;
+        if (j == K && (K & (CHOL_NQ - 1)) == q && err && !(dkk > CHOL_PIVOT_TOL * g_orig)) *err = 1;
+        // 1 / sqrt in ONE sequence (the step's longest dependent chain); d = dkk / sqrt(dkk)
+        const double dk = fmax(dkk, 1e-300), id = rsqrt(dk), d = dk * id;
+        const cplx rkj = make_double2(pj.x * id, pj.y * id);
+        cplx pub = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int i = CHOL_NQ * t + q;          // scalar
+            if (i > K) {
+                if (i <= j && j < nb) {
+                    const cplx rki = make_double2(pi[t].x * id, pi[t].y * id);
+                    a[t].x -= rki.x * rkj.x + rki.y * rkj.y;                   // conj(r_Ki) r_Kj
+                    a[t].y -= rki.x * rkj.y - rki.y * rkj.x;
+                }
+                if (i == K + 1) pub = a[t];         // the next pivot row, up to date
+            } else if (i == K) {
+                if (j >= K && j < nb) a[t] = (j == K) ? make_double2(d, 0.0) : rkj;    // row K of R
             }
         }
-        __syncthreads();                                                 // the pivot row has been read by everybody, row K + 1 is final
-        if (q == 0 && j >= K && j < nb) s[K][j] = (j == K) ? make_double2(d, 0.0) : make_double2(s[K][j].x * id, s[K][j].y * id);
+        if (((K + 1) & (CHOL_NQ - 1)) == q) prow[(K + 1) & 1][j] = pub;
     }
     __syncthreads();
-    if (j < nb) {
-        for (int i = q; i < nb; i += 4) Gm[(size_t)(j0 + j) * ld + (j0 + i)] = (i <= j) ? s[i][j] : make_double2(0.0, 0.0);
-        if (R1m) {
-            for (int i = q; i <= j; i += 4) {                        // (R2 R1)[i][j] = sum_{t = i .. j} R2[i][t] R1[t][j]
-                cplx acc = make_double2(0.0, 0.0);
-                for (int t = i; t <= j; ++t) {
-                    const cplx a = s[i][t], b = s1[t][j];
-                    acc.x += a.x * b.x - a.y * b.y;
-                    acc.y += a.x * b.y + a.y * b.x;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int i = CHOL_NQ * t + q;
+        s[i][j] = a[t];
+        if (j < nb && i < nb) Gm[(size_t)(j0 + j) * ld + (j0 + i)] = (i <= j) ? a[t] : make_double2(0.0, 0.0);
+    }
+    if (!R1m) return;
+    __syncthreads();
+    // (R2 R1)[i][j] = sum_{t = i .. j} R2[i][t] R1[t][j], t ascending: one pass over t, R1[t][j] read once per t, R2[i][t] broadcast
+    cplx acc[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) acc[u] = make_double2(0.0, 0.0);
+    for (int t = 0; t < nb; ++t) {
+        const cplx b = s1[t][j];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int i = CHOL_NQ * u + q;          // scalar
+            if (i <= t) {
+                const cplx x = s[i][t];
+                if (t <= j) {
+                    acc[u].x += x.x * b.x - x.y * b.y;
+                    acc[u].y += x.x * b.y + x.y * b.x;
                 }
-                R1m[(size_t)(j0 + j) * ld + (j0 + i)] = acc;
             }
         }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int i = CHOL_NQ * u + q;
+        if (j < nb && i <= j) R1m[(size_t)(j0 + j) * ld + (j0 + i)] = acc[u];
     }
 }
 // C[0:rows, 0:cols] += D[0:rows, 0:cols] (both with leading dimension ld)
@@ -985,10 +1033,10 @@ int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
             ++launches;
         }
         gemm(1, Qj, 0, Qj, Rj + j0, b, b, n, 0);                     // G = A_j^H A_j into R's diagonal block
-        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(256), 0, lc.st, A, n, j0, b, (cplx*)nullptr, w.err, lc.cs);
+        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(64 * CHOL_NQ), 0, lc.st, A, n, j0, b, (cplx*)nullptr, w.err, lc.cs);
         launches += 1 + trsm_rec(lc, n, A, Q, j0, b, 0, 0);          // A_j <- A_j R1^-1
         gemm(1, Qj, 0, Qj, S + (size_t)j0 * n + j0, b, b, n, 0);     // second pass: G' = A_j^H A_j (close to the identity)
-        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(256), 0, lc.st, S, n, j0, b, A, w.err, lc.cs);   // R2; R_jj = R2 R1
+        hipLaunchKernelGGL(k_chol64, dim3(1, 1, lc.nb), dim3(64 * CHOL_NQ), 0, lc.st, S, n, j0, b, A, w.err, lc.cs);   // R2; R_jj = R2 R1
         launches += 1 + trsm_rec(lc, n, S, Q, j0, b, 0, 0);          // Q_j = A_j R2^-1
     }
     return launches;

@@ -37,6 +37,15 @@ __device__ __forceinline__ cplx u_cmul(cplx a, cplx b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 __device__ __forceinline__ cplx u_csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+// v[idx], idx in 0..3, as an OR of masked bit patterns (exact)
+__device__ __forceinline__ double u_pick4d(int idx, double v0, double v1, double v2, double v3) {
+    const long long m0 = idx == 0 ? -1ll : 0ll, m1 = idx == 1 ? -1ll : 0ll, m2 = idx == 2 ? -1ll : 0ll, m3 = idx == 3 ? -1ll : 0ll;
+    return __longlong_as_double((__double_as_longlong(v0) & m0) | (__double_as_longlong(v1) & m1) |
+                                (__double_as_longlong(v2) & m2) | (__double_as_longlong(v3) & m3));
+}
+__device__ __forceinline__ cplx u_pick4(int idx, cplx v0, cplx v1, cplx v2, cplx v3) {
+    return make_double2(u_pick4d(idx, v0.x, v1.x, v2.x, v3.x), u_pick4d(idx, v0.y, v1.y, v2.y, v3.y));
+}
 __device__ __forceinline__ double u_wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -642,6 +651,21 @@ __global__ __launch_bounds__(NT) void k_update_decide(DevModel dm, DevUpdateStat
             }
             if (tid < MSF * MSF) {             // lane (a, b) publishes delta[a][b] and G[c,c][a][b]
                 cplx dsel = make_double2(0.0, 0.0);
+                if constexpr (MSF == 4) {
+                    // O(3): lane (a, b) forms ITS entry only -- row a of e^{-dtau V'} and column b of e^{+dtau V} picked by selects, the four
+                    // terms in the same order as before (round 3 had every lane form all 16 entries and keep one: 256 dependent-issue
+                    // fp64 FMAs on the scalar leg of every proposal)
+                    const int la = tid >> 2, lb = tid & 3;
+                    cplx acc = make_double2(la == lb ? -1.0 : 0.0, 0.0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // (bit-mask picks: written as ?: chains the compiler turns them into a dynamically indexed array in scratch)
+                        const cplx r = u_pick4(la, emvNew[0][q], emvNew[1][q], emvNew[2][q], emvNew[3][q]);
+                        const cplx c = u_pick4(lb, evOld[q][0], evOld[q][1], evOld[q][2], evOld[q][3]);
+                        acc = u_cfma(r, c, acc);
+                    }
+                    dsel = acc;
+                } else {
 #pragma unroll
                 for (int a = 0; a < MSF; ++a)
 #pragma unroll
@@ -651,6 +675,7 @@ __global__ __launch_bounds__(NT) void k_update_decide(DevModel dm, DevUpdateStat
                         for (int q = 0; q < MSF; ++q) acc = u_cfma(emvNew[a][q], evOld[q][b], acc);
                         if (tid == a * MSF + b) dsel = acc;
                     }
+                }
                 *(cplx*)&sdec[2 * tid] = dsel;
                 *(cplx*)&sdec[2 * MSF * MSF + 2 * tid] = *(const cplx*)&scand[O_GCC + 2 * tid];
             }
