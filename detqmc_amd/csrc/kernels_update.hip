@@ -380,7 +380,18 @@ __global__ __launch_bounds__(NT) void k_update_decide(DevModel dm, DevUpdateStat
     fetch(pre, pu, pv, site, -1, cur, 0);
     // No global store happens inside the loop: a store followed by a load that may alias makes the compiler wait
     // for the store's round trip (s_waitcnt vmcnt(0)) before every prefetch.  The slice's field lives in LDS.
-    for (int t = tid; t < OPDIM * N; t += NT) sphi[t] = phik[t];
+    {   // eight loads in flight per thread (written as `sphi[t] = phik[t]` the loop compiles to load, s_waitcnt vmcnt(0), ds_write per
+        // element: seven dependent trips to memory in front of the first proposal of an O(3) L = 24 launch)
+        constexpr int UB = 8;
+        const int total = OPDIM * N;
+        for (int base = tid; base < total; base += UB * NT) {
+            double r[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) r[u] = phik[min(base + u * NT, total - 1)];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { const int t = base + u * NT; if (t < total) sphi[t] = r[u]; }
+        }
+    }
     int cnd_nI = 0;                                // nI the u/v registers were loaded for
     [[maybe_unused]] unsigned long long win_cur = cur;      // PROP != 0: cursor the current candidate's window of uniforms starts at
     // PROP 2 / 3: the Box-Muller stack of NormalDistribution (normaldistribution.h:44-78) -- after a pair has been generated its first
