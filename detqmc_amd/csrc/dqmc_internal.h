@@ -160,6 +160,7 @@ struct GemmArgs {
     // split-K (skinny products with a long contraction index, e.g. Q_prev^H A_j of the block Gram-Schmidt QR: few output tiles, K = n):
     // ksplit > 1 slices of K are computed by separate workgroups into part[slice][N][M] and summed in a fixed order by a second kernel
     int ksplit; cplx* part;
+    size_t part_count;          // capacity of part in complex numbers (0: eight slices of M x N, the round-3 contract)
     int tag;                    // 1: a product inside a factorisation (LU trailing update, triangular solve) -- same code, its own kernel
                                 // name (template argument), so that profiles keep it apart from the model's n_g^3 products
 };

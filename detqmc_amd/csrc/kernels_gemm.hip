@@ -623,11 +623,14 @@ static void launch_gemm_tagged(const Launch& lc, const GemmArgs& a) {
     } else {
         const int t = ((a.M + 31) / 32) * ((a.N + 31) / 32);
         dim3 grid = (lc.nb % 8 == 0) ? dim3(t * lc.nb, 1, 1) : dim3(t, 1, lc.nb);
-        // split-K: few tiles, long contraction, a scratch buffer offered and no epilogue scaling -> slices of >= 256 k until ~ 256
-        // workgroups are in flight
+        // split-K: few tiles, long contraction, a scratch buffer offered and no epilogue scaling -> slices of >= 64 k until ~ 512
+        // workgroups are in flight (a workgroup's k loop is a chain of dependent trips to memory, 16 k per trip: a slice of 288 k took
+        // 30 us whatever the tile count; round 3 split into at most 8 slices of >= 256 k and only below 128 tiles)
         int ks = 1;
-        if (a.part && a.K >= 1024 && !a.Kdev && !a.kscale && !a.rowscale && !a.colscale && !a.b_lower && (long)t * lc.nb < 128) {
-            ks = (int)std::min<long>(std::min<long>(8, a.K / 256), (256 + (long)t * lc.nb - 1) / ((long)t * lc.nb));
+        const long wg = (long)t * lc.nb;
+        if (a.part && a.K >= 512 && !a.Kdev && !a.kscale && !a.rowscale && !a.colscale && !a.b_lower && wg < 256) {
+            const long cap = (long)((a.part_count ? a.part_count : (size_t)a.M * a.N * 8) / ((size_t)a.M * a.N));
+            ks = (int)std::min<long>(std::min<long>(std::min<long>(32, cap), a.K / 64), (512 + wg - 1) / wg);
             if (ks < 2) ks = 1;
         }
         if (ks > 1) {

@@ -1016,7 +1016,7 @@ int run_qr_bgs(const Launch& lc, int n, cplx* A, cplx* Q, const QrWork& w) {
         GemmArgs g = GemmArgs();
         g.A = Am; g.lda = n; g.opA = opA; g.B = Bm; g.ldb = n; g.opB = opB; g.C = Cm; g.ldc = n;
         g.M = M; g.N = N; g.K = K; g.Kmul = 1; g.accumulate = sub; g.negate = sub; g.tag = 1;
-        if (w.part && (size_t)M * N * 8 <= w.part_count) g.part = w.part;      // split-K scratch: the skinny Q^H A / Gram products
+        if (w.part && (size_t)M * N * 2 <= w.part_count) { g.part = w.part; g.part_count = w.part_count; }      // split-K scratch: the skinny Q^H A / Gram products and the long-K panel updates
         launch_gemm(lc, g);
         ++launches;
     };
