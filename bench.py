@@ -52,7 +52,7 @@ CONFIGS = {
     "o2_L16_b20": dict(workload=dict(opdim=2, L=16, beta=20.0, delaySteps=32), batch=256, sub=4,
                        label="SDW-O2 L=16 beta=20", text="DetSDW O(2) L=16 beta=20 dtau=0.1 s=10"),
     # no magnetic flux: the reference refuses weakZflux for opdim = 3 (src/detsdwparams.cpp:57-60), and so does detsdw_create
-    "o3_L24_b20": dict(workload=dict(opdim=3, L=24, beta=20.0, delaySteps=16), batch=8, sub=2,     # 8 chains in two contexts: 1.46 against 1.29 in one (round 3)
+    "o3_L24_b20": dict(workload=dict(opdim=3, L=24, beta=20.0, delaySteps=16), batch=8, sub=4,     # 8 chains in four contexts: 1.67 (two: 1.63, eight: 1.09; round 4, profiles/r04_bench_o3_L24_b20_pt8.json)
                        label="SDW-O3 L=24 beta=20", text="DetSDW O(3) L=24 beta=20 dtau=0.1 s=10 (no flux: the reference rejects O(3) + flux)",
                        ref_parts=True),
 }
